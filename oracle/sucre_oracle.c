@@ -1,0 +1,317 @@
+/*
+ * sucre_oracle.c -- CPU restatement of the SUCRe hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP engine in sucre_amd/csrc.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; nothing under sucre_amd/ may import, link or call it.
+ *
+ * It restates, in plain C and in the reference's own ragged data format (per-view lists of
+ * (u1, v1, cP, I), loader.py:33-53), the algorithm of clementinboittiaux/sucre:
+ *   - dense two-way matching           sfm.py:90-125, 154-175   (oracle_match_view)
+ *   - observation preparation          sfm.py:137, loader.py:87,113 (oracle_unproject)
+ *   - image-formation model + Adam fit sucre.py:52-82, 124-157  (oracle_fit)
+ *   - closed-form J                    sucre.py:66-77           (oracle_update_J)
+ *
+ * Pinning: the reference has no tests of its own, so the oracle is pinned against
+ * golden vectors produced by running the reference itself in the dev container
+ * (tests/golden/gen_golden.py -> tests/golden/<name>.npz; checked by tests/test_oracle_golden.py).
+ *
+ * Arithmetic notes (all verified against torch 2.10 CPU):
+ *   - a float32 (3x3)@(3xn) torch matmul is, per output element, the FMA chain
+ *     fma(a2,b2, fma(a1,b1, a0*b0)); dot3() below reproduces it bit for bit, so match sets are bit-exact.
+ *   - Tensor.long() of a float truncates toward zero; NaN / out-of-range give INT64_MIN (x86 cvttss2si).
+ *   - torch.optim.Adam (single-tensor, non-capturable branch) is restated in adam_step().
+ * Build with -ffp-contract=off: every fused multiply-add here is an explicit fmaf().
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int32_t H, W;
+    float K[9];     /* camera matrix                      sfm.py:62-73  */
+    float Kinv[9];  /* K.inverse() as torch computes it   sfm.py:92     */
+    float R[9];     /* world-from-camera rotation         sfm.py:32-40  */
+    float t[3];
+    float Rinv[9];  /* Pose.inverse(): R.T                sfm.py:42-47  */
+    float tinv[3];  /*                 -R.T @ t                          */
+} oracle_cam_t;
+
+int oracle_version(void) { return 1; }
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* one row of a float32 torch matmul with inner dimension 3 */
+static inline float dot3(const float *a, float x, float y, float z) {
+    float acc = a[0] * x;
+    acc = fmaf(a[1], y, acc);
+    acc = fmaf(a[2], z, acc);
+    return acc;
+}
+
+/* sfm.py:90-93  cP = K^-1 @ (d * [u+0.5, v+0.5, 1]) */
+static inline void unproject(const oracle_cam_t *c, float u, float v, float d, float out[3]) {
+    const float x = d * (u + 0.5f), y = d * (v + 0.5f), z = d * 1.0f;
+    out[0] = dot3(c->Kinv + 0, x, y, z);
+    out[1] = dot3(c->Kinv + 3, x, y, z);
+    out[2] = dot3(c->Kinv + 6, x, y, z);
+}
+
+/* sfm.py:49-55  R @ P + t */
+static inline void rigid(const float *R, const float *t, const float p[3], float out[3]) {
+    out[0] = dot3(R + 0, p[0], p[1], p[2]) + t[0];
+    out[1] = dot3(R + 3, p[0], p[1], p[2]) + t[1];
+    out[2] = dot3(R + 6, p[0], p[1], p[2]) + t[2];
+}
+
+/* Tensor.long() on x86 */
+static inline int64_t to_long(float x) {
+    if (!(x > -9.2233720368547758e18f && x < 9.2233720368547758e18f)) return INT64_MIN;
+    return (int64_t)x;
+}
+
+/* sfm.py:103-107 + 116-117: world point -> integer pixel of camera c, 1 if inside the image */
+static inline int project_px(const oracle_cam_t *c, const float wP[3], int64_t *u, int64_t *v) {
+    float cP[3], cp[3];
+    rigid(c->Rinv, c->tinv, wP, cP);
+    cp[0] = dot3(c->K + 0, cP[0], cP[1], cP[2]);
+    cp[1] = dot3(c->K + 3, cP[0], cP[1], cP[2]);
+    cp[2] = dot3(c->K + 6, cP[0], cP[1], cP[2]);
+    *u = to_long(cp[0] / cp[2]);
+    *v = to_long(cp[1] / cp[2]);
+    return (0 <= *u) && (*u < c->W) && (0 <= *v) && (*v < c->H);
+}
+
+/*
+ * Image.match_two_way (sfm.py:121-125) of image 1 against image 2, followed by d = depth2[v2,u2] (sfm.py:137).
+ * Outputs are in torch.where order of image 1 (row-major), sized for H1*W1 entries; any may be NULL.
+ * Returns the number of matches, or -1 on allocation failure.
+ */
+int64_t oracle_match_view(const float *depth1, const oracle_cam_t *c1, const float *depth2, const oracle_cam_t *c2,
+                          int16_t *u1o, int16_t *v1o, int16_t *u2o, int16_t *v2o, float *d2o) {
+    const int64_t n2 = (int64_t)c2->H * c2->W;
+    /* matches2.map(): where every pixel of image 2 lands in image 1, -1 = nowhere (sfm.py:154-159) */
+    int64_t *map = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)n2);
+    if (!map) return -1;
+    for (int64_t i = 0; i < 2 * n2; ++i) map[i] = -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < n2; ++p) {
+        const float d = depth2[p];
+        if (!(d > 0)) continue;
+        const int64_t v = p / c2->W, u = p % c2->W;
+        float cP[3], wP[3];
+        int64_t ub, vb;
+        unproject(c2, (float)u, (float)v, d, cP);
+        rigid(c2->R, c2->t, cP, wP);
+        if (project_px(c1, wP, &ub, &vb)) {
+            map[2 * p + 0] = vb;
+            map[2 * p + 1] = ub;
+        }
+    }
+    /* matches1 and the intersection (sfm.py:115-119, 171-175) */
+    int64_t n = 0;
+    for (int64_t v = 0; v < c1->H; ++v) {
+        for (int64_t u = 0; u < c1->W; ++u) {
+            const float d = depth1[v * c1->W + u];
+            if (!(d > 0)) continue;
+            float cP[3], wP[3];
+            int64_t uf, vf;
+            unproject(c1, (float)u, (float)v, d, cP);
+            rigid(c1->R, c1->t, cP, wP);
+            if (!project_px(c2, wP, &uf, &vf)) continue;
+            const int64_t q = vf * c2->W + uf;
+            if (map[2 * q + 0] != v || map[2 * q + 1] != u) continue;
+            if (u1o) u1o[n] = (int16_t)u;
+            if (v1o) v1o[n] = (int16_t)v;
+            if (u2o) u2o[n] = (int16_t)uf;
+            if (v2o) v2o[n] = (int16_t)vf;
+            if (d2o) d2o[n] = depth2[q];
+            ++n;
+        }
+    }
+    free(map);
+    return n;
+}
+
+/* loader.py:113  cP = image.unproject_depth(u2, v2, d), u2/v2 int16; cP is (3,n) row-major */
+void oracle_unproject(const oracle_cam_t *c, const int16_t *u, const int16_t *v, const float *d, int64_t n, float *cP) {
+    for (int64_t i = 0; i < n; ++i) {
+        float p[3];
+        unproject(c, (float)u[i], (float)v[i], d[i], p);
+        cP[i] = p[0];
+        cP[n + i] = p[1];
+        cP[2 * n + i] = p[2];
+    }
+}
+
+/* loader.py:87  I = rgb[v2,u2].T with rgb = uint8/255 (loader.py:157,163); rgb is (H,W,3) uint8, I is (3,n) */
+void oracle_gather_rgb(const uint8_t *rgb, int W, const int16_t *u, const int16_t *v, int64_t n, float *I) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c)
+            I[c * n + i] = (float)((double)rgb[((int64_t)v[i] * W + u[i]) * 3 + c] / 255.0);
+}
+
+/* sucre.py:53 */
+static inline float norm3(const float *cP, int64_t n, int64_t i) {
+    const float x = cP[i], y = cP[n + i], z = cP[2 * n + i];
+    return sqrtf(x * x + y * y + z * z);
+}
+
+/*
+ * SUCRe.update_J (sucre.py:66-77): J = sum_k (I-b)*a / sum_k a^2, one view at a time, float32.
+ * J is (H,W,3); pixels without observation become 0/0 = NaN.  Returns -1 on allocation failure.
+ */
+int oracle_update_J(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                    const int16_t *const *vs, const float *const *cPs, const float *const *Is,
+                    const float *params, float *J) {
+    const size_t npx = (size_t)H * W * 3;
+    float *num = (float *)calloc(npx, sizeof(float)), *den = (float *)calloc(npx, sizeof(float));
+    if (!num || !den) { free(num); free(den); return -1; }
+    const float *B = params, *beta = params + 3, *gamma = params + 6;
+    for (int s = 0; s < n_samples; ++s) {
+        const int64_t n = counts[s];
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            const float z = norm3(cPs[s], n, i);
+            const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
+            for (int c = 0; c < 3; ++c) {
+                const float a = expf(-beta[c] * z);
+                const float b = B[c] * (1.0f - expf(-gamma[c] * z));
+                num[px + c] += (Is[s][c * n + i] - b) * a;
+                den[px + c] += a * a;
+            }
+        }
+    }
+    for (size_t i = 0; i < npx; ++i) J[i] = num[i] / den[i];
+    free(num);
+    free(den);
+    return 0;
+}
+
+/* torch/optim/adam.py::_single_tensor_adam, non-capturable, no amsgrad / weight decay */
+typedef struct { float w1, beta2, w2, step_size_neg, bc2_sqrt, eps; } adam_coef_t;
+
+static adam_coef_t adam_coef(int step, double lr, double beta1, double beta2, double eps) {
+    adam_coef_t c;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    c.w1 = (float)(1.0 - beta1);
+    c.beta2 = (float)beta2;
+    c.w2 = (float)(1.0 - beta2);
+    c.step_size_neg = (float)(-(lr / bc1));
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.eps = (float)eps;
+    return c;
+}
+
+static inline void adam_step(float *p, float *m, float *v, float g, const adam_coef_t *c) {
+    *m = fmaf(c->w1, g - *m, *m);                 /* exp_avg.lerp_(grad, 1-beta1)                    */
+    *v = (*v * c->beta2) + (c->w2 * g) * g;       /* exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)  */
+    const float denom = sqrtf(*v) / c->bc2_sqrt + c->eps;
+    *p = *p + (c->step_size_neg * *m) / denom;    /* param.addcdiv_(exp_avg, denom, value=-step_size) */
+}
+
+/*
+ * sucre.adam (sucre.py:124-157) on the reference's observation lists.
+ *   J       (H,W,3) float32; J-parameter mode: in = rgb1 with NaN where depth1<=0 (sucre.py:46-49), out = fitted.
+ *           closed-form mode: output only (final update_J, sucre.py:156).
+ *   params  B[3], beta[3], gamma[3] in/out (init 0.1, sucre.py:41-43).
+ *   trace   num_iter x 10 doubles: cost (sum of squared residuals before the step, sucre.py:144-146) and the
+ *           nine parameters after the step.
+ * Gradient of L = sum r^2 / (3 n_obs) is analytic; the nine global sums and the cost are
+ * accumulated in double, per-pixel J gradients in float32.
+ */
+int oracle_fit(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+               const int16_t *const *vs, const float *const *cPs, const float *const *Is,
+               float *J, float *params, int num_iter, double lr, int use_closed_form, double *trace) {
+    const size_t npx = (size_t)H * W * 3;
+    int64_t n_obs = 0;
+    for (int s = 0; s < n_samples; ++s) n_obs += counts[s];
+    float *gJ = (float *)calloc(npx, sizeof(float));
+    float *mJ = (float *)calloc(npx, sizeof(float)), *vJ = (float *)calloc(npx, sizeof(float));
+    float **zs = (float **)calloc((size_t)n_samples, sizeof(float *));
+    if (!gJ || !mJ || !vJ || !zs) return -1;
+    for (int s = 0; s < n_samples; ++s) {
+        zs[s] = (float *)malloc(sizeof(float) * (size_t)(counts[s] > 0 ? counts[s] : 1));
+        if (!zs[s]) return -1;
+        for (int64_t i = 0; i < counts[s]; ++i) zs[s][i] = norm3(cPs[s], counts[s], i);
+    }
+    float mP[9] = {0}, vP[9] = {0};
+    /* (loss / n_obs / 3).backward(): d/dloss = (1/3)/n_obs in float32 (sucre.py:145) */
+    const float scale = (1.0f / 3.0f) / (float)n_obs;
+    float *B = params, *beta = params + 3, *gamma = params + 6;
+
+    for (int it = 0; it < num_iter; ++it) {
+        if (use_closed_form &&
+            oracle_update_J(H, W, n_samples, counts, us, vs, cPs, Is, params, J) != 0) return -1;
+        memset(gJ, 0, sizeof(float) * npx);
+        double gB[3] = {0, 0, 0}, gbeta[3] = {0, 0, 0}, ggamma[3] = {0, 0, 0}, cost = 0.0;
+        for (int s = 0; s < n_samples; ++s) {
+            const int64_t n = counts[s];
+            double tB[3] = {0, 0, 0}, tb[3] = {0, 0, 0}, tg[3] = {0, 0, 0}, tc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : tB[:3], tb[:3], tg[:3], tc)
+            for (int64_t i = 0; i < n; ++i) {
+                const float z = zs[s][i];
+                const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
+                for (int c = 0; c < 3; ++c) {
+                    const float a = expf(-beta[c] * z);
+                    const float g = expf(-gamma[c] * z);
+                    const float Jc = J[px + c];
+                    const float Ihat = Jc * a + B[c] * (1.0f - g);      /* sucre.py:79-82, l = 1 */
+                    const float r = Is[s][c * n + i] - Ihat;
+                    const float dr = -2.0f * r * scale;                 /* dL/dIhat */
+                    tc += (double)r * (double)r;
+                    if (!use_closed_form) gJ[px + c] += dr * a;          /* unique (v,u) within one view */
+                    tB[c] += (double)(dr * (1.0f - g));
+                    tb[c] += (double)(dr * Jc * a * -z);
+                    tg[c] += (double)(dr * B[c] * g * z);
+                }
+            }
+            for (int c = 0; c < 3; ++c) { gB[c] += tB[c]; gbeta[c] += tb[c]; ggamma[c] += tg[c]; }
+            cost += tc;
+        }
+        const adam_coef_t co = adam_coef(it + 1, lr, 0.9, 0.999, 1e-8);
+        for (int c = 0; c < 3; ++c) {
+            adam_step(&B[c], &mP[c], &vP[c], (float)gB[c], &co);
+            adam_step(&beta[c], &mP[3 + c], &vP[3 + c], (float)gbeta[c], &co);
+            adam_step(&gamma[c], &mP[6 + c], &vP[6 + c], (float)ggamma[c], &co);
+        }
+        if (!use_closed_form) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
+        }
+        if (trace) {
+            trace[it * 10] = cost;
+            for (int k = 0; k < 9; ++k) trace[it * 10 + 1 + k] = (double)params[k];
+        }
+    }
+    int rc = 0;
+    if (use_closed_form) rc = oracle_update_J(H, W, n_samples, counts, us, vs, cPs, Is, params, J);
+    for (int s = 0; s < n_samples; ++s) free(zs[s]);
+    free(zs); free(gJ); free(mJ); free(vJ);
+    return rc;
+}
+
+/* SUCRe.__init__ (sucre.py:46-49): J0 = rgb (uint8/255), NaN where depth <= 0 */
+void oracle_init_J(const uint8_t *rgb, const float *depth, int H, int W, float *J) {
+    for (int64_t p = 0; p < (int64_t)H * W; ++p)
+        for (int c = 0; c < 3; ++c)
+            J[p * 3 + c] = (depth[p] <= 0) ? NAN : (float)((double)rgb[p * 3 + c] / 255.0);
+}

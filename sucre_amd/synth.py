@@ -1,0 +1,186 @@
+"""Seeded synthetic underwater scenes.
+
+Build-owned generator, used by the golden-fixture script, the tests and ``bench.py``.  Everything is derived
+from a counter-based integer hash, evaluated in float64 and then quantised exactly the way the reference's
+loaders see real data:
+
+* depth maps are uint16 millimetres (``loader.py:167-170`` of the reference divides the PNG by 1000 in
+  float64 and casts to float32),
+* colour images are uint8 (``loader.py:157,163``: ``uint8 / 255`` in float64, cast to float32),
+* poses are world-from-camera ``(R 3x3, t 3x1)`` float32, cameras are PINHOLE ``K`` float32
+  (``sfm.py:32-78,186-222``).
+
+The scene is a seabed height field seen by downward-looking cameras on a lawn-mower grid, coloured by an
+albedo pattern pushed through the image-formation model ``I = J*exp(-beta*z) + B*(1-exp(-gamma*z))`` with
+known water parameters, so a restoration has a ground truth to converge towards.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+GT_B = (0.05, 0.25, 0.35)
+GT_BETA = (0.6, 0.2, 0.15)
+GT_GAMMA = (0.7, 0.3, 0.2)
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash_u32(x: torch.Tensor) -> torch.Tensor:
+    """32-bit integer mixer on int64 tensors (same bits on CPU and GPU)."""
+    x = x & _M32
+    x = ((x ^ (x >> 16)) * 0x7FEB352D) & _M32
+    x = ((x ^ (x >> 15)) * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    return x
+
+
+def _uniform(idx: torch.Tensor, stream: int, seed: int) -> torch.Tensor:
+    """Uniform (0,1) float64 from integer counters."""
+    h = _hash_u32(idx * 0x9E3779B1 + (stream * 0x85EBCA6B + seed * 0xC2B2AE35 + 0x27D4EB2F))
+    h = _hash_u32(h + 0x165667B1)
+    return (h.to(torch.float64) + 0.5) / 4294967296.0
+
+
+def _normal_host(n: int, stream: int, seed: int) -> np.ndarray:
+    idx = torch.arange(n, dtype=torch.int64)
+    u1 = _uniform(idx, 2 * stream, seed).numpy()
+    u2 = _uniform(idx, 2 * stream + 1, seed).numpy()
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def _rodrigues(w: np.ndarray) -> np.ndarray:
+    theta = float(np.linalg.norm(w))
+    Wx = np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+    if theta < 1e-12:
+        return np.eye(3) + Wx
+    return np.eye(3) + math.sin(theta) / theta * Wx + (1.0 - math.cos(theta)) / theta ** 2 * (Wx @ Wx)
+
+
+@dataclass
+class SynthView:
+    name: str
+    R: torch.Tensor          # (3,3) float32 world-from-camera rotation
+    t: torch.Tensor          # (3,1) float32 world-from-camera translation
+    depth_u16: torch.Tensor  # (H,W) int32 holding uint16 millimetres (0 = invalid)
+    rgb_u8: torch.Tensor     # (H,W,3) uint8
+
+    def depth_f32(self) -> torch.Tensor:
+        """float32(float64(mm)/1000): what the reference's load_depth_map returns."""
+        return (self.depth_u16.to(torch.float64) / 1000.0).to(torch.float32)
+
+    def rgb_f32(self) -> torch.Tensor:
+        """float32(float64(u8)/255): what the reference's load_rgb returns."""
+        return (self.rgb_u8.to(torch.float64) / 255.0).to(torch.float32)
+
+
+@dataclass
+class SynthScene:
+    width: int
+    height: int
+    K: torch.Tensor                      # (3,3) float32
+    views: list[SynthView] = field(default_factory=list)
+    target: int = 0                      # index of the image to restore inside ``views``
+    seed: int = 0
+
+    @property
+    def names(self) -> list[str]:
+        return [v.name for v in self.views]
+
+
+def _seabed(x: torch.Tensor, y: torch.Tensor, relief: float) -> torch.Tensor:
+    return 3.0 + relief * torch.sin(1.3 * x) * torch.cos(0.9 * y)
+
+
+def _albedo(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Smooth, strictly positive albedo in [0.15, 0.9], one (..,3) plane."""
+    chans = []
+    for c, (fx, fy, ph) in enumerate(((2.1, 1.7, 0.3), (1.6, 2.3, 1.1), (2.7, 1.9, 2.0))):
+        a = 0.525 + 0.25 * torch.sin(fx * x + ph) * torch.cos(fy * y - 0.5 * ph) \
+            + 0.125 * torch.sin(5.3 * x + 3.1 * y + c)
+        chans.append(a)
+    return torch.stack(chans, dim=-1)
+
+
+def render_view(K: torch.Tensor, R: np.ndarray, t: np.ndarray, width: int, height: int, view_id: int,
+                seed: int, relief: float, invalid_frac: float, device: str | torch.device = 'cpu'):
+    """Ray-cast one camera against the seabed -> (depth mm as int32, rgb uint8)."""
+    dev = torch.device(device)
+    f64 = torch.float64
+    fx, fy, cx, cy = (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
+    v, u = torch.meshgrid(torch.arange(height, device=dev, dtype=f64),
+                          torch.arange(width, device=dev, dtype=f64), indexing='ij')
+    dx = (u + 0.5 - cx) / fx
+    dy = (v + 0.5 - cy) / fy
+    Rt = torch.tensor(R, dtype=f64, device=dev)
+    wx = Rt[0, 0] * dx + Rt[0, 1] * dy + Rt[0, 2]
+    wy = Rt[1, 0] * dx + Rt[1, 1] * dy + Rt[1, 2]
+    wz = Rt[2, 0] * dx + Rt[2, 1] * dy + Rt[2, 2]
+    ox, oy, oz = float(t[0]), float(t[1]), float(t[2])
+    s = (3.0 - oz) / wz
+    for _ in range(8):  # fixed point on the ray parameter; |grad h| <= 0.2 so it contracts fast
+        s = (_seabed(ox + s * wx, oy + s * wy, relief) - oz) / wz
+    X, Y = ox + s * wx, oy + s * wy
+    depth_mm = torch.round(s * 1000.0)
+    ok = (depth_mm >= 1) & (depth_mm <= 65535) & (wz > 0)
+    pix = (torch.arange(height * width, device=dev, dtype=torch.int64).view(height, width)
+           + view_id * 0x1000193)
+    ok &= _uniform(pix, 7, seed) >= invalid_frac
+    depth_mm = torch.where(ok, depth_mm, torch.zeros_like(depth_mm)).to(torch.int32)
+    rng = s * torch.sqrt(dx * dx + dy * dy + 1.0)
+    alb = _albedo(X, Y)
+    B = torch.tensor(GT_B, dtype=f64, device=dev)
+    beta = torch.tensor(GT_BETA, dtype=f64, device=dev)
+    gamma = torch.tensor(GT_GAMMA, dtype=f64, device=dev)
+    img = alb * torch.exp(-beta * rng[..., None]) + B * (1.0 - torch.exp(-gamma * rng[..., None]))
+    noise = (_uniform(pix, 11, seed) - 0.5)[..., None] * (1.5 / 255.0)
+    rgb = torch.clamp(torch.round((img + noise) * 255.0), 0, 255).to(torch.uint8)
+    return depth_mm, rgb
+
+
+def make_scene(width: int, height: int, n_neighbours: int, seed: int = 0, relief: float = 0.15,
+               spacing: float = 0.1, invalid_frac: float = 0.01, rot_sigma: float = 0.03,
+               pos_sigma: float = 0.1, device: str | torch.device = 'cpu',
+               far_views: int = 0) -> SynthScene:
+    """A target camera plus its ``n_neighbours`` nearest grid neighbours (+ optional far, non-overlapping
+    views that exercise the ``min_cover`` rule of ``sfm.py:136``).
+
+    Cameras sit on a lawn-mower grid whose pitch is ``spacing`` x the image footprint at the nominal 3 m
+    altitude, each perturbed by twist noise (``rot_sigma`` rad, ``pos_sigma`` x pitch-normalised metres).
+    Views are returned sorted by name (the order the reference's HDF5 groups iterate in).
+    """
+    fxy = 0.78 * width
+    K = torch.tensor([[fxy, 0.0, width / 2.0], [0.0, fxy, height / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    foot_w = 3.0 * width / fxy
+    foot_h = 3.0 * height / fxy
+    # grid offsets sorted by normalised centre distance; offset (0,0) is the target itself
+    r = int(math.ceil(math.sqrt(n_neighbours + 1))) + 2
+    offs = [(i, j) for j in range(-r, r + 1) for i in range(-r, r + 1)]
+    offs.sort(key=lambda ij: (ij[0] * ij[0] + ij[1] * ij[1], ij[1], ij[0]))
+    offs = offs[:n_neighbours + 1]
+    for f in range(far_views):
+        offs.append((int(3.0 / spacing) + 5 * (f + 1), 0))
+    n = len(offs)
+    nw = _normal_host(3 * n, 1, seed).reshape(n, 3) * rot_sigma
+    npos = _normal_host(3 * n, 2, seed).reshape(n, 3) * pos_sigma
+    # boustrophedon numbering so names follow the survey path, not the distance order
+    order = sorted(range(n), key=lambda q: (offs[q][1], offs[q][0] if offs[q][1] % 2 == 0 else -offs[q][0]))
+    views: list[SynthView] = []
+    target = -1
+    for rank, q in enumerate(order):
+        i, j = offs[q]
+        R = _rodrigues(nw[q])
+        t = np.array([i * spacing * foot_w + npos[q, 0] * spacing * foot_w,
+                      j * spacing * foot_h + npos[q, 1] * spacing * foot_h,
+                      0.0 + npos[q, 2] * 0.5])
+        R32 = torch.tensor(R, dtype=torch.float32)
+        t32 = torch.tensor(t, dtype=torch.float32).view(3, 1)
+        depth_mm, rgb = render_view(K, R32.double().numpy(), t32.double().numpy().ravel(), width, height,
+                                    view_id=q, seed=seed, relief=relief, invalid_frac=invalid_frac, device=device)
+        views.append(SynthView(name=f'img_{rank:04d}.png', R=R32, t=t32, depth_u16=depth_mm, rgb_u8=rgb))
+        if (i, j) == (0, 0):
+            target = rank
+    return SynthScene(width=width, height=height, K=K, views=views, target=target, seed=seed)

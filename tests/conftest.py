@@ -1,0 +1,19 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / 'tests'):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session', params=['plane_64x48_n4', 'relief_96x64_n6'])
+def golden(request):
+    import helpers
+    return helpers.load_fixture(request.param)

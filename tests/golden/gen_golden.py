@@ -1,0 +1,85 @@
+"""Generates tests/golden/*.npz by running the REAL reference (/root/reference) on synthetic scenes.
+
+Run in the dev container only:  python tests/golden/gen_golden.py
+A fixture is data: the synthetic inputs (uint8 colour, uint16-mm depth, poses, K) and what the reference
+computed from them (match sets, J after 1/5/200 Adam steps, per-iteration cost and water parameters, closed-form
+results).  No reference source is stored.  Generated with torch 2.10.0 CPU, 8 threads.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+sys.path.insert(0, str(HERE))
+
+import ref_harness as rh  # noqa: E402
+from sucre_amd import synth  # noqa: E402
+
+FIXTURES = {
+    # name: (width, height, n_neighbours, seed, relief, far_views)
+    'plane_64x48_n4': (64, 48, 4, 0, 0.0, 1),
+    'relief_96x64_n6': (96, 64, 6, 1, 0.15, 1),
+}
+
+
+def dense_match_map(rec, H, W, W2):
+    m = np.full((H, W), -1, np.int32)
+    m[rec['v1'].numpy().astype(np.int64), rec['u1'].numpy().astype(np.int64)] = \
+        rec['v2'].numpy().astype(np.int32) * W2 + rec['u2'].numpy().astype(np.int32)
+    return m
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def generate(name, spec):
+    W, H, nn, seed, relief, far = spec
+    scene = synth.make_scene(W, H, nn, seed=seed, relief=relief, far_views=far)
+    out = dict(width=W, height=H, seed=seed, relief=relief, n_neighbours=nn, far_views=far, target=scene.target,
+               K=scene.K.numpy(), names=np.array(scene.names),
+               R=np.stack([v.R.numpy() for v in scene.views]), t=np.stack([v.t.numpy() for v in scene.views]),
+               depth_u16=np.stack([v.depth_u16.numpy().astype(np.uint16) for v in scene.views]),
+               rgb_u8=np.stack([v.rgb_u8.numpy() for v in scene.views]))
+    per_view, md, target = rh.reference_matches(scene, min_cover=1e-6)
+    out['kept'] = np.array([r['kept'] for r in per_view])
+    out['n_matches'] = np.array([len(r['u1']) for r in per_view], np.int64)
+    out['match_map'] = np.stack([dense_match_map(r, H, W, W) for r in per_view])
+    out['n_obs'] = np.int64(len(md))
+    fit = quiet(rh.reference_fit, scene, md, target, num_iter=200, snapshots=(1, 5), batch_size=5)
+    out['J_param_200'] = fit['J']
+    out['J_param_1'] = fit['snaps'][1]
+    out['J_param_5'] = fit['snaps'][5]
+    out['trace_param'] = fit['trace']
+    fitc = quiet(rh.reference_fit, scene, md, target, num_iter=200, use_closed_form=True, batch_size=5)
+    out['J_closed_200'] = fitc['J']
+    out['trace_closed'] = fitc['trace']
+    # closed-form J straight from the initial parameters (update_J alone, sucre.py:66-77)
+    _, _, _, sucre_mod = rh.import_reference()
+    model = sucre_mod.SUCRe(image=target, use_closed_form=True)
+    model.update_J(md)
+    out['J_closed_init'] = model.J.numpy().copy()
+    # a stricter min_cover drops real views (sfm.py:136)
+    per_view2, md2, _ = rh.reference_matches(scene, min_cover=0.8)
+    out['kept_cover80'] = np.array([r['kept'] for r in per_view2])
+    out['n_obs_cover80'] = np.int64(len(md2))
+    fit2 = quiet(rh.reference_fit, scene, md2, target, num_iter=50, batch_size=5)
+    out['J_param_50_cover80'] = fit2['J']
+    out['trace_param_cover80'] = fit2['trace']
+    np.savez_compressed(HERE / f'{name}.npz', **out)
+    print(name, 'views', len(scene.views), 'n_obs', int(out['n_obs']), 'kept', out['kept'].tolist(),
+          'kept@0.8', out['kept_cover80'].tolist(), 'size', (HERE / f'{name}.npz').stat().st_size)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    for name, spec in FIXTURES.items():
+        generate(name, spec)

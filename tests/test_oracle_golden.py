@@ -1,0 +1,89 @@
+"""Pins the CPU oracle (oracle/sucre_oracle.c) to golden vectors computed by the reference itself.
+
+The reference ships no tests; tests/golden/*.npz were produced by importing the reference
+in the dev container (tests/golden/gen_golden.py).  Bars: match sets bit-exact; J within 1e-6 RMS of the
+reference in J-parameter mode (the reference's own summation-order noise is ~5e-8) and 1e-4 in closed-form mode.
+"""
+import numpy as np
+
+import helpers
+from oracle import oracle
+
+
+def test_synthetic_generator_reproduces_fixture_inputs(golden):
+    """The seeded generator must give the same scene on every machine (bench/test inputs depend on it)."""
+    from sucre_amd import synth
+    z = golden.z
+    scene = synth.make_scene(int(z['width']), int(z['height']), int(z['n_neighbours']), seed=int(z['seed']),
+                             relief=float(z['relief']), far_views=int(z['far_views']))
+    assert scene.target == golden.scene.target
+    for a, b in zip(scene.views, golden.scene.views):
+        assert a.name == b.name
+        assert np.array_equal(a.R.numpy(), b.R.numpy()) and np.array_equal(a.t.numpy(), b.t.numpy())
+        # quantised renders: allow a vanishing number of rounding flips across libm builds
+        assert (a.depth_u16 != b.depth_u16).float().mean() < 1e-4
+        assert (a.rgb_u8 != b.rgb_u8).float().mean() < 1e-4
+
+
+def test_matching_bit_exact(golden):
+    per_view, _ = helpers.oracle_scene_samples(golden.scene)
+    assert [k for _, k, _ in per_view] == golden['kept'].tolist()
+    for k, (name, kept, m) in enumerate(per_view):
+        u1, v1, u2, v2 = golden.match_lists(k)
+        assert len(m) == int(golden['n_matches'][k]), name
+        assert np.array_equal(m.u1, u1) and np.array_equal(m.v1, v1), name
+        assert np.array_equal(m.u2, u2) and np.array_equal(m.v2, v2), name
+        d2 = golden.scene.views[k].depth_f32().numpy()[v2.astype(np.int64), u2.astype(np.int64)]
+        assert np.array_equal(m.d, d2), name
+
+
+def test_min_cover_rule(golden):
+    per_view, samples = helpers.oracle_scene_samples(golden.scene, min_cover=0.8)
+    assert [k for _, k, _ in per_view] == golden['kept_cover80'].tolist()
+    assert sum(len(s[0]) for s in samples) == int(golden['n_obs_cover80'])
+
+
+def _fit(golden, num_iter, closed=False, min_cover=1e-6):
+    sc = golden.scene
+    _, samples = helpers.oracle_scene_samples(sc, min_cover=min_cover)
+    tgt = sc.views[sc.target]
+    J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    return oracle.fit(sc.height, sc.width, samples, J0, num_iter=num_iter, use_closed_form=closed)
+
+
+def test_fit_J_parameter_mode(golden):
+    for T, key in ((1, 'J_param_1'), (5, 'J_param_5'), (200, 'J_param_200')):
+        J, params, trace = _fit(golden, T)
+        ref = golden[key]
+        assert np.array_equal(np.isnan(J), np.isnan(ref))
+        assert helpers.rms_per_channel(J, ref).max() < 1e-6, (T, helpers.rms_per_channel(J, ref))
+        rt = golden['trace_param'][:T]
+        assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 2e-6
+        assert np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 2e-5
+
+
+def test_fit_closed_form_mode(golden):
+    J, params, trace = _fit(golden, 200, closed=True)
+    ref = golden['J_closed_200']
+    assert np.array_equal(np.isnan(J), np.isnan(ref))
+    assert helpers.rms_per_channel(J, ref).max() < 1e-4
+    rt = golden['trace_closed']
+    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 2e-4
+    assert np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 1e-4
+
+
+def test_update_J_closed_form(golden):
+    sc = golden.scene
+    _, samples = helpers.oracle_scene_samples(sc)
+    J = oracle.update_J(sc.height, sc.width, samples, np.full(9, 0.1, np.float32))
+    ref = golden['J_closed_init']
+    assert np.array_equal(np.isnan(J), np.isnan(ref))
+    assert helpers.rms_per_channel(J, ref).max() < 1e-6
+
+
+def test_fit_with_dropped_views(golden):
+    J, _, trace = _fit(golden, 50, min_cover=0.8)
+    ref = golden['J_param_50_cover80']
+    assert np.array_equal(np.isnan(J), np.isnan(ref))
+    assert helpers.rms_per_channel(J, ref).max() < 1e-6
+    assert np.abs(trace[:, 1:] - golden['trace_param_cover80'][:, 1:]).max() < 2e-6
