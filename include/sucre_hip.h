@@ -1,0 +1,146 @@
+/*
+ * sucre_hip.h -- C ABI of libsucre_hip.so, the MI355X (gfx950) engine for the SUCRe hot path.
+ *
+ * The reference (clementinboittiaux/sucre) is pure Python and has no FFI layer; its boundary for this path is
+ * the Python surface   sfm.Image.match_images (sfm.py:127-138),  loader.MatchesFile.prepare_matches /
+ * load_matches (loader.py:78-118),  sucre.SUCRe.__init__/update_J/forward (sucre.py:36-82)  and
+ * sucre.adam (sucre.py:124-157).  A drop-in therefore binds these entry points with ctypes (INTEGRATION.md shows
+ * the stub); sucre_amd/{sfm,loader,sucre}.py is that binding, mirroring the reference's names and arguments.
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only.  Every `*_dev` / device pointer is HIP device memory owned by the
+ *     caller (e.g. a PyTorch-ROCm allocation); the library allocates no persistent device memory, performs no
+ *     host<->device copy of bulk data and never synchronises: every call only enqueues kernels on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream) and returns.
+ *   - Return value: 0 = OK, negative = error; sucre_last_error() gives the message for the calling thread.
+ *     No C++ exception crosses the ABI.  All arguments are validated before anything is launched.
+ *   - Re-entrant; no global mutable state except the thread-local error string.  One host thread / process
+ *     per GPU; concurrent calls on different streams or devices are safe.
+ *   - All state of one restoration lives in ONE caller-allocated workspace of sucre_workspace_bytes() bytes,
+ *     256-byte aligned.  Its internal layout (observation store, Adam state, ...) is private; the few regions a
+ *     host needs to read back are located with sucre_ws_offset().
+ *
+ * Data layout in HBM: the target image is cut into 16x16-pixel tiles.  The observation
+ * store holds, for every (tile, view) pair, one 1792-byte chunk = 256 float32 ranges z=||cP|| (0 = no
+ * observation) + 256 x 3 uint8 colours, replacing the reference's 28-byte (u,v,cP,I) records
+ * (loader.py:33-53, 103-118) and its HDF5 spill.  J and the Adam moments are tile-major float32 planes.
+ */
+#ifndef SUCRE_HIP_H
+#define SUCRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUCRE_ABI_VERSION 1
+
+/* error codes */
+#define SUCRE_OK 0
+#define SUCRE_ERR_ARG (-1)      /* NULL / misaligned pointer, bad size            */
+#define SUCRE_ERR_RANGE (-2)    /* view index, iteration count ... out of range    */
+#define SUCRE_ERR_LAUNCH (-3)   /* HIP reported a launch error                     */
+
+/* fit flags */
+#define SUCRE_FIT_CLOSED_FORM 1u /* --use-closed-form: J is a closed-form buffer, sucre.py:66-77,141 */
+
+/*
+ * One view of the scene = the arguments the reference reads from an sfm.Image (sfm.py:81-88): depth map,
+ * colour image, camera, pose.  The 3x3 matrices are row-major float32 and must be computed by the caller the
+ * way the reference computes them (Kinv = K.inverse(), sfm.py:92; Rinv/tinv = Pose.inverse() = (R.T, -R.T@t),
+ * sfm.py:42-47) so that match sets are bit-identical to the reference's.
+ */
+typedef struct sucre_view {
+    const float *depth;   /* device, (H,W) float32 metres, <=0 = invalid   loader.py:166-170 */
+    const uint8_t *rgb;   /* device, (H,W,3) uint8                         loader.py:156-163 */
+    int32_t H, W;
+    float K[9];
+    float Kinv[9];
+    float R[9];           /* world-from-camera                              sfm.py:32-40      */
+    float t[3];
+    float Rinv[9];
+    float tinv[3];
+} sucre_view_t;
+
+/* workspace regions a host may read back (all written by the library) */
+enum {
+    SUCRE_WS_VIEW_COUNT = 0, /* uint64[n_views]  matches per view (before the min_cover rule), sfm.py:136 */
+    SUCRE_WS_VIEW_KEEP = 1,  /* uint32[n_views]  1 = view passed min_cover                                */
+    SUCRE_WS_N_OBS = 2,      /* uint64[1]        len(matches_data), sucre.py:135,202                       */
+    SUCRE_WS_PARAMS = 3,     /* float32[9]       B[3], beta[3], gamma[3], sucre.py:41-43                  */
+    SUCRE_WS_SUMS = 4,       /* float64[12]      reduced gradient sums of the last sucre_fit_grad (multi-GPU) */
+    SUCRE_WS_N_OBS_TOTAL = 5 /* uint64[1]        n_obs used for the 1/(3 n_obs) scale (shared-water: summed over ranks) */
+};
+
+int sucre_version(void);
+const char *sucre_last_error(void);
+
+/* Bytes of the workspace for an HxW target fitted against n_views views (0 on invalid arguments). */
+size_t sucre_workspace_bytes(int H, int W, int n_views);
+/* Byte offset of a SUCRE_WS_* region inside the workspace (-1 on invalid arguments). */
+int64_t sucre_ws_offset(int H, int W, int n_views, int region);
+
+/*
+ * Replaces Image.match_images (sfm.py:127-138) + MatchesFile.prepare_matches/load_matches (loader.py:78-118)
+ * for views k0 <= k < k1 of `views_dev` (a device array of n_views sucre_view_t): two-way depth-map matching
+ * (sfm.py:90-125, 154-175), d = depth2[v2,u2], cP = K2^-1 d [u2+.5, v2+.5, 1], z = ||cP|| (sucre.py:53),
+ * I = rgb2[v2,u2]; results go to the observation store of `ws`.  `target` is a HOST struct whose depth/rgb
+ * point to device memory.
+ */
+int sucre_match_views(void *ws, int H, int W, int n_views, const sucre_view_t *target,
+                      const sucre_view_t *views_dev, int k0, int k1, void *stream);
+
+/*
+ * The `len(matches) / (W*H) > min_cover` rule (sfm.py:136) for every view, n_obs, and the per-tile view lists
+ * the fit iterates over.  Call once after all sucre_match_views calls.
+ */
+int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream);
+
+/*
+ * SUCRe.__init__ (sucre.py:36-50): B, beta, gamma <- params0 (host, 9 floats; the reference uses 0.1),
+ * J <- rgb1/255 with NaN where depth1 <= 0, Adam moments <- 0.  If J0_dev != NULL it is an (H,W,3) float32
+ * warm start replacing rgb1/255 (--params-path, sucre.py:206-207).
+ */
+int sucre_fit_init(void *ws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
+                   const float *params0, const float *J0_dev, void *stream);
+
+/*
+ * sucre.adam (sucre.py:124-157): iterations t0+1 .. t0+T of torch.optim.Adam(lr, betas, eps) on {B,beta,gamma,J}
+ * (or {B,beta,gamma} with SUCRE_FIT_CLOSED_FORM), all enqueued without a host sync.  trace_dev (nullable) gets
+ * T x 10 float64: the cost sum r^2 the reference logs (sucre.py:146,150) and the nine parameters after the step.
+ * With SUCRE_FIT_CLOSED_FORM the final update_J of sucre.py:156 is included.
+ */
+int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr, double beta1, double beta2,
+                  double eps, unsigned flags, double *trace_dev, void *stream);
+
+/*
+ * The two halves of one iteration, for data-parallel runs where several GPUs share the water parameters:
+ * sucre_fit_grad leaves the reduced sums at SUCRE_WS_SUMS (float64[12]) so the host can all-reduce them
+ * (RCCL) before sucre_fit_step applies Adam to B, beta, gamma.  sucre_fit_run == T x (grad, step).
+ */
+int sucre_fit_grad(void *ws, int H, int W, int n_views, int step, double lr, double beta1, double beta2,
+                   double eps, unsigned flags, void *stream);
+int sucre_fit_step(void *ws, int H, int W, int n_views, int step, double lr, double beta1, double beta2,
+                   double eps, double *trace_row_dev, void *stream);
+/* Overrides the observation count used in the 1/(3 n_obs) gradient scale (sum over ranks). */
+int sucre_set_n_obs_total(void *ws, int H, int W, int n_views, uint64_t n_obs_total, void *stream);
+
+/* SUCRe.update_J(force_update=True) (sucre.py:66-77): closed-form J from the current parameters. */
+int sucre_update_J(void *ws, int H, int W, int n_views, void *stream);
+
+/* J as the reference lays it out: (H,W,3) float32 (sucre.py:213-215). */
+int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream);
+
+/*
+ * One view of the observation store as dense planes (inverse of the tiling): z (H,W) float32, 0 = no match,
+ * and rgb (H,W,3) uint8.  Either output may be NULL.  Used by tests and by the MatchesData compatibility shim.
+ */
+int sucre_export_view(const void *ws, int H, int W, int n_views, int k, float *z_dev, uint8_t *rgb_dev,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUCRE_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libsucre_hip.so (include/sucre_hip.h).
+
+The HIP library is the product: if it is missing or does not export the ABI this module raises -- there is no
+CPU or PyTorch fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+ABI_VERSION = 1
+LIB_PATH = Path(__file__).resolve().parent / 'libsucre_hip.so'
+
+FIT_CLOSED_FORM = 1
+WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)
+
+
+class SucreView(C.Structure):
+    """sucre_view_t"""
+    _fields_ = [('depth', C.c_void_p), ('rgb', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32),
+                ('K', C.c_float * 9), ('Kinv', C.c_float * 9), ('R', C.c_float * 9), ('t', C.c_float * 3),
+                ('Rinv', C.c_float * 9), ('tinv', C.c_float * 3)]
+
+
+assert C.sizeof(SucreView) == 192
+
+# name -> (restype, argtypes); mirrors include/sucre_hip.h one to one (tests/test_abi.py checks both ways)
+_i, _vp, _d, _u64 = C.c_int, C.c_void_p, C.c_double, C.c_uint64
+SIGNATURES = {
+    'sucre_version': (_i, []),
+    'sucre_last_error': (C.c_char_p, []),
+    'sucre_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
+    'sucre_ws_offset': (C.c_int64, [_i, _i, _i, _i]),
+    'sucre_match_views': (_i, [_vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_finalize_matches': (_i, [_vp, _i, _i, _i, _d, _vp]),
+    'sucre_fit_init': (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
+    'sucre_fit_run': (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp, _vp]),
+    'sucre_fit_grad': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp]),
+    'sucre_fit_step': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp]),
+    'sucre_set_n_obs_total': (_i, [_vp, _i, _i, _i, _u64, _vp]),
+    'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
+    'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sucre_export_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SucreError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SucreError(f'{LIB_PATH} is missing: build the gfx950 HIP library first '
+                         f'(make -C {LIB_PATH.parent / "csrc"}); there is no fallback path')
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.sucre_version() != ABI_VERSION:
+        raise SucreError(f'libsucre_hip.so has ABI {lib.sucre_version()}, expected {ABI_VERSION}: rebuild it')
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SucreError(f'libsucre_hip error {rc}: {load().sucre_last_error().decode()}')

@@ -1,0 +1,195 @@
+// extern "C" surface of libsucre_hip.so (include/sucre_hip.h): argument validation, error strings, launch order.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "launch.h"
+
+namespace sucre {
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return SUCRE_OK;
+    return fail(SUCRE_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+static bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+static int check_ws(const void *ws, int H, int W, int n_views, Layout *L) {
+    if (!make_layout(H, W, n_views, L))
+        return fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d (need 1..32767, 1..%d views)", H, W, n_views,
+                    kMaxViews);
+    if (!ws) return fail(SUCRE_ERR_ARG, "workspace is NULL");
+    if (!aligned(ws, 256)) return fail(SUCRE_ERR_ARG, "workspace must be 256-byte aligned");
+    return SUCRE_OK;
+}
+
+// torch/optim/adam.py: bias_correction1 = 1 - beta1 ** step; step_size = lr / bias_correction1;
+// bias_correction2_sqrt = (1 - beta2 ** step) ** 0.5  -- Python floats (double), cast to float32 at use.
+AdamCoef adam_coef(int step, double lr, double beta1, double beta2, double eps) {
+    AdamCoef c;
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    c.w1 = (float)(1.0 - beta1);
+    c.beta2 = (float)beta2;
+    c.w2 = (float)(1.0 - beta2);
+    c.step_size_neg = (float)(-(lr / bc1));
+    c.bc2_sqrt = (float)std::sqrt(bc2);
+    c.eps = (float)eps;
+    return c;
+}
+
+static int check_adam(int step, double lr, double beta1, double beta2, double eps) {
+    if (step < 1) return fail(SUCRE_ERR_RANGE, "Adam step must be >= 1 (got %d)", step);
+    if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0))
+        return fail(SUCRE_ERR_ARG, "invalid Adam hyper-parameters lr=%g betas=(%g,%g) eps=%g", lr, beta1, beta2, eps);
+    return SUCRE_OK;
+}
+
+}  // namespace sucre
+
+using namespace sucre;
+
+extern "C" {
+
+int sucre_version(void) { return SUCRE_ABI_VERSION; }
+
+const char *sucre_last_error(void) { return g_err; }
+
+size_t sucre_workspace_bytes(int H, int W, int n_views) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) {
+        fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views);
+        return 0;
+    }
+    return L.total;
+}
+
+int64_t sucre_ws_offset(int H, int W, int n_views, int region) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) return fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views);
+    switch (region) {
+        case SUCRE_WS_VIEW_COUNT: return (int64_t)L.off_view_count;
+        case SUCRE_WS_VIEW_KEEP: return (int64_t)L.off_view_keep;
+        case SUCRE_WS_N_OBS: return (int64_t)L.off_n_obs;
+        case SUCRE_WS_PARAMS: return (int64_t)L.off_params;
+        case SUCRE_WS_SUMS: return (int64_t)L.off_sums;
+        case SUCRE_WS_N_OBS_TOTAL: return (int64_t)L.off_n_obs_total;
+        default: return fail(SUCRE_ERR_RANGE, "unknown workspace region %d", region);
+    }
+}
+
+int sucre_match_views(void *ws, int H, int W, int n_views, const sucre_view_t *target,
+                      const sucre_view_t *views_dev, int k0, int k1, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (!target || !views_dev) return fail(SUCRE_ERR_ARG, "target / views_dev is NULL");
+    if (!target->depth) return fail(SUCRE_ERR_ARG, "target depth map is NULL");
+    if (target->H != H || target->W != W)
+        return fail(SUCRE_ERR_ARG, "target is %dx%d but the workspace is laid out for %dx%d", target->W, target->H, W, H);
+    if (!aligned(views_dev, 8)) return fail(SUCRE_ERR_ARG, "views_dev must be 8-byte aligned");
+    if (k0 < 0 || k1 > n_views || k0 >= k1) return fail(SUCRE_ERR_RANGE, "view range [%d,%d) outside [0,%d)", k0, k1, n_views);
+    return check_hip(launch_match(L, static_cast<uint8_t *>(ws), *target, views_dev, k0, k1,
+                                  static_cast<hipStream_t>(stream)), "sucre_match_views");
+}
+
+int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
+    return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream)),
+                     "sucre_finalize_matches");
+}
+
+int sucre_fit_init(void *ws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
+                   const float *params0, const float *J0_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (!depth1_dev || !params0) return fail(SUCRE_ERR_ARG, "depth1_dev / params0 is NULL");
+    if (!rgb1_dev && !J0_dev) return fail(SUCRE_ERR_ARG, "need rgb1_dev or J0_dev");
+    return check_hip(launch_fit_init(L, static_cast<uint8_t *>(ws), rgb1_dev, depth1_dev, params0, J0_dev,
+                                     static_cast<hipStream_t>(stream)), "sucre_fit_init");
+}
+
+int sucre_fit_grad(void *ws, int H, int W, int n_views, int step, double lr, double beta1, double beta2,
+                   double eps, unsigned flags, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
+    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    return check_hip(launch_fit_grad(L, static_cast<uint8_t *>(ws), adam_coef(step, lr, beta1, beta2, eps), flags,
+                                     static_cast<hipStream_t>(stream)), "sucre_fit_grad");
+}
+
+int sucre_fit_step(void *ws, int H, int W, int n_views, int step, double lr, double beta1, double beta2,
+                   double eps, double *trace_row_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
+    if (trace_row_dev && !aligned(trace_row_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
+    return check_hip(launch_fit_step(L, static_cast<uint8_t *>(ws), adam_coef(step, lr, beta1, beta2, eps),
+                                     trace_row_dev, static_cast<hipStream_t>(stream)), "sucre_fit_step");
+}
+
+int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr, double beta1, double beta2,
+                  double eps, unsigned flags, double *trace_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
+    if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
+    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
+    auto *w = static_cast<uint8_t *>(ws);
+    auto s = static_cast<hipStream_t>(stream);
+    for (int it = 0; it < T; ++it) {
+        const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
+        if (int rc = check_hip(launch_fit_grad(L, w, co, flags, s), "sucre_fit_run/grad")) return rc;
+        if (int rc = check_hip(launch_fit_step(L, w, co, trace_dev ? trace_dev + (size_t)it * 10 : nullptr, s),
+                               "sucre_fit_run/step")) return rc;
+    }
+    if (flags & SUCRE_FIT_CLOSED_FORM) return check_hip(launch_update_J(L, w, s), "sucre_fit_run/update_J");
+    return SUCRE_OK;
+}
+
+int sucre_set_n_obs_total(void *ws, int H, int W, int n_views, uint64_t n_obs_total, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (n_obs_total == 0) return fail(SUCRE_ERR_RANGE, "n_obs_total must be > 0");
+    return check_hip(launch_set_n_obs_total(L, static_cast<uint8_t *>(ws), n_obs_total,
+                                            static_cast<hipStream_t>(stream)), "sucre_set_n_obs_total");
+}
+
+int sucre_update_J(void *ws, int H, int W, int n_views, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), static_cast<hipStream_t>(stream)), "sucre_update_J");
+}
+
+int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (!J_dev) return fail(SUCRE_ERR_ARG, "J_dev is NULL");
+    return check_hip(launch_export_J(L, static_cast<const uint8_t *>(ws), J_dev, static_cast<hipStream_t>(stream)),
+                     "sucre_export_J");
+}
+
+int sucre_export_view(const void *ws, int H, int W, int n_views, int k, float *z_dev, uint8_t *rgb_dev,
+                      void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
+    if (!z_dev && !rgb_dev) return fail(SUCRE_ERR_ARG, "both outputs are NULL");
+    return check_hip(launch_export_view(L, static_cast<const uint8_t *>(ws), k, z_dev, rgb_dev,
+                                        static_cast<hipStream_t>(stream)), "sucre_export_view");
+}
+
+}  // extern "C"

@@ -1,0 +1,443 @@
+// Exponential-model fit for gfx950.
+//
+// One iteration of sucre.adam (sucre.py:138-148) = fit_grad_kernel (streams the observation store once,
+// updates J in place) + reduce_sums_kernel + param_step_kernel (Adam on B, beta, gamma).
+//
+// Work decomposition: one 256-thread workgroup per 16x16 tile.  Phase 1 is view-parallel: the tile's kept
+// views are dealt round-robin to the four waves, each lane owning 4 pixels x 3 channels, so every load is a
+// fully coalesced 1 KiB (ranges, dwordx4) or 768 B (colours, dwordx3) wave access and the per-pixel sums need
+// no atomics.  Phase 2 adds the four waves' per-pixel sums through LDS in a fixed order; phase 3 is
+// pixel-parallel (one pixel per thread): torch.optim.Adam on J.  The ten global sums go wave shuffle -> LDS ->
+// one float32 partial per tile -> float64 fixed-order reduction, so results are bitwise reproducible.
+//
+// Model (sucre.py:79-82, l = 1):  Ihat = J a + B (1 - g),  a = exp(-beta z),  g = exp(-gamma z),  r = I - Ihat.
+// With L = sum r^2 / (3 n_obs) and s = (1/3)/n_obs (sucre.py:145):
+//   dL/dJ[p]  = -2 s sum_k r a          dL/dB     = -2 s sum r (1 - g)
+//   dL/dbeta  = +2 s sum_p J sum_k r a z    dL/dgamma = -2 s B sum r g z        (per channel)
+#include "launch.h"
+
+namespace sucre {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+// float32(float64(k)/255) for every uint8 k (loader.py:157,163) as fma(k, hi, k*lo); checked for all 256 values
+// in tests/test_host_logic.py and on the GPU by tests/test_gpu_parity.py.
+constexpr float kInv255Hi = (float)(1.0 / 255.0);
+constexpr float kInv255Lo = (float)(1.0 / 255.0 - (double)kInv255Hi);
+
+__device__ __forceinline__ float unit_from_u8(uint32_t k) {
+    const float kf = (float)k;
+    return __builtin_fmaf(kf, kInv255Hi, kf * kInv255Lo);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay), float32
+__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const AdamCoef &co) {
+    m = __builtin_fmaf(co.w1, g - m, m);
+    v = (v * co.beta2) + (co.w2 * g) * g;
+    const float denom = sqrtf(v) / co.bc2_sqrt + co.eps;
+    p = p + (co.step_size_neg * m) / denom;
+}
+
+struct Water {
+    float B[3], nb[3], ng[3];  // B, -beta*log2(e), -gamma*log2(e)
+};
+
+__device__ __forceinline__ Water load_water(const float *__restrict__ params) {
+    Water w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        w.B[c] = params[c];
+        w.nb[c] = -params[3 + c] * kLog2e;
+        w.ng[c] = -params[6 + c] * kLog2e;
+    }
+    return w;
+}
+
+// What one pass over a view accumulates.
+enum Pass { kPassGradJ = 0, kPassClosedJ = 1, kPassGradClosed = 2 };
+
+struct Acc {
+    float pa[3][4];  // per pixel-channel: sum r a           | closed-form numerator   sum (I - b) a
+    float pb[3][4];  // per pixel-channel: sum r a z         | closed-form denominator sum a^2
+    float sB[3];     // sum r (1 - g)
+    float sGZ[3];    // sum r g z
+    float cost;      // sum r^2
+};
+
+template <int kPass>
+__device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
+                                                const float (&J)[3][4], Acc &acc) {
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    const uint32_t cc[3] = {c3.x, c3.y, c3.z};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float z = zz[j];
+        const bool valid = z > 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float I = unit_from_u8((cc[c] >> (8 * j)) & 255u);
+            const float a = fast_exp2(z * w.nb[c]);
+            const float g = fast_exp2(z * w.ng[c]);
+            const float omg = 1.0f - g;
+            const float bt = w.B[c] * omg;
+            if (kPass == kPassClosedJ) {
+                // sucre.py:73-76: numerator += (I - backscatter) * absorption ; denominator += absorption^2
+                const float y = valid ? (I - bt) : 0.0f;
+                const float a2 = valid ? a * a : 0.0f;
+                acc.pa[c][j] = __builtin_fmaf(y, a, acc.pa[c][j]);
+                acc.pb[c][j] += a2;
+            } else {
+                const float Ihat = __builtin_fmaf(J[c][j], a, bt);
+                const float r = valid ? (I - Ihat) : 0.0f;  // select, not multiply: J may be NaN where unobserved
+                const float rz = r * z;
+                acc.cost = __builtin_fmaf(r, r, acc.cost);
+                if (kPass == kPassGradJ) acc.pa[c][j] = __builtin_fmaf(r, a, acc.pa[c][j]);
+                acc.pb[c][j] = __builtin_fmaf(rz, a, acc.pb[c][j]);
+                acc.sB[c] = __builtin_fmaf(r, omg, acc.sB[c]);
+                acc.sGZ[c] = __builtin_fmaf(rz, g, acc.sGZ[c]);
+            }
+        }
+    }
+}
+
+// Streams this wave's share of the tile's views (software-prefetched one view ahead).
+template <int kPass>
+__device__ __forceinline__ void stream_views(const uint8_t *__restrict__ tile_obs, const uint32_t *__restrict__ lst,
+                                             uint32_t n, int wave, int lane, const Water &w,
+                                             const float (&J)[3][4], Acc &acc) {
+    uint32_t i = (uint32_t)wave;
+    float4 zc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint3 cc = make_uint3(0u, 0u, 0u);
+    if (i < n) {
+        const uint8_t *chunk = tile_obs + (size_t)lst[i] * kChunk;
+        zc = *reinterpret_cast<const float4 *>(chunk + lane * 16);
+        cc = *reinterpret_cast<const uint3 *>(chunk + kChunkZ + lane * 12);
+    }
+    while (i < n) {
+        const uint32_t in = i + 4;
+        float4 zn = zc;
+        uint3 cn = cc;
+        if (in < n) {
+            const uint8_t *chunk = tile_obs + (size_t)lst[in] * kChunk;
+            zn = *reinterpret_cast<const float4 *>(chunk + lane * 16);
+            cn = *reinterpret_cast<const uint3 *>(chunk + kChunkZ + lane * 12);
+        }
+        accumulate_view<kPass>(zc, cc, w, J, acc);
+        zc = zn;
+        cc = cn;
+        i = in;
+    }
+}
+
+__device__ __forceinline__ void zero_acc(Acc &a) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.pa[c][j] = 0.f; a.pb[c][j] = 0.f; }
+        a.sB[c] = 0.f;
+        a.sGZ[c] = 0.f;
+    }
+    a.cost = 0.f;
+}
+
+// Adds the four waves' per-pixel sums (fixed order) and returns, for pixel slot `t`, the six totals.
+__device__ __forceinline__ void reduce_pixels(float (*red)[6][kTilePx], const Acc &acc, int wave, int lane, int t,
+                                              float out[6]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) =
+            make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
+        *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) =
+            make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out[q] = ((red[0][q][t] + red[1][q][t]) + red[2][q][t]) + red[3][q][t];
+}
+
+template <bool kClosed>
+__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ obs,
+                                                       const uint32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ tile_n, int n_views,
+                                                       const float *__restrict__ params,
+                                                       const uint64_t *__restrict__ n_obs_total,
+                                                       float *__restrict__ Jt, float *__restrict__ mt,
+                                                       float *__restrict__ vt, float *__restrict__ partials,
+                                                       const AdamCoef co) {
+    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
+    __shared__ __attribute__((aligned(16))) float jbuf[3][kTilePx];
+    __shared__ float wsum[4][kNumSums];
+    const int tile = blockIdx.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(params);
+    const uint32_t n = tile_n[tile];
+    const uint32_t *lst = list + (size_t)tile * n_views;
+    const uint8_t *tile_obs = obs + (size_t)tile * n_views * kChunk;
+    float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+
+    float J[3][4];
+    Acc acc;
+    float tot[6];
+    if (kClosed) {
+        // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
+        zero_acc(acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
+        stream_views<kPassClosedJ>(tile_obs, lst, n, wave, lane, w, J, acc);
+        reduce_pixels(red, acc, wave, lane, t, tot);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float Jc = tot[c] / tot[3 + c];  // 0/0 = NaN where nothing was observed
+            Jtile[c * kTilePx + t] = Jc;
+            jbuf[c][t] = Jc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(&jbuf[c][lane * 4]);
+            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+        }
+    }
+
+    zero_acc(acc);
+    if (kClosed) stream_views<kPassGradClosed>(tile_obs, lst, n, wave, lane, w, J, acc);
+    else stream_views<kPassGradJ>(tile_obs, lst, n, wave, lane, w, J, acc);
+    reduce_pixels(red, acc, wave, lane, t, tot);
+
+    // pixel-parallel tail: this thread owns pixel slot t
+    float sBeta[3];
+    if (kClosed) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float Jc = jbuf[c][t];
+            sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
+        }
+    } else {
+        const float scale = (1.0f / 3.0f) / (float)(*n_obs_total);  // (loss / n_obs / 3).backward(), sucre.py:145
+        const float gscale = -2.0f * scale;
+        float *mtile = mt + (size_t)tile * 3 * kTilePx;
+        float *vtile = vt + (size_t)tile * 3 * kTilePx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float Jc = Jtile[c * kTilePx + t];
+            float m = mtile[c * kTilePx + t];
+            float v = vtile[c * kTilePx + t];
+            // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
+            sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
+            adam_update(Jc, m, v, gscale * tot[c], co);
+            Jtile[c * kTilePx + t] = Jc;
+            mtile[c * kTilePx + t] = m;
+            vtile[c * kTilePx + t] = v;
+        }
+    }
+
+    // ten tile sums: wave shuffle tree, then the four waves in fixed order
+    float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
+                         sBeta[0], sBeta[1], sBeta[2], acc.cost};
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) wsum[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (t < kNumSums) partials[(size_t)tile * kNumSums + t] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+}
+
+// SUCRe.update_J alone (sucre.py:66-77, 156)
+__global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ obs,
+                                                       const uint32_t *__restrict__ list,
+                                                       const uint32_t *__restrict__ tile_n, int n_views,
+                                                       const float *__restrict__ params, float *__restrict__ Jt) {
+    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
+    const int tile = blockIdx.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(params);
+    float J[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
+    Acc acc;
+    zero_acc(acc);
+    stream_views<kPassClosedJ>(obs + (size_t)tile * n_views * kChunk, list + (size_t)tile * n_views, tile_n[tile],
+                               wave, lane, w, J, acc);
+    float tot[6];
+    reduce_pixels(red, acc, wave, lane, t, tot);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + t] = tot[c] / tot[3 + c];
+}
+
+// Fixed-order float64 reduction of the per-tile partials: sums[q] = sum_tile partials[tile][q].
+__global__ __launch_bounds__(1024) void reduce_sums_kernel(const float *__restrict__ partials, int n_tiles,
+                                                           double *__restrict__ sums) {
+    __shared__ double wpart[16][kNumSums];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double s[kNumSums];
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) s[q] = 0.0;
+    for (int tile = t; tile < n_tiles; tile += 1024) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) s[q] += (double)partials[(size_t)tile * kNumSums + q];
+    }
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) wpart[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (t < kNumSums) {
+        double a = 0.0;
+        for (int wv = 0; wv < 16; ++wv) a += wpart[wv][t];
+        sums[t] = a;
+    }
+}
+
+// torch.optim.Adam step on B, beta, gamma (sucre.py:148) from the reduced sums; logs cost + parameters
+// (sucre.py:149-152) into one trace row.
+__global__ void param_step_kernel(const double *__restrict__ sums, float *__restrict__ pstate,
+                                  const uint64_t *__restrict__ n_obs_total, const AdamCoef co,
+                                  double *__restrict__ trace_row) {
+    const int q = threadIdx.x;
+    const float scale = (1.0f / 3.0f) / (float)(*n_obs_total);
+    float p = 0.f, m = 0.f, v = 0.f;
+    double g = 0.0;
+    if (q < 9) {
+        const int c = q % 3;
+        if (q < 3) g = -2.0 * (double)scale * sums[c];                            // dL/dB
+        else if (q < 6) g = 2.0 * (double)scale * sums[6 + c];                    // dL/dbeta
+        else g = -2.0 * (double)scale * (double)pstate[c] * sums[3 + c];           // dL/dgamma (uses B before its step)
+        p = pstate[q];
+        m = pstate[9 + q];
+        v = pstate[18 + q];
+    }
+    __syncthreads();  // every lane has read B before any lane overwrites it
+    if (q < 9) {
+        adam_update(p, m, v, (float)g, co);
+        pstate[q] = p;
+        pstate[9 + q] = m;
+        pstate[18 + q] = v;
+    }
+    if (trace_row) {
+        if (q < 9) trace_row[1 + q] = (double)p;
+        if (q == 9) trace_row[0] = sums[9];
+    }
+}
+
+struct Params9 { float v[9]; };
+
+__global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict__ rgb1,
+                                                       const float *__restrict__ depth1,
+                                                       const float *__restrict__ J0, int H, int W, int tiles_x,
+                                                       float *__restrict__ Jt, float *__restrict__ mt,
+                                                       float *__restrict__ vt, float *__restrict__ pstate,
+                                                       const Params9 p0) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v = ty * kTile + (t >> 4), u = tx * kTile + (t & 15);
+    const bool inside = v < H && u < W;
+    const size_t o = inside ? (size_t)v * W + u : 0;
+    const bool valid = inside && !(depth1[o] <= 0.0f);  // self.J[depth <= 0] = nan, sucre.py:48
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float Jc = __builtin_nanf("");
+        if (valid) Jc = J0 ? J0[o * 3 + c] : unit_from_u8(rgb1[o * 3 + c]);
+        const size_t i = ((size_t)tile * 3 + c) * kTilePx + t;
+        Jt[i] = Jc;
+        mt[i] = 0.f;
+        vt[i] = 0.f;
+    }
+    if (tile == 0 && t < 27) pstate[t] = t < 9 ? p0.v[t] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__ Jt, int H, int W, int tiles_x,
+                                                       float *__restrict__ J) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v = ty * kTile + (t >> 4), u = tx * kTile + (t & 15);
+    if (v >= H || u >= W) return;
+    const size_t o = ((size_t)v * W + u) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[o + c] = Jt[((size_t)tile * 3 + c) * kTilePx + t];
+}
+
+__global__ void set_n_obs_total_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
+
+hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,
+                           const float *params0, const float *J0, hipStream_t s) {
+    Params9 p0;
+    for (int i = 0; i < 9; ++i) p0.v[i] = params0[i];
+    hipLaunchKernelGGL(fit_init_kernel, dim3(L.n_tiles), dim3(256), 0, s, rgb1, depth1, J0, L.H, L.W, L.tiles_x,
+                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
+                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_params), p0);
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
+    auto *list = reinterpret_cast<const uint32_t *>(ws + L.off_list);
+    auto *tile_n = reinterpret_cast<const uint32_t *>(ws + L.off_tile_n);
+    auto *params = reinterpret_cast<const float *>(ws + L.off_params);
+    auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
+    auto *Jt = reinterpret_cast<float *>(ws + L.off_J);
+    auto *mt = reinterpret_cast<float *>(ws + L.off_m);
+    auto *vt = reinterpret_cast<float *>(ws + L.off_v);
+    auto *partials = reinterpret_cast<float *>(ws + L.off_partials);
+    if (flags & SUCRE_FIT_CLOSED_FORM)
+        hipLaunchKernelGGL(fit_grad_kernel<true>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, list, tile_n,
+                           L.n_views, params, nobs, Jt, mt, vt, partials, co);
+    else
+        hipLaunchKernelGGL(fit_grad_kernel<false>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, list, tile_n,
+                           L.n_views, params, nobs, Jt, mt, vt, partials, co);
+    hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(1024), 0, s, partials, L.n_tiles,
+                       reinterpret_cast<double *>(ws + L.off_sums));
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
+    hipLaunchKernelGGL(param_step_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const double *>(ws + L.off_sums),
+                       reinterpret_cast<float *>(ws + L.off_params),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total), co, trace_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s) {
+    hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_list),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_tile_n), L.n_views,
+                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J));
+    return hipGetLastError();
+}
+
+hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s) {
+    hipLaunchKernelGGL(export_J_kernel, dim3(L.n_tiles), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(ws + L.off_J), L.H, L.W, L.tiles_x, J);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(set_n_obs_total_kernel, dim3(1), dim3(1), 0, s,
+                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total), n);
+    return hipGetLastError();
+}
+
+}  // namespace sucre

@@ -1,0 +1,42 @@
+// Internal launcher interface between abi.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/sucre_hip.h"
+#include "layout.h"
+
+namespace sucre {
+
+// Camera of the target image, passed by value as a kernel argument (SGPR-resident).
+struct CamDev {
+    float K[9], Kinv[9], R[9], t[3], Rinv[9], tinv[3];
+    int H, W;
+};
+
+// torch.optim.Adam scalars of one step, computed on the host in double like torch does
+// (torch/optim/adam.py::_single_tensor_adam, non-capturable branch).
+struct AdamCoef {
+    float w1;             // 1 - beta1            exp_avg.lerp_(grad, 1 - beta1)
+    float beta2;          // beta2                exp_avg_sq.mul_(beta2)
+    float w2;             // 1 - beta2            .addcmul_(grad, grad, value=1 - beta2)
+    float step_size_neg;  // -(lr / (1 - beta1^t))
+    float bc2_sqrt;       // sqrt(1 - beta2^t)
+    float eps;
+};
+
+AdamCoef adam_coef(int step, double lr, double beta1, double beta2, double eps);
+
+hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
+                        int k0, int k1, hipStream_t s);
+hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s);
+hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);
+
+hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,
+                           const float *params0, const float *J0, hipStream_t s);
+hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s);
+hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s);
+hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s);
+hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
+hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
+
+}  // namespace sucre

@@ -1,0 +1,254 @@
+// Dense two-way matching for gfx950: one wave owns one 16x16 tile of the target image, four pixels per lane.
+//
+// Replaces, per (target, view) pair, the reference's chain
+//   unproject_depth_map (sfm.py:95-101) -> match_one_way x2 (sfm.py:115-119) -> Matches.map / __and__
+//   (sfm.py:154-175) -> d = depth2[v2,u2] (sfm.py:137) -> I = rgb2[v2,u2] (loader.py:87)
+//   -> cP = K2^-1 d [u2+.5, v2+.5, 1] (loader.py:113) -> z = ||cP|| (sucre.py:53)
+// with one fused per-pixel test: p1 -> p2 = trunc(project(unproject(p1))) must be inside view 2, have
+// depth2[p2] > 0, and p2 must project back onto exactly p1.  This is the map-free form of Matches.__and__ (every
+// p2 occurs at most once in the backward list, so map[p2] == p1 iff the backward projection of p2 is p1).
+//
+// The arithmetic mirrors torch CPU float32 bit for bit: a (3x3)@(3xn) matmul is the FMA chain of dot3(), the
+// divide and sqrt are IEEE (-fhip-fp32-correctly-rounded-divide-sqrt), and the file is built with
+// -ffp-contract=off so no other operation is fused.  Match sets therefore equal the reference's exactly.
+#include "launch.h"
+
+namespace sucre {
+
+__device__ __forceinline__ float dot3(const float *a, float x, float y, float z) {
+    float acc = a[0] * x;
+    acc = __builtin_fmaf(a[1], y, acc);
+    acc = __builtin_fmaf(a[2], z, acc);
+    return acc;
+}
+
+// sfm.py:90-93
+__device__ __forceinline__ void unproject(const float *Kinv, float u, float v, float d, float out[3]) {
+    const float x = d * (u + 0.5f), y = d * (v + 0.5f), z = d * 1.0f;
+    out[0] = dot3(Kinv + 0, x, y, z);
+    out[1] = dot3(Kinv + 3, x, y, z);
+    out[2] = dot3(Kinv + 6, x, y, z);
+}
+
+// sfm.py:49-55
+__device__ __forceinline__ void rigid(const float *R, const float *t, const float p[3], float out[3]) {
+    out[0] = dot3(R + 0, p[0], p[1], p[2]) + t[0];
+    out[1] = dot3(R + 3, p[0], p[1], p[2]) + t[1];
+    out[2] = dot3(R + 6, p[0], p[1], p[2]) + t[2];
+}
+
+// sfm.py:103-107,116-117: world point -> continuous pixel; true when Tensor.long() of it lies inside WxH.
+// trunc(x) in [0, W-1]  <=>  -1 < x < W ; NaN and +-inf fail both comparisons like INT64_MIN fails the bound test.
+__device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, float Wf, float Hf,
+                                        const float wP[3], float *px, float *py) {
+    float cP[3];
+    rigid(Rinv, tinv, wP, cP);
+    const float c0 = dot3(K + 0, cP[0], cP[1], cP[2]);
+    const float c1 = dot3(K + 3, cP[0], cP[1], cP[2]);
+    const float c2 = dot3(K + 6, cP[0], cP[1], cP[2]);
+    *px = c0 / c2;
+    *py = c1 / c2;
+    return (*px > -1.0f) && (*px < Wf) && (*py > -1.0f) && (*py < Hf);
+}
+
+constexpr int kViewsPerGroup = 16;
+
+__global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
+                                                    const float *__restrict__ depth1, const CamDev c1,
+                                                    const sucre_view_t *__restrict__ views, int n_views, int k0,
+                                                    int k1, int tiles_x, int n_tiles, int tiles_per_xcd) {
+    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
+    // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
+    const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v1 = ty * kTile + (lane >> 2);
+    const int u1b = tx * kTile + (lane & 3) * 4;
+    const float W1f = (float)c1.W, H1f = (float)c1.H;
+
+    float wP[4][3];
+    bool ok1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int u1 = u1b + j;
+        float d = 0.0f;
+        if (v1 < c1.H && u1 < c1.W) d = depth1[(size_t)v1 * c1.W + u1];
+        ok1[j] = d > 0.0f;
+        float cP[3];
+        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
+        rigid(c1.R, c1.t, cP, wP[j]);
+    }
+
+    const int kb = k0 + blockIdx.y * kViewsPerGroup;
+    const int ke = min(kb + kViewsPerGroup, k1);
+    for (int k = kb + wave; k < ke; k += 4) {
+        const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
+        const float *__restrict__ depth2 = vw->depth;
+        const uint8_t *__restrict__ rgb2 = vw->rgb;
+        const int W2 = vw->W;
+        const float W2f = (float)W2, H2f = (float)vw->H;
+        float zo[4];
+        uint32_t r4 = 0, g4 = 0, b4 = 0;
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool m = ok1[j];
+            float z = 0.0f;
+            uint32_t r = 0, g = 0, b = 0;
+            if (m) {
+                float px, py;
+                m = project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP[j], &px, &py);
+                if (m) {
+                    const int u2 = (int)px, v2 = (int)py;
+                    const size_t q = (size_t)v2 * W2 + u2;
+                    const float d2 = depth2[q];
+                    m = d2 > 0.0f;
+                    if (m) {
+                        float c2[3], w2[3], qx, qy;
+                        unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
+                        rigid(vw->R, vw->t, c2, w2);
+                        m = project(c1.Rinv, c1.tinv, c1.K, W1f, H1f, w2, &qx, &qy);
+                        m = m && ((int)qx == u1b + j) && ((int)qy == v1);
+                        if (m) {
+                            z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+                            const uint8_t *p = rgb2 + q * 3;
+                            r = p[0]; g = p[1]; b = p[2];
+                        }
+                    }
+                }
+            }
+            zo[j] = z;
+            r4 |= r << (8 * j);
+            g4 |= g << (8 * j);
+            b4 |= b << (8 * j);
+            total += __builtin_popcountll(__ballot(m));
+        }
+        if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
+        if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
+            uint8_t *chunk = obs + ((size_t)tile * n_views + k) * kChunk;
+            *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
+            uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ + lane * 12);
+            c[0] = r4; c[1] = g4; c[2] = b4;
+        }
+    }
+}
+
+// len(matches) per view and the min_cover rule of sfm.py:136 (Python int/int true division, strict >).
+__global__ __launch_bounds__(256) void view_count_kernel(const uint16_t *__restrict__ cnt, int n_tiles, int n_views,
+                                                         double min_cover, double hw,
+                                                         uint64_t *__restrict__ view_count,
+                                                         uint32_t *__restrict__ view_keep) {
+    __shared__ unsigned long long part[256];
+    const int k = blockIdx.x;
+    unsigned long long s = 0;
+    for (int tile = threadIdx.x; tile < n_tiles; tile += 256) s += cnt[(size_t)tile * n_views + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        view_count[k] = part[0];
+        view_keep[k] = ((double)part[0] / hw > min_cover) ? 1u : 0u;
+    }
+}
+
+// Per tile: compacted list of the views that are kept and have at least one match inside the tile.
+// One wave per tile.  Wave 0 of block 0 also totals n_obs = len(matches_data) (loader.py:52-53).
+__global__ __launch_bounds__(256) void tile_list_kernel(const uint16_t *__restrict__ cnt,
+                                                        const uint32_t *__restrict__ view_keep,
+                                                        const uint64_t *__restrict__ view_count, int n_tiles,
+                                                        int n_views, uint32_t *__restrict__ list,
+                                                        uint32_t *__restrict__ tile_n, uint64_t *__restrict__ n_obs,
+                                                        uint64_t *__restrict__ n_obs_total) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile < n_tiles) {
+        uint32_t n = 0;
+        for (int base = 0; base < n_views; base += 64) {
+            const int k = base + lane;
+            const bool f = k < n_views && view_keep[k] != 0 && cnt[(size_t)tile * n_views + k] > 0;
+            const unsigned long long mask = __ballot(f);
+            const uint32_t before = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (f) list[(size_t)tile * n_views + n + before] = (uint32_t)k;
+            n += __builtin_popcountll(mask);
+        }
+        if (lane == 0) tile_n[tile] = n;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        unsigned long long s = 0;
+        for (int k = lane; k < n_views; k += 64) s += view_keep[k] ? view_count[k] : 0ull;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) { *n_obs = s; *n_obs_total = s; }
+    }
+}
+
+__global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restrict__ obs,
+                                                          const uint16_t *__restrict__ cnt, int n_views, int k,
+                                                          int tiles_x, int H, int W, float *__restrict__ z_out,
+                                                          uint8_t *__restrict__ rgb_out) {
+    const int tile = blockIdx.x;
+    const int slot = threadIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v = ty * kTile + (slot >> 4), u = tx * kTile + (slot & 15);
+    if (v >= H || u >= W) return;
+    float z = 0.0f;
+    uint8_t c[3] = {0, 0, 0};
+    if (cnt[(size_t)tile * n_views + k] > 0) {
+        const uint8_t *chunk = obs + ((size_t)tile * n_views + k) * kChunk;
+        z = reinterpret_cast<const float *>(chunk)[slot];
+        const uint8_t *p = chunk + kChunkZ + (slot >> 2) * 12 + (slot & 3);
+        c[0] = p[0]; c[1] = p[4]; c[2] = p[8];
+    }
+    const size_t o = (size_t)v * W + u;
+    if (z_out) z_out[o] = z;
+    if (rgb_out) {
+        const bool has = z > 0.0f;
+        rgb_out[o * 3 + 0] = has ? c[0] : 0;
+        rgb_out[o * 3 + 1] = has ? c[1] : 0;
+        rgb_out[o * 3 + 2] = has ? c[2] : 0;
+    }
+}
+
+static CamDev to_cam(const sucre_view_t &v) {
+    CamDev c;
+    for (int i = 0; i < 9; ++i) { c.K[i] = v.K[i]; c.Kinv[i] = v.Kinv[i]; c.R[i] = v.R[i]; c.Rinv[i] = v.Rinv[i]; }
+    for (int i = 0; i < 3; ++i) { c.t[i] = v.t[i]; c.tinv[i] = v.tinv[i]; }
+    c.H = v.H; c.W = v.W;
+    return c;
+}
+
+hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
+                        int k0, int k1, hipStream_t s) {
+    const int tiles_per_xcd = (L.n_tiles + 7) / 8;
+    const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
+    hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
+                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s) {
+    auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
+    auto *vc = reinterpret_cast<uint64_t *>(ws + L.off_view_count);
+    auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
+    hipLaunchKernelGGL(view_count_kernel, dim3(L.n_views), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, min_cover,
+                       (double)L.W * (double)L.H, vc, vk);
+    hipLaunchKernelGGL(tile_list_kernel, dim3((L.n_tiles + 3) / 4), dim3(256), 0, s, cnt, vk, vc, L.n_tiles,
+                       L.n_views, reinterpret_cast<uint32_t *>(ws + L.off_list),
+                       reinterpret_cast<uint32_t *>(ws + L.off_tile_n),
+                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
+                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
+    return hipGetLastError();
+}
+
+hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {
+    hipLaunchKernelGGL(export_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, k, L.tiles_x, L.H, L.W, z, rgb);
+    return hipGetLastError();
+}
+
+}  // namespace sucre

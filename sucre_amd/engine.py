@@ -1,0 +1,171 @@
+"""Host driver of the HIP engine: device buffers, launch order, read-back.
+
+PyTorch-ROCm is plumbing here (device memory, streams); every kernel lives in libsucre_hip.so.  One
+``Restoration`` owns the workspace of one target image of size HxW fitted against ``n_views`` views and is
+reused across images of the same geometry.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class DeviceView:
+    """What the engine needs from one sfm.Image: pixels on the GPU + float32 camera/pose matrices computed on
+    the host the way the reference computes them (sfm.py:42-47, 92)."""
+    depth: torch.Tensor   # (H,W) float32, cuda
+    rgb: torch.Tensor     # (H,W,3) uint8, cuda
+    K: torch.Tensor       # (3,3) float32, cpu
+    R: torch.Tensor       # (3,3) float32, cpu   world-from-camera
+    t: torch.Tensor       # (3,1) float32, cpu
+    name: str = ''
+
+    def to_struct(self) -> _lib.SucreView:
+        H, W = self.depth.shape
+        assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
+        assert self.rgb.dtype == torch.uint8 and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
+        K = self.K.to(torch.float32).cpu()
+        R = self.R.to(torch.float32).cpu()
+        t = self.t.to(torch.float32).cpu().view(3, 1)
+        Kinv = K.inverse()      # sfm.py:92
+        Rinv = R.T              # sfm.py:47
+        tinv = -R.T @ t         # sfm.py:47
+        s = _lib.SucreView()
+        s.depth, s.rgb, s.H, s.W = self.depth.data_ptr(), self.rgb.data_ptr(), H, W
+        for name, val in (('K', K), ('Kinv', Kinv), ('R', R), ('t', t), ('Rinv', Rinv), ('tinv', tinv)):
+            flat = val.contiguous().view(-1).tolist()
+            setattr(s, name, (C.c_float * len(flat))(*flat))
+        return s
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Restoration:
+    """Workspace + launch sequence for one target image (replaces the HDF5 spill and the host-resident
+    MatchesData of the reference, loader.py:56-130)."""
+
+    def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda'):
+        self.lib = _lib.load()
+        self.H, self.W, self.n_views = int(height), int(width), int(n_views)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.SucreError('the HIP engine needs a GPU device (there is no CPU fallback)')
+        nbytes = self.lib.sucre_workspace_bytes(self.H, self.W, self.n_views)
+        if nbytes == 0:
+            raise _lib.SucreError(self.lib.sucre_last_error().decode())
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        assert self.ws.data_ptr() % 256 == 0
+        self._views_dev = None
+        self._keepalive = []
+        self.trace = None
+        self.steps_done = 0
+
+    # -- plumbing -----------------------------------------------------------------------------------------
+    @property
+    def _geom(self):
+        return C.c_void_p(self.ws.data_ptr()), self.H, self.W, self.n_views
+
+    def _region(self, region: int, dtype: torch.dtype, count: int) -> torch.Tensor:
+        off = self.lib.sucre_ws_offset(self.H, self.W, self.n_views, region)
+        if off < 0:
+            raise _lib.SucreError(self.lib.sucre_last_error().decode())
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.ws[off:off + nbytes].view(dtype)
+
+    # -- matching (sfm.py:127-138 + loader.py:78-118) ---------------------------------------------------------
+    def match(self, target: DeviceView, views: list[DeviceView], min_cover: float = 1e-6) -> None:
+        assert len(views) == self.n_views
+        tgt = target.to_struct()
+        table = (_lib.SucreView * self.n_views)(*[v.to_struct() for v in views])
+        host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+        self._views_dev = host.to(self.device)
+        self._keepalive = [target, views]
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
+                                                  0, n, _stream_ptr()))
+            _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
+
+    def view_counts(self) -> torch.Tensor:
+        return self._region(_lib.WS_VIEW_COUNT, torch.int64, self.n_views)
+
+    def view_keep(self) -> torch.Tensor:
+        return self._region(_lib.WS_VIEW_KEEP, torch.int32, self.n_views)
+
+    def n_obs(self) -> int:
+        return int(self._region(_lib.WS_N_OBS, torch.int64, 1).item())
+
+    def export_view(self, k: int):
+        """Dense (z (H,W) float32, rgb (H,W,3) uint8) planes of view k's matches."""
+        z = torch.empty((self.H, self.W), dtype=torch.float32, device=self.device)
+        rgb = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=self.device)
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_export_view(ws, H, W, n, int(k), C.c_void_p(z.data_ptr()),
+                                                  C.c_void_p(rgb.data_ptr()), _stream_ptr()))
+        return z, rgb
+
+    # -- fit (sucre.py:36-82, 124-157) --------------------------------------------------------------------------
+    def fit_init(self, target: DeviceView, params0=None, J0: torch.Tensor | None = None) -> None:
+        p0 = np.full(9, 0.1, np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(9)
+        p0c = (C.c_float * 9)(*p0.tolist())
+        j0 = None
+        if J0 is not None:
+            j0 = J0.to(self.device, torch.float32).contiguous()
+            assert j0.shape == (self.H, self.W, 3)
+            self._keepalive.append(j0)
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_fit_init(ws, H, W, n, C.c_void_p(target.rgb.data_ptr()),
+                                               C.c_void_p(target.depth.data_ptr()), p0c,
+                                               C.c_void_p(j0.data_ptr()) if j0 is not None else None, _stream_ptr()))
+        self.steps_done = 0
+
+    def fit(self, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
+            eps: float = 1e-8, record_trace: bool = True) -> torch.Tensor | None:
+        """Enqueues ``num_iter`` Adam iterations without any host sync; returns the (num_iter,10) float64
+        device trace (cost, B, beta, gamma per iteration) or None."""
+        trace = torch.zeros((num_iter, 10), dtype=torch.float64, device=self.device) if record_trace else None
+        flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_fit_run(ws, H, W, n, self.steps_done, int(num_iter), float(lr), float(betas[0]),
+                                              float(betas[1]), float(eps), flags,
+                                              C.c_void_p(trace.data_ptr()) if trace is not None else None,
+                                              _stream_ptr()))
+        self.steps_done += int(num_iter)
+        self.trace = trace
+        return trace
+
+    def update_J(self) -> None:
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_update_J(ws, H, W, n, _stream_ptr()))
+
+    def params(self) -> torch.Tensor:
+        """B[3], beta[3], gamma[3] on the device."""
+        return self._region(_lib.WS_PARAMS, torch.float32, 9)
+
+    def J(self) -> torch.Tensor:
+        out = torch.empty((self.H, self.W, 3), dtype=torch.float32, device=self.device)
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_export_J(ws, H, W, n, C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
+
+
+def device_views_from_scene(scene, device='cuda') -> list[DeviceView]:
+    """Uploads a synthetic scene (sucre_amd.synth) the way the loaders would: float32 depth, uint8 colour."""
+    out = []
+    for v in scene.views:
+        out.append(DeviceView(depth=v.depth_f32().to(device).contiguous(), rgb=v.rgb_u8.to(device).contiguous(),
+                              K=scene.K, R=v.R, t=v.t, name=v.name))
+    return out
