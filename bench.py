@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): restored Mpixels/s at 1080p with 64 neighbour views + % of HBM roofline.
+
+A step = one full restoration of one synthetic 1920x1080 image against 65 views (64 neighbours + itself):
+match all views -> min_cover/finalize -> init -> 200 Adam iterations -> export J, with every input already
+resident in HBM.  N>1: one process per GPU (torchrun contract), every rank restores its own image of the scene
+(per-image mode of the reference: no data-path collective, weak scaling); --shared-water adds the one
+all-reduce per iteration of the shared-water extension.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for how each field is measured).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+OBS_BYTES = 7           # float32 range + 3 uint8 colours per observation (c = 7)
+STATE_BYTES_PER_PX = 72  # J, exp_avg, exp_avg_sq: 3 planes x 3 channels x 4 B, read + written
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--width', type=int, default=1920)
+    p.add_argument('--height', type=int, default=1080)
+    p.add_argument('--neighbours', type=int, default=64)
+    p.add_argument('--num-iter', type=int, default=200)
+    p.add_argument('--use-closed-form', action='store_true')
+    p.add_argument('--shared-water', action='store_true')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-views', type=int, default=9, help='views in the CPU-baseline sample')
+    p.add_argument('--cpu-iters', type=int, default=5, help='Adam iterations in the CPU-baseline sample')
+    return p.parse_args()
+
+
+def cpu_baseline(scene, n_obs_full, n_views_full, num_iter, sample_views, sample_iters):
+    """The CPU oracle (oracle/sucre_oracle.c: C + OpenMP restatement of the reference path, kind 'port') timed on
+    this box's host cores over a bounded sample of the SAME image, then scaled to one full restoration."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import copy
+    import helpers
+    from oracle import oracle
+    sub = copy.copy(scene)
+    order = sorted(range(len(scene.views)), key=lambda i: abs(i - scene.target))[:sample_views]
+    order.sort()
+    sub.views = [scene.views[i] for i in order]
+    sub.target = order.index(scene.target)
+    for v in sub.views:  # host copies of the resident scene
+        v.depth_u16 = v.depth_u16.cpu()
+        v.rgb_u8 = v.rgb_u8.cpu()
+    t0 = time.perf_counter()
+    per_view, samples = helpers.oracle_scene_samples(sub)
+    t_match = time.perf_counter() - t0
+    n_obs_s = sum(len(s[0]) for s in samples)
+    tgt = sub.views[sub.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    t0 = time.perf_counter()
+    oracle.fit(sub.height, sub.width, samples, J0, num_iter=sample_iters)
+    t_fit = time.perf_counter() - t0
+    t_full = t_match * (n_views_full / len(sub.views)) + (t_fit / sample_iters) * (n_obs_full / max(n_obs_s, 1)) * num_iter
+    mpix = scene.width * scene.height / 1e6 / t_full
+    return {
+        'value': mpix, 'unit': 'Mpix/s', 'cores': oracle.num_threads(), 'kind': 'port',
+        'sample': (f'{scene.width}x{scene.height} target, {len(sub.views)} of {n_views_full} views matched '
+                   f'({t_match:.2f}s) + {sample_iters} of {num_iter} Adam iterations on {n_obs_s} obs ({t_fit:.2f}s); '
+                   f'scaled linearly to {n_views_full} views / {n_obs_full} obs / {num_iter} iterations '
+                   f'= {t_full:.1f}s per image'),
+        'ns_per_obs_iter': t_fit / sample_iters / max(n_obs_s, 1) * 1e9,
+    }
+
+
+def main():
+    args = parse()
+    from sucre_amd import dist as sdist
+    from sucre_amd import engine, synth
+    rank, local_rank, world = sdist.init_process_group()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun)'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP engine has no CPU fallback'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    W, H, T = args.width, args.height, args.num_iter
+
+    # every rank restores its own image (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
+    scene = synth.make_scene(W, H, args.neighbours, seed=rank, device=device)
+    views = engine.device_views_from_scene(scene, device)
+    tgt = views[scene.target]
+    n_views = len(views)
+    resto = engine.Restoration(H, W, n_views, device=device)
+    J_out = None
+
+    fit_events = []
+
+    def step(record):
+        nonlocal J_out
+        resto.match(tgt, views, min_cover=1e-6)
+        resto.fit_init(tgt)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()   # torch's current stream == the stream handed to the C ABI
+        if args.shared_water:
+            be = engine.HipWaterBackend(resto, use_closed_form=args.use_closed_form)
+            sdist.fit_shared_water(be, T)
+            if args.use_closed_form:
+                resto.update_J()
+        else:
+            resto.fit(T, use_closed_form=args.use_closed_form, record_trace=True)
+        if record:
+            e1.record()
+            fit_events.append((e0, e1))
+        J_out = resto.J()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    n_obs = resto.n_obs()
+    fit_ms = sum(a.elapsed_time(b) for a, b in fit_events) / len(fit_events)
+    iter_ms = fit_ms / T
+    obs_passes = 2 if args.use_closed_form else 1  # closed form streams the observations twice (J, then gradient)
+    state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
+    algo_bytes = OBS_BYTES * n_obs + state_bytes  # A_fit / T, independent of how often we re-read
+    achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
+    cover = resto.view_counts().cpu().numpy() / float(W * H)
+
+    if rank == 0:
+        out = {
+            'metric': 'restored Mpixels/sec/GPU at 1080p, 64 neighbour views; % HBM roofline',
+            'value': world * args.steps * W * H / 1e6 / elapsed,
+            'unit': 'Mpix/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'1 image {W}x{H} x {n_views} views (64 neighbours + self) per step per GPU, '
+                                   f'{T} Adam iterations, '
+                                   + ('closed-form J' if args.use_closed_form else 'J as parameter')
+                                   + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
+                                      else ', per-image water parameters (no collective)'),
+                       'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_per_s_per_gpu':
+                           args.steps / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps * 1e3 - fit_ms},
+            'roofline': {'bound': 'hbm', 'kernel': 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': algo_bytes, 'ms_per_launch': iter_ms,
+                         'obs_passes_per_launch': obs_passes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(scene, n_obs, n_views, T, args.cpu_views, args.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

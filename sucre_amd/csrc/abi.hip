@@ -152,9 +152,8 @@ int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr,
     auto s = static_cast<hipStream_t>(stream);
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
-        if (int rc = check_hip(launch_fit_grad(L, w, co, flags, s), "sucre_fit_run/grad")) return rc;
-        if (int rc = check_hip(launch_fit_step(L, w, co, trace_dev ? trace_dev + (size_t)it * 10 : nullptr, s),
-                               "sucre_fit_run/step")) return rc;
+        if (int rc = check_hip(launch_fit_iter_fused(L, w, co, flags, trace_dev ? trace_dev + (size_t)it * 10 : nullptr, s),
+                               "sucre_fit_run")) return rc;
     }
     if (flags & SUCRE_FIT_CLOSED_FORM) return check_hip(launch_update_J(L, w, s), "sucre_fit_run/update_J");
     return SUCRE_OK;

@@ -156,18 +156,83 @@ __device__ __forceinline__ void reduce_pixels(float (*red)[6][kTilePx], const Ac
     for (int q = 0; q < 6; ++q) out[q] = ((red[0][q][t] + red[1][q][t]) + red[2][q][t]) + red[3][q][t];
 }
 
-template <bool kClosed>
+// Fixed-order float64 reduction of the per-tile partials by one 256-thread workgroup:
+// sums[q] = sum_tile partials[tile][q].  Same code (hence same bits) in the fused and the split path.
+__device__ __forceinline__ void block_reduce_partials(const float *__restrict__ partials, int n_tiles,
+                                                      double (*wpart)[kNumSums], double *stot,
+                                                      double *__restrict__ sums) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double s[kNumSums];
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) s[q] = 0.0;
+    for (int tile = t; tile < n_tiles; tile += 256) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) s[q] += (double)partials[(size_t)tile * kNumSums + q];
+    }
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) wpart[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (t < kNumSums) {
+        const double tot = ((wpart[0][t] + wpart[1][t]) + wpart[2][t]) + wpart[3][t];
+        sums[t] = tot;  // global copy: read by the host all-reduce in shared-water runs
+        stot[t] = tot;  // LDS copy: read by water_step of the same workgroup
+    }
+    __syncthreads();
+}
+
+// torch.optim.Adam step on B, beta, gamma (sucre.py:148) from the reduced sums, by lanes 0..8 of one wave;
+// logs cost + parameters (sucre.py:149-152) into one trace row.  All lanes of the wave must call it.
+__device__ __forceinline__ void water_step(const double *__restrict__ sums, float *__restrict__ pstate,
+                                           const uint64_t *__restrict__ n_obs_total, const AdamCoef &co,
+                                           double *__restrict__ trace_row) {
+    const int q = threadIdx.x & 63;
+    const float scale = (1.0f / 3.0f) / (float)(*n_obs_total);
+    float p = 0.f, m = 0.f, v = 0.f;
+    double g = 0.0;
+    if (q < 9) {
+        const int c = q % 3;
+        if (q < 3) g = -2.0 * (double)scale * sums[c];                            // dL/dB
+        else if (q < 6) g = 2.0 * (double)scale * sums[6 + c];                    // dL/dbeta
+        else g = -2.0 * (double)scale * (double)pstate[c] * sums[3 + c];           // dL/dgamma (B before its step)
+        p = pstate[q];
+        m = pstate[9 + q];
+        v = pstate[18 + q];
+    }
+    __builtin_amdgcn_wave_barrier();  // B is read (above) by lanes 6..8 before lanes 0..2 overwrite it (below)
+    if (q < 9) {
+        adam_update(p, m, v, (float)g, co);
+        pstate[q] = p;
+        pstate[9 + q] = m;
+        pstate[18 + q] = v;
+    }
+    if (trace_row) {
+        if (q < 9) trace_row[1 + q] = (double)p;
+        if (q == 9) trace_row[0] = sums[9];
+    }
+}
+
+template <bool kClosed, bool kFused>
 __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ obs,
                                                        const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ tile_n, int n_views,
-                                                       const float *__restrict__ params,
-                                                       const uint64_t *__restrict__ n_obs_total,
+                                                       float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
-                                                       float *__restrict__ vt, float *__restrict__ partials,
-                                                       const AdamCoef co) {
+                                                       float *__restrict__ vt, float *partials, const AdamCoef co,
+                                                       unsigned *ticket, double *sums, double *trace_row) {
     __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
     __shared__ __attribute__((aligned(16))) float jbuf[3][kTilePx];
     __shared__ float wsum[4][kNumSums];
+    __shared__ double wpart[4][kNumSums];
+    __shared__ double stot[kSumsPad];
+    __shared__ int is_last;
+    const float *params = pstate;
     const int tile = blockIdx.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -256,6 +321,33 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
     __syncthreads();
     if (t < kNumSums) partials[(size_t)tile * kNumSums + t] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+
+    if (kFused) {
+        // Last-arriver tail: the workgroup that takes the final ticket reduces all partials and steps the water
+        // parameters, so an iteration is ONE launch.  Hand-off per cdna_hip_programming.md Guideline 16:
+        // storing waves drain vmcnt -> workgroup barrier -> one lane: agent release, drain, relaxed agent
+        // atomic; the last arriver: agent acquire, drain, barrier, then plain loads.  No spinning anywhere.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned got = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (got == gridDim.x - 1) ? 1 : 0;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+            }
+            is_last = last;
+        }
+        __syncthreads();
+        if (is_last) {  // workgroup-uniform
+            block_reduce_partials(partials, (int)gridDim.x, wpart, stot, sums);
+            // every other workgroup has finished (it took its ticket after its last use of the parameters)
+            if (t < 64) water_step(stot, pstate, n_obs_total, co, trace_row);
+        }
+    }
 }
 
 // SUCRe.update_J alone (sucre.py:66-77, 156)
@@ -284,64 +376,17 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
     for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + t] = tot[c] / tot[3 + c];
 }
 
-// Fixed-order float64 reduction of the per-tile partials: sums[q] = sum_tile partials[tile][q].
-__global__ __launch_bounds__(1024) void reduce_sums_kernel(const float *__restrict__ partials, int n_tiles,
-                                                           double *__restrict__ sums) {
-    __shared__ double wpart[16][kNumSums];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double s[kNumSums];
-#pragma unroll
-    for (int q = 0; q < kNumSums; ++q) s[q] = 0.0;
-    for (int tile = t; tile < n_tiles; tile += 1024) {
-#pragma unroll
-        for (int q = 0; q < kNumSums; ++q) s[q] += (double)partials[(size_t)tile * kNumSums + q];
-    }
-#pragma unroll
-    for (int q = 0; q < kNumSums; ++q) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < kNumSums; ++q) wpart[wave][q] = s[q];
-    }
-    __syncthreads();
-    if (t < kNumSums) {
-        double a = 0.0;
-        for (int wv = 0; wv < 16; ++wv) a += wpart[wv][t];
-        sums[t] = a;
-    }
+__global__ __launch_bounds__(256) void reduce_sums_kernel(const float *__restrict__ partials, int n_tiles,
+                                                          double *__restrict__ sums) {
+    __shared__ double wpart[4][kNumSums];
+    __shared__ double stot[kSumsPad];
+    block_reduce_partials(partials, n_tiles, wpart, stot, sums);
 }
 
-// torch.optim.Adam step on B, beta, gamma (sucre.py:148) from the reduced sums; logs cost + parameters
-// (sucre.py:149-152) into one trace row.
-__global__ void param_step_kernel(const double *__restrict__ sums, float *__restrict__ pstate,
-                                  const uint64_t *__restrict__ n_obs_total, const AdamCoef co,
-                                  double *__restrict__ trace_row) {
-    const int q = threadIdx.x;
-    const float scale = (1.0f / 3.0f) / (float)(*n_obs_total);
-    float p = 0.f, m = 0.f, v = 0.f;
-    double g = 0.0;
-    if (q < 9) {
-        const int c = q % 3;
-        if (q < 3) g = -2.0 * (double)scale * sums[c];                            // dL/dB
-        else if (q < 6) g = 2.0 * (double)scale * sums[6 + c];                    // dL/dbeta
-        else g = -2.0 * (double)scale * (double)pstate[c] * sums[3 + c];           // dL/dgamma (uses B before its step)
-        p = pstate[q];
-        m = pstate[9 + q];
-        v = pstate[18 + q];
-    }
-    __syncthreads();  // every lane has read B before any lane overwrites it
-    if (q < 9) {
-        adam_update(p, m, v, (float)g, co);
-        pstate[q] = p;
-        pstate[9 + q] = m;
-        pstate[18 + q] = v;
-    }
-    if (trace_row) {
-        if (q < 9) trace_row[1 + q] = (double)p;
-        if (q == 9) trace_row[0] = sums[9];
-    }
+__global__ __launch_bounds__(64) void param_step_kernel(const double *__restrict__ sums, float *__restrict__ pstate,
+                                                        const uint64_t *__restrict__ n_obs_total, const AdamCoef co,
+                                                        double *__restrict__ trace_row) {
+    water_step(sums, pstate, n_obs_total, co, trace_row);
 }
 
 struct Params9 { float v[9]; };
@@ -351,7 +396,7 @@ __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict
                                                        const float *__restrict__ J0, int H, int W, int tiles_x,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *__restrict__ pstate,
-                                                       const Params9 p0) {
+                                                       unsigned *__restrict__ ticket, const Params9 p0) {
     const int tile = blockIdx.x, t = threadIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int v = ty * kTile + (t >> 4), u = tx * kTile + (t & 15);
@@ -368,6 +413,7 @@ __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict
         vt[i] = 0.f;
     }
     if (tile == 0 && t < 27) pstate[t] = t < 9 ? p0.v[t] : 0.f;
+    if (tile == 0 && t == 32) *ticket = 0u;
 }
 
 __global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__ Jt, int H, int W, int tiles_x,
@@ -389,26 +435,39 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
     for (int i = 0; i < 9; ++i) p0.v[i] = params0[i];
     hipLaunchKernelGGL(fit_init_kernel, dim3(L.n_tiles), dim3(256), 0, s, rgb1, depth1, J0, L.H, L.W, L.tiles_x,
                        reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
-                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_params), p0);
+                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_params),
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket), p0);
     return hipGetLastError();
 }
 
+template <bool kClosed, bool kFused>
+static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
+    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_list),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_tile_n), L.n_views,
+                       reinterpret_cast<float *>(ws + L.off_params),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
+                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
+                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_partials), co,
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket), reinterpret_cast<double *>(ws + L.off_sums),
+                       trace_row);
+}
+
+// One whole iteration in a single launch (gradient pass + last-arriver reduction + water-parameter step).
+hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags,
+                                 double *trace_row, hipStream_t s) {
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, true>(L, ws, co, trace_row, s);
+    else launch_grad_variant<false, true>(L, ws, co, trace_row, s);
+    return hipGetLastError();
+}
+
+// Split form for multi-GPU shared-water runs: gradient pass + reduction, sums left at off_sums for the host's
+// all-reduce; launch_fit_step applies them.
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
-    auto *list = reinterpret_cast<const uint32_t *>(ws + L.off_list);
-    auto *tile_n = reinterpret_cast<const uint32_t *>(ws + L.off_tile_n);
-    auto *params = reinterpret_cast<const float *>(ws + L.off_params);
-    auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
-    auto *Jt = reinterpret_cast<float *>(ws + L.off_J);
-    auto *mt = reinterpret_cast<float *>(ws + L.off_m);
-    auto *vt = reinterpret_cast<float *>(ws + L.off_v);
-    auto *partials = reinterpret_cast<float *>(ws + L.off_partials);
-    if (flags & SUCRE_FIT_CLOSED_FORM)
-        hipLaunchKernelGGL(fit_grad_kernel<true>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, list, tile_n,
-                           L.n_views, params, nobs, Jt, mt, vt, partials, co);
-    else
-        hipLaunchKernelGGL(fit_grad_kernel<false>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, list, tile_n,
-                           L.n_views, params, nobs, Jt, mt, vt, partials, co);
-    hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(1024), 0, s, partials, L.n_tiles,
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, nullptr, s);
+    else launch_grad_variant<false, false>(L, ws, co, nullptr, s);
+    hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(ws + L.off_partials), L.n_tiles,
                        reinterpret_cast<double *>(ws + L.off_sums));
     return hipGetLastError();
 }

@@ -33,6 +33,8 @@ hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *
 
 hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,
                            const float *params0, const float *J0, hipStream_t s);
+hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, double *trace_row,
+                                 hipStream_t s);
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s);
 hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s);
 hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s);

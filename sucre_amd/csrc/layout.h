@@ -26,6 +26,7 @@ struct Layout {
     size_t off_n_obs_total; // uint64 [1]
     size_t off_params;      // float  [9] params, [9] exp_avg, [9] exp_avg_sq
     size_t off_sums;        // double [kSumsPad]
+    size_t off_ticket;      // uint32 [1]  arrival counter of the fused last-arriver reduction
     size_t off_partials;    // float  [n_tiles][kNumSums]
     size_t off_J, off_m, off_v;  // float [n_tiles][3][256]
     size_t total;
@@ -52,6 +53,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_n_obs_total = take(sizeof(uint64_t));
     L->off_params = take(27 * sizeof(float));
     L->off_sums = take(kSumsPad * sizeof(double));
+    L->off_ticket = take(sizeof(uint32_t));
     L->off_partials = take(nt * kNumSums * sizeof(float));
     L->off_J = take(nt * 3 * kTilePx * sizeof(float));
     L->off_m = take(nt * 3 * kTilePx * sizeof(float));

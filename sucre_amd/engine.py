@@ -169,3 +169,39 @@ def device_views_from_scene(scene, device='cuda') -> list[DeviceView]:
         out.append(DeviceView(depth=v.depth_f32().to(device).contiguous(), rgb=v.rgb_u8.to(device).contiguous(),
                               K=scene.K, R=v.R, t=v.t, name=v.name))
     return out
+
+
+class HipWaterBackend:
+    """dist.WaterBackend over a Restoration: split grad/step launches around the host's all-reduce."""
+
+    def __init__(self, restoration: Restoration, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
+                 use_closed_form: bool = False, trace: torch.Tensor | None = None):
+        self.r = restoration
+        self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))
+        self.flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
+        self.trace = trace
+        self._sums = restoration._region(_lib.WS_SUMS, torch.float64, 12)
+
+    def grad_device(self):
+        return self.r.device
+
+    def n_obs(self) -> int:
+        return self.r.n_obs()
+
+    def set_n_obs_total(self, n: int) -> None:
+        ws, H, W, nv = self.r._geom
+        with torch.cuda.device(self.r.device):
+            _lib.check(self.r.lib.sucre_set_n_obs_total(ws, H, W, nv, int(n), _stream_ptr()))
+
+    def grad(self, step: int) -> torch.Tensor:
+        ws, H, W, nv = self.r._geom
+        with torch.cuda.device(self.r.device):
+            _lib.check(self.r.lib.sucre_fit_grad(ws, H, W, nv, int(step), *self.hyper, self.flags, _stream_ptr()))
+        return self._sums
+
+    def step(self, step: int) -> None:
+        ws, H, W, nv = self.r._geom
+        row = C.c_void_p(self.trace[step - 1].data_ptr()) if self.trace is not None else None
+        with torch.cuda.device(self.r.device):
+            _lib.check(self.r.lib.sucre_fit_step(ws, H, W, nv, int(step), *self.hyper, row, _stream_ptr()))
+        self.r.steps_done = int(step)

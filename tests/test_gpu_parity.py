@@ -211,3 +211,26 @@ def test_full_size_properties():
     r.fit_init(tgt)
     t2 = r.fit(12)
     assert torch.equal(t1, t2) and torch.equal(torch.nan_to_num(J), torch.nan_to_num(r.J()))
+
+
+def test_split_grad_step_path_equals_fused(golden):
+    """sucre_fit_grad + sucre_fit_step (the multi-GPU shared-water form) == sucre_fit_run, bit for bit."""
+    import ctypes as C
+    from sucre_amd import _lib
+    for closed in (False, True):
+        J1, p1, t1 = _fit_engine(golden.scene, 15, closed=closed)
+        r, views = _engine(golden.scene)
+        r.fit_init(views[golden.scene.target])
+        ws, H, W, n = r._geom
+        trace = torch.zeros((15, 10), dtype=torch.float64, device='cuda')
+        flags = _lib.FIT_CLOSED_FORM if closed else 0
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for it in range(15):
+            _lib.check(r.lib.sucre_fit_grad(ws, H, W, n, it + 1, 0.05, 0.9, 0.999, 1e-8, flags, st))
+            _lib.check(r.lib.sucre_fit_step(ws, H, W, n, it + 1, 0.05, 0.9, 0.999, 1e-8,
+                                            C.c_void_p(trace[it].data_ptr()), st))
+        if closed:
+            r.update_J()
+        torch.cuda.synchronize()
+        assert np.array_equal(trace.cpu().numpy(), t1)
+        assert np.array_equal(r.J().cpu().numpy(), J1, equal_nan=True)
