@@ -70,6 +70,10 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
                                                 const float (&J)[3][4], Acc &acc) {
     const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const uint32_t cc[3] = {c3.x, c3.y, c3.z};
+#ifdef SUCRE_EXP_NOCOMPUTE  // experiment build only (tools/microbench.py): touch the data, skip the model
+    acc.cost += (z4.x + z4.y) + (z4.z + z4.w) + (float)(c3.x ^ c3.y ^ c3.z);
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float z = zz[j];
@@ -101,34 +105,112 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
     }
 }
 
-// Streams this wave's share of the tile's views (software-prefetched one view ahead).
-template <int kPass>
-__device__ __forceinline__ void stream_views(const uint8_t *__restrict__ tile_obs, const uint32_t *__restrict__ lst,
-                                             uint32_t n, int wave, int lane, const Water &w,
-                                             const float (&J)[3][4], Acc &acc) {
-    uint32_t i = (uint32_t)wave;
-    float4 zc = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint3 cc = make_uint3(0u, 0u, 0u);
-    if (i < n) {
-        const uint8_t *chunk = tile_obs + (size_t)lst[i] * kChunk;
-        zc = *reinterpret_cast<const float4 *>(chunk + lane * 16);
-        cc = *reinterpret_cast<const uint3 *>(chunk + kChunkZ + lane * 12);
-    }
-    while (i < n) {
-        const uint32_t in = i + 4;
-        float4 zn = zc;
-        uint3 cn = cc;
-        if (in < n) {
-            const uint8_t *chunk = tile_obs + (size_t)lst[in] * kChunk;
-            zn = *reinterpret_cast<const float4 *>(chunk + lane * 16);
-            cn = *reinterpret_cast<const uint3 *>(chunk + kChunkZ + lane * 12);
-        }
-        accumulate_view<kPass>(zc, cc, w, J, acc);
-        zc = zn;
-        cc = cn;
-        i = in;
-    }
+// ---------------------------------------------------------------------------------------------------------------
+// Observation streaming: per-wave LDS-DMA ring.
+//
+// Each wave consumes the chunks of views wave, wave+4, ... of the tile's list.  A chunk is copied HBM -> LDS by
+// two LDS-DMA instructions (global_load_lds_dwordx4: 1 KiB of ranges, global_load_lds_dwordx3: 768 B of colours,
+// which the hardware lays down at a 16-byte lane stride -- measured, tools/probes/lds_dma_probe.hip -- so the LDS
+// image of a chunk is 2 KiB and the colours read back as one aligned ds_read_b128) into one of kRing private slots; kAhead = kRing-1 chunks stay in flight behind the one being consumed.
+// The DMAs have no VGPR destination, so prefetch depth costs LDS, not registers, and hipcc can neither sink them
+// next to their use nor drain them early: they live in inline asm and are waited for by hand-counted
+// s_waitcnt vmcnt(2 * chunks still allowed in flight) (vmcnt retires in issue order; cdna_hip_programming.md 5.7).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRing = 3;
+constexpr int kAhead = kRing - 1;
+constexpr int kSlot = 2 * kChunkZ;  // LDS image of one chunk: 1 KiB ranges + 64 x 16 B colours (12 valid)
+
+struct __attribute__((aligned(16))) FitLds {
+    union {
+        uint8_t ring[4][kRing][kSlot];  // phase 1: per-wave chunk ring
+        float red[4][6][kTilePx];        // phase 2: per-pixel sums of the four waves (ring is dead by then)
+    } u;
+    float jbuf[3][kTilePx];              // closed-form J of the tile
+    double wpart[4][kNumSums];
+    double stot[kSumsPad];
+    float wsum[4][kNumSums];
+    int is_last;
+};
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a flat LDS address = LDS offset
 }
+
+// chunk (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address); lane offsets are loop constants
+__device__ __forceinline__ void dma_chunk(const uint8_t *chunk, uint32_t slot, uint32_t voff_z, uint32_t voff_c) {
+#ifndef SUCRE_EXP_NOLOAD
+    unsigned keep;
+    const uint32_t slot_c = slot + kChunkZ;  // colours: 64 lanes x 16 B behind the ranges
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx3 %5, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_z), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff_c)
+        : "memory");
+#endif
+}
+
+// Waits until at most 2*ahead DMA instructions are outstanding.
+template <int kAheadNow>
+__device__ __forceinline__ void wait_chunks() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAheadNow) : "memory");
+}
+
+// Number of list entries (wave, wave+4, ...) this wave consumes.
+__device__ __forceinline__ uint32_t views_of_wave(uint32_t n, int wave) {
+    return n > (uint32_t)wave ? (n - (uint32_t)wave + 3u) / 4u : 0u;
+}
+
+// Ring prologue: put the first kAhead chunks in flight.
+__device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs,
+                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane) {
+    const uint32_t voff_z = lane * 16, voff_c = kChunkZ + lane * 12;
+    const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
+#pragma unroll
+    for (uint32_t d = 0; d < (uint32_t)kAhead; ++d)
+        if (d < r) dma_chunk(tile_obs + (size_t)lst[wave + 4u * d] * kChunk, ring0 + d * kSlot, voff_z, voff_c);
+}
+
+// Ring steady state + drain; stream_begin must have been called for the same (tile, wave).
+template <int kPass>
+__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs,
+                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane,
+                                             const Water &w, const float (&J)[3][4], Acc &acc) {
+    const uint32_t voff_z = lane * 16, voff_c = kChunkZ + lane * 12;
+    const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
+    uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
+    for (uint32_t v = 0; v < r; ++v) {
+        if (v + kAhead < r)
+            dma_chunk(tile_obs + (size_t)lst[wave + 4u * (v + kAhead)] * kChunk, ring0 + slot_in * kSlot, voff_z,
+                      voff_c);
+        const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
+        if (ahead >= (uint32_t)kAhead) wait_chunks<kAhead>();
+        else if (kAhead > 2 && ahead == 2u) wait_chunks<2>();
+        else if (ahead == 1u) wait_chunks<1>();
+        else wait_chunks<0>();
+        const uint8_t *sp = &lds.u.ring[wave][slot][0];
+#ifdef SUCRE_EXP_NOLOAD
+        const float4 z4 = make_float4(2.5f + v, 2.0f + lane, 3.0f, 2.5f);
+        const uint3 c3 = make_uint3(0x10203040u + v, 0x50607080u, 0x11223344u + lane);
+#else
+        const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(sp + kChunkZ + lane * 16);
+        const uint3 c3 = make_uint3(c4.x, c4.y, c4.z);
+#endif
+        accumulate_view<kPass>(z4, c3, w, J, acc);
+        slot = slot + 1 == kRing ? 0 : slot + 1;
+        slot_in = slot_in + 1 == kRing ? 0 : slot_in + 1;
+    }
+    wait_chunks<0>();  // nothing of ours is in flight past this point
+}
+static_assert(kAhead == 2 || kAhead == 3, "wait ladder in stream_views covers kAhead 2 and 3");
 
 __device__ __forceinline__ void zero_acc(Acc &a) {
 #pragma unroll
@@ -142,32 +224,36 @@ __device__ __forceinline__ void zero_acc(Acc &a) {
 }
 
 // Adds the four waves' per-pixel sums (fixed order) and returns, for pixel slot `t`, the six totals.
-__device__ __forceinline__ void reduce_pixels(float (*red)[6][kTilePx], const Acc &acc, int wave, int lane, int t,
-                                              float out[6]) {
+// The leading barrier retires every wave's ring before `red` (which overlays it) is written.
+__device__ __forceinline__ void reduce_pixels(FitLds &lds, const Acc &acc, int wave, int lane, int t, float out[6]) {
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) =
+        *reinterpret_cast<float4 *>(&lds.u.red[wave][c][lane * 4]) =
             make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
-        *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) =
+        *reinterpret_cast<float4 *>(&lds.u.red[wave][3 + c][lane * 4]) =
             make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 6; ++q) out[q] = ((red[0][q][t] + red[1][q][t]) + red[2][q][t]) + red[3][q][t];
+    for (int q = 0; q < 6; ++q)
+        out[q] = ((lds.u.red[0][q][t] + lds.u.red[1][q][t]) + lds.u.red[2][q][t]) + lds.u.red[3][q][t];
 }
 
-// Fixed-order float64 reduction of the per-tile partials by one 256-thread workgroup:
-// sums[q] = sum_tile partials[tile][q].  Same code (hence same bits) in the fused and the split path.
-__device__ __forceinline__ void block_reduce_partials(const float *__restrict__ partials, int n_tiles,
-                                                      double (*wpart)[kNumSums], double *stot,
-                                                      double *__restrict__ sums) {
+// Fixed-order float64 reduction of the per-tile partials (layout [kNumSums][n_tiles]) by one 256-thread
+// workgroup: sums[q] = sum_tile partials[q][tile].  Same code (hence same bits) in the fused and the split path.
+// Partials are read with agent-scope (sc1) loads: they were published by sc1 write-through stores.
+__device__ __forceinline__ void block_reduce_partials(const float *partials, int n_tiles, double (*wpart)[kNumSums],
+                                                      double *stot, double *__restrict__ sums) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double s[kNumSums];
 #pragma unroll
     for (int q = 0; q < kNumSums; ++q) s[q] = 0.0;
     for (int tile = t; tile < n_tiles; tile += 256) {
 #pragma unroll
-        for (int q = 0; q < kNumSums; ++q) s[q] += (double)partials[(size_t)tile * kNumSums + q];
+        for (int q = 0; q < kNumSums; ++q)
+            s[q] += (double)__hip_atomic_load(partials + (size_t)q * n_tiles + tile, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int q = 0; q < kNumSums; ++q) {
@@ -226,26 +312,23 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
                                                        unsigned *ticket, double *sums, double *trace_row) {
-    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
-    __shared__ __attribute__((aligned(16))) float jbuf[3][kTilePx];
-    __shared__ float wsum[4][kNumSums];
-    __shared__ double wpart[4][kNumSums];
-    __shared__ double stot[kSumsPad];
-    __shared__ int is_last;
-    const float *params = pstate;
+    __shared__ FitLds lds;
     const int tile = blockIdx.x;
+    const int n_tiles = gridDim.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(params);
+    const Water w = load_water(pstate);
     const uint32_t n = tile_n[tile];
     const uint32_t *lst = list + (size_t)tile * n_views;
     const uint8_t *tile_obs = obs + (size_t)tile * n_views * kChunk;
     float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
 
+    const uint32_t r = views_of_wave(n, wave);
     float J[3][4];
     Acc acc;
     float tot[6];
+    stream_begin(lds, tile_obs, lst, r, wave, lane);
     if (kClosed) {
         // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
         zero_acc(acc);
@@ -253,39 +336,47 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-        stream_views<kPassClosedJ>(tile_obs, lst, n, wave, lane, w, J, acc);
-        reduce_pixels(red, acc, wave, lane, t, tot);
+        stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+        reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float Jc = tot[c] / tot[3 + c];  // 0/0 = NaN where nothing was observed
             Jtile[c * kTilePx + t] = Jc;
-            jbuf[c][t] = Jc;
+            lds.jbuf[c][t] = Jc;
         }
-        __syncthreads();
+        __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
+        stream_begin(lds, tile_obs, lst, r, wave, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(&jbuf[c][lane * 4]);
+            const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
             J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
         }
     } else {
+        // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count the
+        // asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's first
+        // use; the empty asm makes that first use happen here, where only the prologue (issued at the same time,
+        // hence landing at the same time) is outstanding: one shared start-up latency, nothing drained later.
+        float4 jv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
-            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+            asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
+            J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
         }
     }
 
     zero_acc(acc);
-    if (kClosed) stream_views<kPassGradClosed>(tile_obs, lst, n, wave, lane, w, J, acc);
-    else stream_views<kPassGradJ>(tile_obs, lst, n, wave, lane, w, J, acc);
-    reduce_pixels(red, acc, wave, lane, t, tot);
+    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+    else stream_views<kPassGradJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+    reduce_pixels(lds, acc, wave, lane, t, tot);
 
     // pixel-parallel tail: this thread owns pixel slot t
     float sBeta[3];
     if (kClosed) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float Jc = jbuf[c][t];
+            const float Jc = lds.jbuf[c][t];
             sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
         }
     } else {
@@ -317,35 +408,40 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
     if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < kNumSums; ++q) wsum[wave][q] = s[q];
+        for (int q = 0; q < kNumSums; ++q) lds.wsum[wave][q] = s[q];
     }
     __syncthreads();
-    if (t < kNumSums) partials[(size_t)tile * kNumSums + t] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+    // Publish the tile's partials with agent-scope write-through (sc1) stores: they need no release fence
+    // (a release = L2 write-back in EVERY workgroup measured +260 us per launch; cdna_hip_programming.md section 5,
+    // 'In-launch split-K reduction').
+    if (t < kNumSums)
+        __hip_atomic_store(partials + (size_t)t * n_tiles + tile,
+                           ((lds.wsum[0][t] + lds.wsum[1][t]) + lds.wsum[2][t]) + lds.wsum[3][t], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 
     if (kFused) {
-        // Last-arriver tail: the workgroup that takes the final ticket reduces all partials and steps the water
-        // parameters, so an iteration is ONE launch.  Hand-off per cdna_hip_programming.md Guideline 16:
-        // storing waves drain vmcnt -> workgroup barrier -> one lane: agent release, drain, relaxed agent
-        // atomic; the last arriver: agent acquire, drain, barrier, then plain loads.  No spinning anywhere.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // Last-arriver tail: the workgroup that draws the final ticket reduces all partials and steps the water
+        // parameters, so an iteration is ONE launch.  Hand-off (Guideline 16, sc1 form): the storing wave drains
+        // vmcnt, then one of its lanes does a relaxed agent-scope fetch_add; the last arriver does one agent
+        // acquire, drains, joins a workgroup barrier, and reads the partials with sc1 loads.  Nobody spins.
+        if (t < 64) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned got = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (got == gridDim.x - 1) ? 1 : 0;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+            if (t == 0) {
+                const unsigned got = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (got == (unsigned)n_tiles - 1u) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+                }
+                lds.is_last = last;
             }
-            is_last = last;
         }
         __syncthreads();
-        if (is_last) {  // workgroup-uniform
-            block_reduce_partials(partials, (int)gridDim.x, wpart, stot, sums);
+        if (lds.is_last) {  // workgroup-uniform
+            block_reduce_partials(partials, n_tiles, lds.wpart, lds.stot, sums);
             // every other workgroup has finished (it took its ticket after its last use of the parameters)
-            if (t < 64) water_step(stot, pstate, n_obs_total, co, trace_row);
+            if (t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);
         }
     }
 }
@@ -355,12 +451,16 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ tile_n, int n_views,
                                                        const float *__restrict__ params, float *__restrict__ Jt) {
-    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
+    __shared__ FitLds lds;
     const int tile = blockIdx.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(params);
+    const uint32_t n = tile_n[tile];
+    const uint32_t r = views_of_wave(n, wave);
+    const uint8_t *tile_obs = obs + (size_t)tile * n_views * kChunk;
+    const uint32_t *lst = list + (size_t)tile * n_views;
     float J[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -368,10 +468,10 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
         for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
     Acc acc;
     zero_acc(acc);
-    stream_views<kPassClosedJ>(obs + (size_t)tile * n_views * kChunk, list + (size_t)tile * n_views, tile_n[tile],
-                               wave, lane, w, J, acc);
+    stream_begin(lds, tile_obs, lst, r, wave, lane);
+    stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
     float tot[6];
-    reduce_pixels(red, acc, wave, lane, t, tot);
+    reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
     for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + t] = tot[c] / tot[3 + c];
 }

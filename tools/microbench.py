@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Times the fit kernel of one or more builds of libsucre_hip on a FABRICATED full-cover workspace
+(every tile sees every view), bypassing matching.  Experiment tool, not part of the product or the bench.
+
+usage: python tools/microbench.py [--views 65] [--iters 30] lib1.so [lib2.so ...]
+"""
+import argparse
+import ctypes as C
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from sucre_amd import _lib  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument('libs', nargs='+')
+p.add_argument('--views', type=int, default=65)
+p.add_argument('--iters', type=int, default=30)
+p.add_argument('--height', type=int, default=1080)
+p.add_argument('--width', type=int, default=1920)
+p.add_argument('--split', action='store_true', help='use sucre_fit_grad/step (no fused tail)')
+args = p.parse_args()
+H, W, NV = args.height, args.width, args.views
+
+
+def bind(path):
+    lib = C.CDLL(str(path))
+    for name, (res, a) in _lib.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, a
+    return lib
+
+
+# offsets of private regions: mirror of csrc/layout.h (experiment tool only)
+def layout(H, W, nv):
+    tx, ty = (W + 15) // 16, (H + 15) // 16
+    nt = tx * ty
+    o = 0
+    offs = {}
+    def take(name, b):
+        nonlocal o
+        offs[name] = o
+        o = (o + b + 255) // 256 * 256
+    take('obs', nt * nv * 1792); take('cnt', nt * nv * 2); take('list', nt * nv * 4); take('tile_n', nt * 4)
+    take('view_count', nv * 8); take('view_keep', nv * 4); take('n_obs', 8); take('n_obs_total', 8)
+    take('params', 27 * 4); take('sums', 12 * 8); take('ticket', 4); take('partials', nt * 10 * 4)
+    take('J', nt * 768 * 4); take('m', nt * 768 * 4); take('v', nt * 768 * 4)
+    return nt, offs, o
+
+
+nt, offs, total = layout(H, W, NV)
+dev = torch.device('cuda')
+for path in args.libs:
+    lib = bind(path)
+    assert lib.sucre_workspace_bytes(H, W, NV) == total, (lib.sucre_workspace_bytes(H, W, NV), total)
+    ws = torch.zeros(total, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    # observations: z in [2.5, 3.5], random colours
+    obs = ws[offs['obs']:offs['obs'] + nt * NV * 1792].view(nt * NV, 1792)
+    obs[:, :1024].view(torch.float32).copy_(2.5 + torch.rand((nt * NV, 256), device=dev, generator=g))
+    obs[:, 1024:].copy_(torch.randint(0, 256, (nt * NV, 768), device=dev, generator=g, dtype=torch.uint8))
+    ws[offs['list']:offs['list'] + nt * NV * 4].view(torch.int32).view(nt, NV).copy_(
+        torch.arange(NV, device=dev, dtype=torch.int32).expand(nt, NV))
+    ws[offs['tile_n']:offs['tile_n'] + nt * 4].view(torch.int32).fill_(NV)
+    n_obs = nt * NV * 256
+    ws[offs['n_obs']:offs['n_obs'] + 8].view(torch.int64).fill_(n_obs)
+    ws[offs['n_obs_total']:offs['n_obs_total'] + 8].view(torch.int64).fill_(n_obs)
+    ws[offs['params']:offs['params'] + 36].view(torch.float32).fill_(0.1)
+    ws[offs['J']:offs['J'] + nt * 768 * 4].view(torch.float32).copy_(torch.rand(nt * 768, device=dev, generator=g))
+    wsp = C.c_void_p(ws.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(T, t0):
+        if args.split:
+            for it in range(T):
+                assert lib.sucre_fit_grad(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, 0, st) == 0
+                assert lib.sucre_fit_step(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, None, st) == 0
+        else:
+            assert lib.sucre_fit_run(wsp, H, W, NV, t0, T, 0.05, 0.9, 0.999, 1e-8, 0, None, st) == 0, lib.sucre_last_error()
+
+    run(3, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(args.iters, 3); e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    byts = 7 * n_obs + 72 * H * W
+    print(f'{Path(path).name:40s} {ms * 1e3:9.1f} us/iter   algorithmic {byts / ms / 1e6:8.1f} GB/s   '
+          f'({byts / 1e6:.0f} MB, n_obs {n_obs})', flush=True)
+    del ws
