@@ -57,6 +57,9 @@ __device__ __forceinline__ Water load_water(const float *__restrict__ params) {
 // What one pass over a view accumulates.
 enum Pass { kPassGradJ = 0, kPassClosedJ = 1, kPassGradClosed = 2 };
 
+// Measured on gfx950 (tools/microbench.py, no-load build): a scalar fp32 VALU op issues in 2 cycles per wave64, a
+// packed v_pk_*_f32 in 4 and v_exp_f32 in 4, so writing this loop two-wide saved instructions but not time (and
+// cost 20 VGPRs); it stays scalar.  ~57 issue slots per observation: 6 exp, 3 byte->float, 48 mul/fma/select.
 struct Acc {
     float pa[3][4];  // per pixel-channel: sum r a           | closed-form numerator   sum (I - b) a
     float pb[3][4];  // per pixel-channel: sum r a z         | closed-form denominator sum a^2
@@ -64,6 +67,8 @@ struct Acc {
     float sGZ[3];    // sum r g z
     float cost;      // sum r^2
 };
+
+constexpr float kInv255 = (float)(1.0 / 255.0);
 
 template <int kPass>
 __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
@@ -80,20 +85,30 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
         const bool valid = z > 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float I = unit_from_u8((cc[c] >> (8 * j)) & 255u);
+            const uint32_t k = (cc[c] >> (8 * j)) & 255u;
             const float a = fast_exp2(z * w.nb[c]);
             const float g = fast_exp2(z * w.ng[c]);
             const float omg = 1.0f - g;
             const float bt = w.B[c] * omg;
             if (kPass == kPassClosedJ) {
                 // sucre.py:73-76: numerator += (I - backscatter) * absorption ; denominator += absorption^2
+                const float I = unit_from_u8(k);
                 const float y = valid ? (I - bt) : 0.0f;
                 const float a2 = valid ? a * a : 0.0f;
                 acc.pa[c][j] = __builtin_fmaf(y, a, acc.pa[c][j]);
                 acc.pb[c][j] += a2;
             } else {
                 const float Ihat = __builtin_fmaf(J[c][j], a, bt);
-                const float r = valid ? (I - Ihat) : 0.0f;  // select, not multiply: J may be NaN where unobserved
+                float r;
+                if (kPass == kPassGradClosed) {
+                    // the closed-form trajectory is ill-conditioned (J is re-solved every iteration, gradients are
+                    // tiny): keep the reference's exactly rounded I = float32(k/255) so it is followed closely
+                    r = unit_from_u8(k) - Ihat;
+                } else {
+                    // I = k/255 folded into the residual: one rounding instead of two, two VALU ops fewer
+                    r = __builtin_fmaf((float)k, kInv255, -Ihat);
+                }
+                r = valid ? r : 0.0f;  // select, not multiply: J may be NaN where unobserved
                 const float rz = r * z;
                 acc.cost = __builtin_fmaf(r, r, acc.cost);
                 if (kPass == kPassGradJ) acc.pa[c][j] = __builtin_fmaf(r, a, acc.pa[c][j]);
@@ -109,23 +124,23 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 // Observation streaming: per-wave LDS-DMA ring.
 //
 // Each wave consumes the chunks of views wave, wave+4, ... of the tile's list.  A chunk is copied HBM -> LDS by
-// two LDS-DMA instructions (global_load_lds_dwordx4: 1 KiB of ranges, global_load_lds_dwordx3: 768 B of colours,
-// which the hardware lays down at a 16-byte lane stride -- measured, tools/probes/lds_dma_probe.hip -- so the LDS
-// image of a chunk is 2 KiB and the colours read back as one aligned ds_read_b128) into one of kRing private slots; kAhead = kRing-1 chunks stay in flight behind the one being consumed.
+// two LDS-DMA instructions (global_load_lds_dwordx4: 64 lanes = 1 KiB of ranges, 48 lanes = 768 B of colours)
+// into one of kRing private slots; kAhead = kRing-1 chunks stay in flight behind the one being consumed.
 // The DMAs have no VGPR destination, so prefetch depth costs LDS, not registers, and hipcc can neither sink them
 // next to their use nor drain them early: they live in inline asm and are waited for by hand-counted
 // s_waitcnt vmcnt(2 * chunks still allowed in flight) (vmcnt retires in issue order; cdna_hip_programming.md 5.7).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRing = 3;
 constexpr int kAhead = kRing - 1;
-constexpr int kSlot = 2 * kChunkZ;  // LDS image of one chunk: 1 KiB ranges + 64 x 16 B colours (12 valid)
+constexpr int kSlot = kChunk;  // LDS image of one chunk = byte-exact copy
 
-struct __attribute__((aligned(16))) FitLds {
+template <bool kWithJ>
+struct __attribute__((aligned(16))) FitLdsT {
     union {
         uint8_t ring[4][kRing][kSlot];  // phase 1: per-wave chunk ring
         float red[4][6][kTilePx];        // phase 2: per-pixel sums of the four waves (ring is dead by then)
     } u;
-    float jbuf[3][kTilePx];              // closed-form J of the tile
+    float jbuf[kWithJ ? 3 : 1][kWithJ ? kTilePx : 4];  // closed-form J of the tile (closed-form kernels only)
     double wpart[4][kNumSums];
     double stot[kSumsPad];
     float wsum[4][kNumSums];
@@ -136,23 +151,32 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a flat LDS address = LDS offset
 }
 
-// chunk (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address); lane offsets are loop constants
-__device__ __forceinline__ void dma_chunk(const uint8_t *chunk, uint32_t slot, uint32_t voff_z, uint32_t voff_c) {
+#ifndef SUCRE_DMA_POLICY
+#define SUCRE_DMA_POLICY " nt"  // chunks are read once per launch: streaming policy (measured -20 % vs default)
+#endif
+
+// chunk (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address); lane offsets are loop constants.
+// A dwordx4 LDS-DMA writes lane i's 16 bytes at slot + 16 i (a dwordx3 one also strides by 16, leaving holes --
+// measured, tools/probes/lds_dma_probe.hip), so the 768 colour bytes are moved by the first 48 lanes of a second
+// dwordx4: the LDS image is a byte-exact copy of the 1792-byte chunk.  EXEC is all ones here (whole workgroup
+// runs this code) and is restored inside the statement; M0 is written in the statement that reads it.
+__device__ __forceinline__ void dma_chunk(const uint8_t *chunk, uint32_t slot, uint32_t voff) {
 #ifndef SUCRE_EXP_NOLOAD
     unsigned keep;
-    const uint32_t slot_c = slot + kChunkZ;  // colours: 64 lanes x 16 B behind the ranges
+    const uint32_t slot_c = slot + kChunkZ;
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
         "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx3 %5, %2\n\t"
+        "s_mov_b32 exec_hi, 0xffff\n\t"
+        "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
+        "s_mov_b32 exec_hi, -1\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff_z), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff_c)
+        : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
         : "memory");
 #endif
 }
@@ -169,41 +193,43 @@ __device__ __forceinline__ uint32_t views_of_wave(uint32_t n, int wave) {
 }
 
 // Ring prologue: put the first kAhead chunks in flight.
+template <class FitLds>
 __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs,
-                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane) {
-    const uint32_t voff_z = lane * 16, voff_c = kChunkZ + lane * 12;
+                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane,
+                                             size_t view_stride) {
+    const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
+#ifdef SUCRE_EXP_NOLOAD  // experiment build only: no DMA; the ring holds plausible constant data instead
+    for (int sl = 0; sl < kRing; ++sl) {
+        *reinterpret_cast<float4 *>(&lds.u.ring[wave][sl][lane * 16]) = make_float4(2.5f, 2.75f, 3.0f, 3.25f);
+        if (lane < 48) *reinterpret_cast<uint4 *>(&lds.u.ring[wave][sl][kChunkZ + lane * 16]) =
+            make_uint4(0x10203040u, 0x50607080u, 0x11223344u, 0x55667788u);
+    }
+#endif
 #pragma unroll
     for (uint32_t d = 0; d < (uint32_t)kAhead; ++d)
-        if (d < r) dma_chunk(tile_obs + (size_t)lst[wave + 4u * d] * kChunk, ring0 + d * kSlot, voff_z, voff_c);
+        if (d < r) dma_chunk(tile_obs + (size_t)lst[wave + 4u * d] * view_stride, ring0 + d * kSlot, voff);
 }
 
 // Ring steady state + drain; stream_begin must have been called for the same (tile, wave).
-template <int kPass>
+template <int kPass, class FitLds>
 __device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs,
                                              const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane,
-                                             const Water &w, const float (&J)[3][4], Acc &acc) {
-    const uint32_t voff_z = lane * 16, voff_c = kChunkZ + lane * 12;
+                                             size_t view_stride, const Water &w, const float (&J)[3][4], Acc &acc) {
+    const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
     uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
     for (uint32_t v = 0; v < r; ++v) {
         if (v + kAhead < r)
-            dma_chunk(tile_obs + (size_t)lst[wave + 4u * (v + kAhead)] * kChunk, ring0 + slot_in * kSlot, voff_z,
-                      voff_c);
+            dma_chunk(tile_obs + (size_t)lst[wave + 4u * (v + kAhead)] * view_stride, ring0 + slot_in * kSlot, voff);
         const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
         if (ahead >= (uint32_t)kAhead) wait_chunks<kAhead>();
         else if (kAhead > 2 && ahead == 2u) wait_chunks<2>();
         else if (ahead == 1u) wait_chunks<1>();
         else wait_chunks<0>();
         const uint8_t *sp = &lds.u.ring[wave][slot][0];
-#ifdef SUCRE_EXP_NOLOAD
-        const float4 z4 = make_float4(2.5f + v, 2.0f + lane, 3.0f, 2.5f);
-        const uint3 c3 = make_uint3(0x10203040u + v, 0x50607080u, 0x11223344u + lane);
-#else
         const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
-        const uint4 c4 = *reinterpret_cast<const uint4 *>(sp + kChunkZ + lane * 16);
-        const uint3 c3 = make_uint3(c4.x, c4.y, c4.z);
-#endif
+        const uint3 c3 = *reinterpret_cast<const uint3 *>(sp + kChunkZ + lane * 12);
         accumulate_view<kPass>(z4, c3, w, J, acc);
         slot = slot + 1 == kRing ? 0 : slot + 1;
         slot_in = slot_in + 1 == kRing ? 0 : slot_in + 1;
@@ -225,6 +251,7 @@ __device__ __forceinline__ void zero_acc(Acc &a) {
 
 // Adds the four waves' per-pixel sums (fixed order) and returns, for pixel slot `t`, the six totals.
 // The leading barrier retires every wave's ring before `red` (which overlays it) is written.
+template <class FitLds>
 __device__ __forceinline__ void reduce_pixels(FitLds &lds, const Acc &acc, int wave, int lane, int t, float out[6]) {
     __syncthreads();
 #pragma unroll
@@ -311,8 +338,9 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
-                                                       unsigned *ticket, double *sums, double *trace_row) {
-    __shared__ FitLds lds;
+                                                       unsigned *ticket, double *sums, double *trace_row,
+                                                       size_t tile_stride, size_t view_stride) {
+    __shared__ FitLdsT<kClosed> lds;  // 25.2 KB (6 workgroups/CU) without jbuf, 28.2 KB (5) with it
     const int tile = blockIdx.x;
     const int n_tiles = gridDim.x;
     const int t = threadIdx.x;
@@ -321,14 +349,14 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     const Water w = load_water(pstate);
     const uint32_t n = tile_n[tile];
     const uint32_t *lst = list + (size_t)tile * n_views;
-    const uint8_t *tile_obs = obs + (size_t)tile * n_views * kChunk;
+    const uint8_t *tile_obs = obs + (size_t)tile * tile_stride;
     float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
 
     const uint32_t r = views_of_wave(n, wave);
     float J[3][4];
     Acc acc;
     float tot[6];
-    stream_begin(lds, tile_obs, lst, r, wave, lane);
+    stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
     if (kClosed) {
         // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
         zero_acc(acc);
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-        stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+        stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
         reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
             lds.jbuf[c][t] = Jc;
         }
         __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
-        stream_begin(lds, tile_obs, lst, r, wave, lane);
+        stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
@@ -367,8 +395,8 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
 
     zero_acc(acc);
-    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
-    else stream_views<kPassGradJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
+    else stream_views<kPassGradJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
     reduce_pixels(lds, acc, wave, lane, t, tot);
 
     // pixel-parallel tail: this thread owns pixel slot t
@@ -450,8 +478,9 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
 __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ obs,
                                                        const uint32_t *__restrict__ list,
                                                        const uint32_t *__restrict__ tile_n, int n_views,
-                                                       const float *__restrict__ params, float *__restrict__ Jt) {
-    __shared__ FitLds lds;
+                                                       const float *__restrict__ params, float *__restrict__ Jt,
+                                                       size_t tile_stride, size_t view_stride) {
+    __shared__ FitLdsT<false> lds;
     const int tile = blockIdx.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -459,7 +488,7 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
     const Water w = load_water(params);
     const uint32_t n = tile_n[tile];
     const uint32_t r = views_of_wave(n, wave);
-    const uint8_t *tile_obs = obs + (size_t)tile * n_views * kChunk;
+    const uint8_t *tile_obs = obs + (size_t)tile * tile_stride;
     const uint32_t *lst = list + (size_t)tile * n_views;
     float J[3][4];
 #pragma unroll
@@ -468,8 +497,8 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
         for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
     Acc acc;
     zero_acc(acc);
-    stream_begin(lds, tile_obs, lst, r, wave, lane);
-    stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, w, J, acc);
+    stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
+    stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
     float tot[6];
     reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
@@ -550,7 +579,7 @@ static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co
                        reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
                        reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_partials), co,
                        reinterpret_cast<unsigned *>(ws + L.off_ticket), reinterpret_cast<double *>(ws + L.off_sums),
-                       trace_row);
+                       trace_row, L.obs_tile_stride, L.obs_view_stride);
 }
 
 // One whole iteration in a single launch (gradient pass + last-arriver reduction + water-parameter step).
@@ -583,7 +612,8 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s) {
     hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
                        reinterpret_cast<const uint32_t *>(ws + L.off_list),
                        reinterpret_cast<const uint32_t *>(ws + L.off_tile_n), L.n_views,
-                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J));
+                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J),
+                       L.obs_tile_stride, L.obs_view_stride);
     return hipGetLastError();
 }
 

@@ -16,7 +16,8 @@ constexpr int kMaxViews = 4096;
 
 struct Layout {
     int H, W, n_views, tiles_x, tiles_y, n_tiles;
-    size_t off_obs;         // uint8  [n_tiles][n_views][kChunk]
+    size_t off_obs;         // uint8  chunks of kChunk bytes, chunk(tile, k) at tile*obs_tile_stride + k*obs_view_stride
+    size_t obs_tile_stride, obs_view_stride;
     size_t off_cnt;         // uint16 [n_tiles][n_views]   matches of view k inside the tile
     size_t off_list;        // uint32 [n_tiles][n_views]   compacted indices of kept, non-empty views
     size_t off_tile_n;      // uint32 [n_tiles]            length of that list
@@ -44,6 +45,11 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L->off_obs = take(nt * nv * kChunk);
+#ifdef SUCRE_OBS_VIEW_MAJOR
+    L->obs_tile_stride = kChunk; L->obs_view_stride = nt * kChunk;      // [view][tile]
+#else
+    L->obs_tile_stride = nv * kChunk; L->obs_view_stride = kChunk;      // [tile][view]
+#endif
     L->off_cnt = take(nt * nv * sizeof(uint16_t));
     L->off_list = take(nt * nv * sizeof(uint32_t));
     L->off_tile_n = take(nt * sizeof(uint32_t));

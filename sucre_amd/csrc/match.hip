@@ -56,7 +56,8 @@ constexpr int kViewsPerGroup = 16;
 __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                     const float *__restrict__ depth1, const CamDev c1,
                                                     const sucre_view_t *__restrict__ views, int n_views, int k0,
-                                                    int k1, int tiles_x, int n_tiles, int tiles_per_xcd) {
+                                                    int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
+                                                    size_t tile_stride, size_t view_stride) {
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         }
         if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
-            uint8_t *chunk = obs + ((size_t)tile * n_views + k) * kChunk;
+            uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
             *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ + lane * 12);
             c[0] = r4; c[1] = g4; c[2] = b4;
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void tile_list_kernel(const uint16_t *__restri
 __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restrict__ obs,
                                                           const uint16_t *__restrict__ cnt, int n_views, int k,
                                                           int tiles_x, int H, int W, float *__restrict__ z_out,
-                                                          uint8_t *__restrict__ rgb_out) {
+                                                          uint8_t *__restrict__ rgb_out, size_t tile_stride,
+                                                          size_t view_stride) {
     const int tile = blockIdx.x;
     const int slot = threadIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restr
     float z = 0.0f;
     uint8_t c[3] = {0, 0, 0};
     if (cnt[(size_t)tile * n_views + k] > 0) {
-        const uint8_t *chunk = obs + ((size_t)tile * n_views + k) * kChunk;
+        const uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
         z = reinterpret_cast<const float *>(chunk)[slot];
         const uint8_t *p = chunk + kChunkZ + (slot >> 2) * 12 + (slot & 3);
         c[0] = p[0]; c[1] = p[4]; c[2] = p[8];
@@ -227,7 +229,7 @@ hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target
     const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
     hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
                        reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
-                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd);
+                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride);
     return hipGetLastError();
 }
 
@@ -247,7 +249,8 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
 
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {
     hipLaunchKernelGGL(export_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
-                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, k, L.tiles_x, L.H, L.W, z, rgb);
+                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, k, L.tiles_x, L.H, L.W, z, rgb,
+                       L.obs_tile_stride, L.obs_view_stride);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ p = argparse.ArgumentParser()
 p.add_argument('libs', nargs='+')
 p.add_argument('--views', type=int, default=65)
 p.add_argument('--iters', type=int, default=30)
+p.add_argument('--rounds', type=int, default=7)
 p.add_argument('--height', type=int, default=1080)
 p.add_argument('--width', type=int, default=1920)
 p.add_argument('--split', action='store_true', help='use sucre_fit_grad/step (no fused tail)')
@@ -52,41 +53,57 @@ def layout(H, W, nv):
 
 nt, offs, total = layout(H, W, NV)
 dev = torch.device('cuda')
-for path in args.libs:
-    lib = bind(path)
-    assert lib.sucre_workspace_bytes(H, W, NV) == total, (lib.sucre_workspace_bytes(H, W, NV), total)
+n_obs = nt * NV * 256
+byts = 7 * n_obs + 72 * H * W
+
+
+def make_ws():
     ws = torch.zeros(total, dtype=torch.uint8, device=dev)
     g = torch.Generator(device=dev); g.manual_seed(0)
-    # observations: z in [2.5, 3.5], random colours
     obs = ws[offs['obs']:offs['obs'] + nt * NV * 1792].view(nt * NV, 1792)
     obs[:, :1024].view(torch.float32).copy_(2.5 + torch.rand((nt * NV, 256), device=dev, generator=g))
     obs[:, 1024:].copy_(torch.randint(0, 256, (nt * NV, 768), device=dev, generator=g, dtype=torch.uint8))
     ws[offs['list']:offs['list'] + nt * NV * 4].view(torch.int32).view(nt, NV).copy_(
         torch.arange(NV, device=dev, dtype=torch.int32).expand(nt, NV))
     ws[offs['tile_n']:offs['tile_n'] + nt * 4].view(torch.int32).fill_(NV)
-    n_obs = nt * NV * 256
     ws[offs['n_obs']:offs['n_obs'] + 8].view(torch.int64).fill_(n_obs)
     ws[offs['n_obs_total']:offs['n_obs_total'] + 8].view(torch.int64).fill_(n_obs)
     ws[offs['params']:offs['params'] + 36].view(torch.float32).fill_(0.1)
     ws[offs['J']:offs['J'] + nt * 768 * 4].view(torch.float32).copy_(torch.rand(nt * 768, device=dev, generator=g))
-    wsp = C.c_void_p(ws.data_ptr())
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ws
 
-    def run(T, t0):
-        if args.split:
-            for it in range(T):
-                assert lib.sucre_fit_grad(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, 0, st) == 0
-                assert lib.sucre_fit_step(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, None, st) == 0
-        else:
-            assert lib.sucre_fit_run(wsp, H, W, NV, t0, T, 0.05, 0.9, 0.999, 1e-8, 0, None, st) == 0, lib.sucre_last_error()
 
-    run(3, 0)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); run(args.iters, 3); e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.iters
-    byts = 7 * n_obs + 72 * H * W
-    print(f'{Path(path).name:40s} {ms * 1e3:9.1f} us/iter   algorithmic {byts / ms / 1e6:8.1f} GB/s   '
-          f'({byts / 1e6:.0f} MB, n_obs {n_obs})', flush=True)
-    del ws
+ws = make_ws()   # one workspace shared by all builds (same bytes, same addresses)
+wsp = C.c_void_p(ws.data_ptr())
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+libs = []
+for path in args.libs:
+    lib = bind(path)
+    assert lib.sucre_workspace_bytes(H, W, NV) == total, (path, lib.sucre_workspace_bytes(H, W, NV), total)
+    libs.append((Path(path).name, lib))
+
+
+def run(lib, T, t0):
+    if args.split:
+        for it in range(T):
+            assert lib.sucre_fit_grad(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, 0, st) == 0
+            assert lib.sucre_fit_step(wsp, H, W, NV, t0 + it + 1, 0.05, 0.9, 0.999, 1e-8, None, st) == 0
+    else:
+        assert lib.sucre_fit_run(wsp, H, W, NV, t0, T, 0.05, 0.9, 0.999, 1e-8, 0, None, st) == 0, lib.sucre_last_error()
+
+
+for _, lib in libs:   # warm-up: clocks, page tables, code objects
+    run(lib, 20, 0)
+torch.cuda.synchronize()
+times = {name: [] for name, _ in libs}
+for rnd in range(args.rounds):   # interleaved rounds: order effects average out
+    for name, lib in libs:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(lib, args.iters, 20); e1.record()
+        torch.cuda.synchronize()
+        times[name].append(e0.elapsed_time(e1) / args.iters)
+for name, _ in libs:
+    t = sorted(times[name])
+    med = t[len(t) // 2]
+    print(f'{name:36s} median {med * 1e3:8.1f} us/iter (min {t[0] * 1e3:.1f} max {t[-1] * 1e3:.1f})   '
+          f'algorithmic {byts / med / 1e6:8.1f} GB/s   ({byts / 1e6:.0f} MB, n_obs {n_obs})', flush=True)
