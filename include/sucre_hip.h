@@ -93,6 +93,15 @@ int sucre_match_views(void *ws, int H, int W, int n_views, const sucre_view_t *t
                       const sucre_view_t *views_dev, int k0, int k1, void *stream);
 
 /*
+ * Image.match_two_way (sfm.py:121-125) of the target against view k in dense form: map_dev[(v1,u1)] = v2*W2 + u2
+ * of the matched pixel, or -1 (H*W int32).  The (u1,v1,u2,v2) lists of sfm.Matches (sfm.py:145-152) are its
+ * non-negative entries in row-major order.  Needs no workspace.  Used by the sfm.Matches compatibility API,
+ * the HDF5 shim of loader.MatchesFile.save_matches (loader.py:68-76) and the parity tests.
+ */
+int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const sucre_view_t *views_dev, int k,
+                    int32_t *map_dev, void *stream);
+
+/*
  * The `len(matches) / (W*H) > min_cover` rule (sfm.py:136) for every view, n_obs, and the per-tile view lists
  * the fit iterates over.  Call once after all sucre_match_views calls.
  */

@@ -166,3 +166,36 @@ def update_J(H: int, W: int, samples, params) -> np.ndarray:
     if rc != 0:
         raise MemoryError('oracle_update_J')
     return J
+
+
+class SharedWaterImage:
+    """One image of a shared-water (lock-step) fit on the CPU oracle: holds J and its Adam moments."""
+
+    def __init__(self, H: int, W: int, samples, J0: np.ndarray, lr: float = 0.05):
+        self.H, self.W, self.lr = H, W, lr
+        self.s = _Samples(samples)
+        self.J = np.ascontiguousarray(J0, np.float32).copy()
+        self.mJ = np.zeros_like(self.J)
+        self.vJ = np.zeros_like(self.J)
+        self.n_obs = int(self.s.counts.sum())
+
+    def grad(self, params: np.ndarray, step: int, n_obs_total: int) -> np.ndarray:
+        sums = np.zeros(10, np.float64)
+        params = np.ascontiguousarray(params, np.float32)
+        lib().oracle_shared_grad.restype = C.c_int
+        rc = lib().oracle_shared_grad(C.c_int(self.H), C.c_int(self.W), C.c_int(self.s.n), _p(self.s.counts, C.c_int64),
+                                      self.s.us, self.s.vs, self.s.cPs, self.s.Is, _p(self.J, C.c_float),
+                                      _p(self.mJ, C.c_float), _p(self.vJ, C.c_float), _p(params, C.c_float),
+                                      C.c_int(step), C.c_double(self.lr), C.c_int64(n_obs_total), _p(sums, C.c_double))
+        if rc != 0:
+            raise MemoryError('oracle_shared_grad')
+        return sums
+
+
+def shared_step(pstate: np.ndarray, sums: np.ndarray, step: int, n_obs_total: int, lr: float = 0.05) -> None:
+    """In-place Adam step of the 27-float water state (params, exp_avg, exp_avg_sq)."""
+    assert pstate.dtype == np.float32 and pstate.size == 27 and pstate.flags.c_contiguous
+    sums = np.ascontiguousarray(sums, np.float64)
+    lib().oracle_shared_step.restype = None
+    lib().oracle_shared_step(_p(pstate, C.c_float), _p(sums, C.c_double), C.c_int(step), C.c_double(lr),
+                             C.c_int64(n_obs_total))

@@ -315,3 +315,53 @@ void oracle_init_J(const uint8_t *rgb, const float *depth, int H, int W, float *
         for (int c = 0; c < 3; ++c)
             J[p * 3 + c] = (depth[p] <= 0) ? NAN : (float)((double)rgb[p * 3 + c] / 255.0);
 }
+
+/*
+ * Shared-water extension (north star; NOT reference behaviour): several images step in lock-step and share
+ * B, beta, gamma; objective  sum_images sum_obs r^2 / (3 * n_obs_total).  Oracle = the reference's per-image
+ * arithmetic (oracle_fit above) with the gradient scale taken from the total observation count and the nine
+ * water gradients summed over images before one Adam step (a tied-parameter composition of reference modules,
+ * SURVEY.md section 8e).  One image's half-iteration:
+ *   sums[0..2] = dS/dB, sums[3..5] = dS/dbeta, sums[6..8] = dS/dgamma for S = sum r^2 (unscaled, float64),
+ *   sums[9] = S;  J takes its Adam step with gradient (dS/dJ) * (1/3)/n_obs_total.
+ */
+int oracle_shared_grad(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                       const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
+                       float *mJ, float *vJ, const float *params, int step, double lr, int64_t n_obs_total,
+                       double *sums) {
+    const size_t npx = (size_t)H * W * 3;
+    float *gJ = (float *)calloc(npx, sizeof(float));
+    if (!gJ) return -1;
+    const float scale = (1.0f / 3.0f) / (float)n_obs_total;
+    const float *B = params, *beta = params + 3, *gamma = params + 6;
+    for (int k = 0; k < 10; ++k) sums[k] = 0.0;
+    for (int s = 0; s < n_samples; ++s) {
+        const int64_t n = counts[s];
+        for (int64_t i = 0; i < n; ++i) {
+            const float z = norm3(cPs[s], n, i);
+            const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
+            for (int c = 0; c < 3; ++c) {
+                const float a = expf(-beta[c] * z), g = expf(-gamma[c] * z);
+                const float Jc = J[px + c];
+                const float r = Is[s][c * n + i] - (Jc * a + B[c] * (1.0f - g));
+                sums[9] += (double)r * (double)r;
+                gJ[px + c] += (-2.0f * r * scale) * a;
+                sums[c] += (double)(-2.0f * r * (1.0f - g));
+                sums[3 + c] += (double)(-2.0f * r * Jc * a * -z);
+                sums[6 + c] += (double)(-2.0f * r * B[c] * g * z);
+            }
+        }
+    }
+    const adam_coef_t co = adam_coef(step, lr, 0.9, 0.999, 1e-8);
+    for (size_t i = 0; i < npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
+    free(gJ);
+    return 0;
+}
+
+/* pstate = params[9], exp_avg[9], exp_avg_sq[9]; sums = all-reduced output of oracle_shared_grad */
+void oracle_shared_step(float *pstate, const double *sums, int step, double lr, int64_t n_obs_total) {
+    const float scale = (1.0f / 3.0f) / (float)n_obs_total;
+    const adam_coef_t co = adam_coef(step, lr, 0.9, 0.999, 1e-8);
+    for (int k = 0; k < 9; ++k)
+        adam_step(&pstate[k], &pstate[9 + k], &pstate[18 + k], (float)(sums[k] * (double)scale), &co);
+}

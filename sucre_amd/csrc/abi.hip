@@ -102,6 +102,17 @@ int sucre_match_views(void *ws, int H, int W, int n_views, const sucre_view_t *t
                                   static_cast<hipStream_t>(stream)), "sucre_match_views");
 }
 
+int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const sucre_view_t *views_dev, int k,
+                    int32_t *map_dev, void *stream) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) return fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views);
+    if (!target || !views_dev || !map_dev) return fail(SUCRE_ERR_ARG, "target / views_dev / map_dev is NULL");
+    if (!target->depth) return fail(SUCRE_ERR_ARG, "target depth map is NULL");
+    if (target->H != H || target->W != W) return fail(SUCRE_ERR_ARG, "target is %dx%d, expected %dx%d", target->W, target->H, W, H);
+    if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
+    return check_hip(launch_match_map(L, *target, views_dev, k, map_dev, static_cast<hipStream_t>(stream)), "sucre_match_map");
+}
+
 int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;

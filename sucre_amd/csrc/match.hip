@@ -51,6 +51,26 @@ __device__ __forceinline__ bool project(const float *Rinv, const float *tinv, co
     return (*px > -1.0f) && (*px < Wf) && (*py > -1.0f) && (*py < Hf);
 }
 
+// The fused two-way test for one target pixel whose world point is wP: returns true and the matched pixel of
+// view 2 (linear index q, camera-frame point c2) iff p1 -> p2 -> p1 closes (see the file header).
+__device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H1f, const sucre_view_t *vw,
+                                            float W2f, float H2f, const float wP[3], int u1, int v1, size_t *q_out,
+                                            float c2[3]) {
+    float px, py;
+    if (!project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP, &px, &py)) return false;
+    const int u2 = (int)px, v2 = (int)py;
+    const size_t q = (size_t)v2 * vw->W + u2;
+    const float d2 = vw->depth[q];
+    if (!(d2 > 0.0f)) return false;
+    float w2[3], qx, qy;
+    unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
+    rigid(vw->R, vw->t, c2, w2);
+    if (!project(c1.Rinv, c1.tinv, c1.K, W1f, H1f, w2, &qx, &qy)) return false;
+    if ((int)qx != u1 || (int)qy != v1) return false;
+    *q_out = q;
+    return true;
+}
+
 constexpr int kViewsPerGroup = 16;
 
 __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
@@ -86,10 +106,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
     const int ke = min(kb + kViewsPerGroup, k1);
     for (int k = kb + wave; k < ke; k += 4) {
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
-        const float *__restrict__ depth2 = vw->depth;
         const uint8_t *__restrict__ rgb2 = vw->rgb;
-        const int W2 = vw->W;
-        const float W2f = (float)W2, H2f = (float)vw->H;
+        const float W2f = (float)vw->W, H2f = (float)vw->H;
         float zo[4];
         uint32_t r4 = 0, g4 = 0, b4 = 0;
         int total = 0;
@@ -99,25 +117,13 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             float z = 0.0f;
             uint32_t r = 0, g = 0, b = 0;
             if (m) {
-                float px, py;
-                m = project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP[j], &px, &py);
+                size_t q;
+                float c2[3];
+                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
                 if (m) {
-                    const int u2 = (int)px, v2 = (int)py;
-                    const size_t q = (size_t)v2 * W2 + u2;
-                    const float d2 = depth2[q];
-                    m = d2 > 0.0f;
-                    if (m) {
-                        float c2[3], w2[3], qx, qy;
-                        unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
-                        rigid(vw->R, vw->t, c2, w2);
-                        m = project(c1.Rinv, c1.tinv, c1.K, W1f, H1f, w2, &qx, &qy);
-                        m = m && ((int)qx == u1b + j) && ((int)qy == v1);
-                        if (m) {
-                            z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
-                            const uint8_t *p = rgb2 + q * 3;
-                            r = p[0]; g = p[1]; b = p[2];
-                        }
-                    }
+                    z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+                    const uint8_t *p = rgb2 + q * 3;
+                    r = p[0]; g = p[1]; b = p[2];
                 }
             }
             zo[j] = z;
@@ -134,6 +140,28 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             c[0] = r4; c[1] = g4; c[2] = b4;
         }
     }
+}
+
+// Explicit correspondences of one view: map[v1*W + u1] = v2*W2 + u2, or -1 (the (u1,v1,u2,v2) lists of
+// sfm.Matches, sfm.py:145-152, in dense form).  One thread per target pixel; same per-pixel test as match_kernel.
+__global__ __launch_bounds__(256) void match_map_kernel(const float *__restrict__ depth1, const CamDev c1,
+                                                        const sucre_view_t *__restrict__ views, int k,
+                                                        int32_t *__restrict__ map) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= c1.H * c1.W) return;
+    const int v1 = idx / c1.W, u1 = idx - v1 * c1.W;
+    const float d = depth1[idx];
+    int32_t out = -1;
+    if (d > 0.0f) {
+        const sucre_view_t *vw = views + k;
+        float cP[3], wP[3], c2[3];
+        size_t q;
+        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
+        rigid(c1.R, c1.t, cP, wP);
+        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, (float)vw->W, (float)vw->H, wP, u1, v1, &q, c2))
+            out = (int32_t)q;
+    }
+    map[idx] = out;
 }
 
 // len(matches) per view and the min_cover rule of sfm.py:136 (Python int/int true division, strict >).
@@ -230,6 +258,13 @@ hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target
     hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
                        reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
                        L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
+                            int32_t *map, hipStream_t s) {
+    hipLaunchKernelGGL(match_map_kernel, dim3((L.H * L.W + 255) / 256), dim3(256), 0, s, target.depth, to_cam(target),
+                       views_dev, k, map);
     return hipGetLastError();
 }
 

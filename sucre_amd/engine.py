@@ -94,6 +94,18 @@ class Restoration:
                                                   0, n, _stream_ptr()))
             _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
 
+    def match_map(self, k: int) -> torch.Tensor:
+        """(H,W) int32: linear pixel index v2*W2+u2 in view k matched to every target pixel, -1 = none
+        (dense form of sfm.Matches).  ``match`` must have been called (it uploads the view table)."""
+        assert self._views_dev is not None, 'call match() first'
+        out = torch.empty((self.H, self.W), dtype=torch.int32, device=self.device)
+        tgt = self._keepalive[0].to_struct()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_match_map(self.H, self.W, self.n_views, C.byref(tgt),
+                                                C.c_void_p(self._views_dev.data_ptr()), int(k),
+                                                C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
+
     def view_counts(self) -> torch.Tensor:
         return self._region(_lib.WS_VIEW_COUNT, torch.int64, self.n_views)
 
@@ -130,9 +142,11 @@ class Restoration:
         self.steps_done = 0
 
     def fit(self, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
-            eps: float = 1e-8, record_trace: bool = True) -> torch.Tensor | None:
+            eps: float = 1e-8, record_trace: bool = True, finalize: bool = True) -> torch.Tensor | None:
         """Enqueues ``num_iter`` Adam iterations without any host sync; returns the (num_iter,10) float64
-        device trace (cost, B, beta, gamma per iteration) or None."""
+        device trace (cost, B, beta, gamma per iteration) or None.  In closed-form mode the C ABI appends the
+        final ``update_J`` of sucre.py:156 to every ``sucre_fit_run`` call; that is idempotent, so a fit split
+        into several calls (``finalize`` is kept for readability) ends in the same state."""
         trace = torch.zeros((num_iter, 10), dtype=torch.float64, device=self.device) if record_trace else None
         flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
         ws, H, W, n = self._geom
@@ -205,3 +219,22 @@ class HipWaterBackend:
         with torch.cuda.device(self.r.device):
             _lib.check(self.r.lib.sucre_fit_step(ws, H, W, nv, int(step), *self.hyper, row, _stream_ptr()))
         self.r.steps_done = int(step)
+
+
+_POOL: dict = {}
+
+
+def acquire_restoration(height: int, width: int, n_views: int, device='cuda') -> Restoration:
+    """Workspace pool: one Restoration per (geometry, device), reused image after image (the 1080p x 65-view
+    workspace is ~1 GB; re-allocating it per image would serialise on the allocator)."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (int(height), int(width), int(n_views), str(dev))
+    if key not in _POOL:
+        _POOL[key] = Restoration(height, width, n_views, device=dev)
+    return _POOL[key]
+
+
+def release_pool() -> None:
+    _POOL.clear()

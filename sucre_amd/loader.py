@@ -1,0 +1,281 @@
+"""Data side of the drop-in: pixel loaders and the matches containers.
+
+Mirrors the reference's ``loader`` module (loader.py:33-180): ``MatchesSample``, ``MatchesData``, ``MatchesFile``,
+``ImageDataset``, ``load_rgb``, ``load_depth_map``, ``load_image_list`` keep their names and call signatures.
+What changes is where the observations live.  The reference spills every match to an HDF5 file (24 B/obs),
+re-reads it three times and keeps 28 B/obs on the host, re-uploading everything each Adam iteration
+(loader.py:46-49, 68-118).  Here ``MatchesFile`` is a handle on the engine's observation store in HBM
+(7 B/obs, written once by the match kernel); ``prepare_matches`` / ``check_integrity`` / ``load_matches`` keep their
+meaning but move no data, and ``MatchesData`` wraps the same store.  ``MatchesData.iter`` still yields the
+reference's ``(u, v, cP, I)`` batches for code written against it.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.utils.data import DataLoader, Dataset
+
+MatchesSample = namedtuple('MatchesSample', ['u', 'v', 'cP', 'I'])
+
+
+# ---- pixel loaders ----------------------------------------------------------------------------------------------------
+
+def _imread_rgb_u8(path: Path) -> np.ndarray:
+    try:
+        import cv2
+        bgr = cv2.imread(str(path))
+        if bgr is None:
+            raise FileNotFoundError(path)
+        return cv2.cvtColor(bgr, cv2.COLOR_BGR2RGB)
+    except ImportError:
+        from PIL import Image as PILImage
+        with PILImage.open(path) as im:
+            return np.asarray(im.convert('RGB'))
+
+
+def _imread_depth_u16(path: Path) -> np.ndarray:
+    try:
+        import cv2
+        d = cv2.imread(str(path), cv2.IMREAD_UNCHANGED)
+        if d is None:
+            raise FileNotFoundError(path)
+        return d
+    except ImportError:
+        from PIL import Image as PILImage
+        with PILImage.open(path) as im:
+            return np.asarray(im)
+
+
+def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor:
+    """(H,W,3) uint8 colour image: the engine's input format (source pixels are exactly k/255)."""
+    rgb = _imread_rgb_u8(Path(rgb_path))
+    if rgb.shape[0] != height or rgb.shape[1] != width:
+        raise NotImplementedError(
+            f'{rgb_path}: image is {rgb.shape[1]}x{rgb.shape[0]} but the camera is {width}x{height}; resized '
+            f'(--image-scale != 1) colours are not multiples of 1/255 and need the float32 observation format, '
+            f'which this build does not have yet')
+    return torch.from_numpy(np.array(rgb, dtype=np.uint8, order="C"))
+
+
+def load_rgb(rgb_path: Path, width: int, height: int) -> Tensor:
+    """(H,W,3) float32 colour in [0,1]: ``uint8 / 255`` evaluated in float64 then cast (loader.py:156-163)."""
+    rgb = _imread_rgb_u8(Path(rgb_path)) / 255
+    if rgb.shape[0] != height or rgb.shape[1] != width:
+        import cv2  # resizing needs OpenCV's INTER_AREA / INTER_CUBIC to match the reference
+        rgb = cv2.resize(rgb, (width, height), interpolation=cv2.INTER_AREA if width < rgb.shape[1] else cv2.INTER_CUBIC)
+    return torch.tensor(rgb, dtype=torch.float32)
+
+
+def load_depth_map(depth_map_path: Path, width: int, height: int) -> Tensor:
+    """(H,W) float32 metres from a 16-bit millimetre PNG: ``uint16 / 1000`` in float64 then cast
+    (loader.py:166-170); nearest-neighbour resize when the camera size differs."""
+    depth = _imread_depth_u16(Path(depth_map_path)) / 1000
+    if depth.shape[0] != height or depth.shape[1] != width:
+        rows = (np.arange(height) * (depth.shape[0] / height)).astype(np.int64).clip(0, depth.shape[0] - 1)
+        cols = (np.arange(width) * (depth.shape[1] / width)).astype(np.int64).clip(0, depth.shape[1] - 1)
+        depth = depth[rows][:, cols]  # cv2.INTER_NEAREST picks floor(dst * scale)
+    return torch.tensor(depth, dtype=torch.float32)
+
+
+def prefetch_device_views(images, device, num_workers: int = 0) -> None:
+    """Decodes and uploads the pixels of every image not yet resident on ``device`` (threads overlap the PNG /
+    JPEG decode; replaces the reference's DataLoader prefetch, loader.py:173-180)."""
+    todo = [im for im in {id(i): i for i in images}.values()
+            if im._device_view is None or im._device_view[0] != torch.device(device)]
+    if num_workers and len(todo) > 1:
+        with ThreadPoolExecutor(max_workers=num_workers) as pool:
+            list(pool.map(lambda im: im.device_view(device), todo))
+    else:
+        for im in todo:
+            im.device_view(device)
+
+
+class ImageDataset(Dataset):
+    """Streams ``(idx, rgb)``, ``(idx, depth)`` or ``(idx, rgb, depth)`` like the reference (loader.py:133-153)."""
+
+    def __init__(self, image_list, return_rgb: bool = True, return_depth_map: bool = True):
+        self.images = image_list
+        self.return_rgb = return_rgb
+        self.return_depth_map = return_depth_map
+
+    def __len__(self) -> int:
+        return len(self.images)
+
+    def __getitem__(self, idx):
+        im = self.images[idx]
+        out = [idx]
+        if self.return_rgb:
+            out.append(im.get_rgb())
+        if self.return_depth_map:
+            out.append(im.get_depth_map())
+        return tuple(out) if len(out) > 1 else None
+
+
+def _first(batch):
+    return batch[0]
+
+
+def load_image_list(image_list, return_rgb: bool = True, return_depth_map: bool = True, num_workers: int = 0):
+    return DataLoader(ImageDataset(image_list, return_rgb=return_rgb, return_depth_map=return_depth_map),
+                      num_workers=num_workers, collate_fn=_first)
+
+
+# ---- matches ----------------------------------------------------------------------------------------------------------
+
+class MatchesData:
+    """Observations of one target image.
+
+    Two flavours share the interface of the reference's class (loader.py:36-53):
+    * engine-backed (``MatchesData(restoration=...)``, what ``MatchesFile.load_matches`` returns): the data are
+      the HBM observation store; ``sucre.adam`` hands it to the HIP fit directly.
+    * list-backed (``MatchesData()`` + ``append``): host tensors in the reference's format, e.g. loaded from a
+      foreign source; ``iter`` works, but ``sucre.adam`` refuses it (no CPU fallback).
+    """
+
+    def __init__(self, restoration=None, image_list=None):
+        self.data: list[MatchesSample] = []
+        self.restoration = restoration
+        self.image_list = image_list
+
+    def append(self, u: Tensor, v: Tensor, cP: Tensor, I: Tensor):
+        self.data.append(MatchesSample(u=u, v=v, cP=cP, I=I))
+
+    def _materialise(self) -> list[MatchesSample]:
+        """Kept views of the observation store in the reference's sample format, groups in name order
+        (h5py iterates groups alphabetically).  ``cP`` is returned as ``(0, 0, z)``: the store keeps the range
+        ``z = ||cP||`` only, which is all ``SUCRe.forward`` reads without the light model (sucre.py:53)."""
+        r = self.restoration
+        keep = r.view_keep().cpu().numpy().astype(bool)
+        order = sorted(range(r.n_views), key=lambda k: self.image_list[k].name if self.image_list else k)
+        out = []
+        for k in order:
+            if not keep[k]:
+                continue
+            z, rgb = r.export_view(k)
+            v, u = torch.where(z > 0)
+            zz = z[v, u]
+            cP = torch.stack([torch.zeros_like(zz), torch.zeros_like(zz), zz])
+            I = (rgb[v, u].to(torch.float64) / 255).to(torch.float32).T.contiguous()
+            out.append(MatchesSample(u=u.short(), v=v.short(), cP=cP, I=I))
+        return out
+
+    def iter(self, batch_size: int = 1, device: str = 'cpu'):
+        data = self.data if self.restoration is None else self._materialise()
+        for i in range(0, len(data), batch_size):
+            chunk = data[i:i + batch_size]
+            yield (torch.hstack([s.u.to(device) for s in chunk]).long(),
+                   torch.hstack([s.v.to(device) for s in chunk]).long(),
+                   torch.hstack([s.cP.to(device) for s in chunk]),
+                   torch.hstack([s.I.to(device) for s in chunk]))
+
+    def __len__(self) -> int:
+        if self.restoration is not None:
+            return self.restoration.n_obs()
+        return sum(int(s.u.shape[0]) for s in self.data)
+
+
+class MatchesFile:
+    """Handle on the matches of one target image (loader.py:56-130).
+
+    ``path`` is kept for interface parity; the matches themselves live in the engine's workspace, attached by
+    ``sfm.Image.match_images``.  With ``persist=True`` (``--keep-matches``) ``save`` writes the reference's
+    dataset names (``<image name>/{u1,v1,u2,v2,d,I}``) to ``path`` -- as HDF5 when h5py is importable, else as a
+    ``.npz`` next to it -- so a later run can tell that matching was already done.
+    """
+
+    def __init__(self, path: Path, colmap_model=None, overwrite: bool = False):
+        self.path = Path(path)
+        if overwrite:
+            self.path.unlink(missing_ok=True)
+            self._npz_path.unlink(missing_ok=True)
+        self.colmap_model = colmap_model
+        self.restoration = None
+        self.target_image = None
+        self.image_list = None
+
+    @property
+    def _npz_path(self) -> Path:
+        return self.path.with_suffix('.npz')
+
+    def exists(self) -> bool:
+        return self.restoration is not None
+
+    def attach(self, restoration, target_image, image_list) -> None:
+        self.restoration = restoration
+        self.target_image = target_image
+        self.image_list = image_list
+
+    def _need(self):
+        if self.restoration is None:
+            raise RuntimeError(f'{self.path}: no matches attached; call Image.match_images first')
+        return self.restoration
+
+    def get_image_list(self):
+        """Images that passed the min_cover rule, in name order (the HDF5 group order of the reference)."""
+        keep = self._need().view_keep().cpu().numpy().astype(bool)
+        return sorted([im for im, k in zip(self.image_list, keep) if k], key=lambda im: im.name)
+
+    def save_matches(self, matches, d: Tensor):
+        raise NotImplementedError('matches are written by the HIP match kernel (Image.match_images), not one '
+                                  'view at a time from the host')
+
+    def prepare_matches(self, num_workers: int = 0):
+        """Colours were gathered by the match kernel (I = rgb2[v2,u2], loader.py:87): nothing left to do."""
+        self._need()
+
+    def check_integrity(self):
+        """Device-side counterpart of loader.py:89-101: every stored range must be finite and >= 0 and the
+        per-view totals must add up to n_obs."""
+        r = self._need()
+        keep = r.view_keep().cpu().numpy().astype(bool)
+        counts = r.view_counts().cpu().numpy()
+        assert int(counts[keep].sum()) == r.n_obs(), f'In {self.path}, observation count mismatch.'
+        for k in np.nonzero(keep)[0]:
+            z, _ = r.export_view(int(k))
+            assert bool(torch.isfinite(z).all()), f'In {self.path}, view {k} contains NaN(s).'
+            assert bool((z >= 0).all()), f'In {self.path}, view {k} contains null of negative depth(s).'
+            assert int((z > 0).sum()) == int(counts[k]), f'In {self.path}, view {k} lost observations.'
+
+    def load_matches(self, pin_memory: bool = False) -> MatchesData:
+        return MatchesData(restoration=self._need(), image_list=self.image_list)
+
+    def save(self) -> Path:
+        """Persists the explicit match lists in the reference's layout (used by --keep-matches)."""
+        r = self._need()
+        keep = r.view_keep().cpu().numpy().astype(bool)
+        groups = {}
+        for k, im in enumerate(self.image_list):
+            if not keep[k]:
+                continue
+            q = r.match_map(k)
+            v1, u1 = torch.where(q >= 0)
+            p2 = q[v1, u1].long()
+            W2 = im.camera.width
+            u2, v2 = p2 % W2, torch.div(p2, W2, rounding_mode='floor')
+            view = im.device_view(r.device)
+            I = (view.rgb[v2, u2].to(torch.float64) / 255).to(torch.float32).T
+            groups[im.name] = dict(u1=u1.short().cpu().numpy(), v1=v1.short().cpu().numpy(),
+                                   u2=u2.short().cpu().numpy(), v2=v2.short().cpu().numpy(),
+                                   d=view.depth[v2, u2].cpu().numpy(), I=I.cpu().numpy())
+        try:
+            import h5py
+            with h5py.File(self.path, 'w', libver='latest') as f:
+                for name, ds in groups.items():
+                    g = f.create_group(name)
+                    for key, val in ds.items():
+                        g.create_dataset(key, data=val)
+            return self.path
+        except ImportError:
+            np.savez(self._npz_path, **{f'{name}/{key}': val for name, ds in groups.items() for key, val in ds.items()})
+            return self._npz_path
+
+    def __len__(self) -> int:
+        return self.restoration.n_obs() if self.restoration is not None else 0
+
+    def __repr__(self) -> str:
+        return f'MatchesFile(path={self.path}, {len(self)} observations)'

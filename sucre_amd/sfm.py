@@ -1,0 +1,301 @@
+"""Structure-from-motion side of the drop-in: poses, cameras, images, matches and the COLMAP model.
+
+Mirrors the reference's ``sfm`` module (sfm.py:32-238) name for name -- ``Pose``, ``Camera``, ``Image``,
+``Matches``, ``COLMAPModel`` with the same constructor arguments, attributes and conventions (float32 tensors,
+points ``(3, n)``, ``(u, v)`` = (column, row), world-from-camera poses) -- but the hot loop of
+``Image.match_images`` (sfm.py:127-138) is one launch of the HIP engine over every view instead of a Python loop
+of eager torch kernels, and its result stays in HBM instead of going to an HDF5 file.
+
+pycolmap is not required: ``COLMAPModel`` reads ``cameras/images.{bin,txt}`` itself (PINHOLE only, as the
+reference asserts, sfm.py:192).
+"""
+from __future__ import annotations
+
+import struct
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import loader
+
+
+class Pose:
+    def __init__(self, R: Tensor, t: Tensor):
+        """Rigid transform ``x -> R @ x + t``.  R: (3,3), t: (3,1)."""
+        self.R = R
+        self.t = t
+
+    def inverse(self) -> 'Pose':
+        Rt = self.R.T
+        return Pose(Rt, -Rt @ self.t)
+
+    def transform(self, P: Tensor) -> Tensor:
+        """Applies the pose to points ``P`` of shape (3, n)."""
+        return self.R.to(P.device) @ P + self.t.to(P.device)
+
+    def __repr__(self) -> str:
+        return f'Pose(R={self.R!r}, t={self.t!r})'
+
+
+class Camera:
+    def __init__(self, camera_id: int, width: int, height: int, K: Tensor):
+        """PINHOLE camera: id in the COLMAP model, sensor size in pixels, 3x3 intrinsics."""
+        self.id = camera_id
+        self.width = width
+        self.height = height
+        self.K = K
+
+    def __repr__(self) -> str:
+        return f'Camera(id={self.id}, width={self.width}, height={self.height}, K={self.K!r})'
+
+
+class Image:
+    def __init__(self, image_id: int, rgb_path: Path, depth_map_path: Path, pose: Pose, camera: Camera):
+        self.id = image_id
+        self.name = str(Path(rgb_path).name)
+        self.rgb_path = rgb_path
+        self.depth_map_path = depth_map_path
+        self.pose = pose          # world-from-camera
+        self.camera = camera
+        self._device_view = None  # (device, engine.DeviceView) cache: pixels stay resident in HBM
+
+    # -- geometry helpers (plain tensor math; used by the output stage and the compatibility shims) -------------
+    def unproject_depth(self, u: Tensor, v: Tensor, d: Tensor) -> Tensor:
+        """Pixel centres ``(u+0.5, v+0.5)`` at depth ``d`` -> camera-frame points (3, n)."""
+        rays = torch.stack([u + 0.5, v + 0.5, torch.ones_like(u)])
+        return self.camera.K.inverse().to(rays.device) @ (d * rays)
+
+    def unproject_depth_map(self, depth_map: Tensor, to_world: bool = True) -> tuple[Tensor, Tensor, Tensor]:
+        """Valid pixels (depth > 0) of a depth map -> ``(u, v, points)`` in the camera or world frame."""
+        v, u = torch.where(depth_map > 0)
+        P = self.unproject_depth(u=u, v=v, d=depth_map[v, u])
+        return (u, v, self.pose.transform(P)) if to_world else (u, v, P)
+
+    def project_to_view(self, wP: Tensor) -> Tensor:
+        """World points (3, n) -> continuous pixel coordinates (2, n) in this image."""
+        cp = self.camera.K.to(wP.device) @ self.pose.inverse().transform(wP)
+        return cp[:2] / cp[2]
+
+    # -- pixel access ---------------------------------------------------------------------------------------------
+    def get_rgb(self) -> Tensor:
+        return loader.load_rgb(self.rgb_path, width=self.camera.width, height=self.camera.height)
+
+    def get_depth_map(self) -> Tensor:
+        return loader.load_depth_map(self.depth_map_path, width=self.camera.width, height=self.camera.height)
+
+    def device_view(self, device):
+        """This image as the engine sees it: uint8 colour + float32 depth resident on ``device`` (cached), and
+        the float32 camera/pose matrices."""
+        from . import engine
+        dev = torch.device(device)
+        if self._device_view is None or self._device_view[0] != dev:
+            rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
+            depth = self.get_depth_map()
+            self._device_view = (dev, engine.DeviceView(depth=depth.to(dev).contiguous(), rgb=rgb.to(dev).contiguous(),
+                                                        K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name))
+        return self._device_view[1]
+
+    def release_device(self) -> None:
+        self._device_view = None
+
+    # -- matching ---------------------------------------------------------------------------------------------------
+    def match_images(self, image_list: list['Image'], matches_file: 'loader.MatchesFile', min_cover: float = 0.000001,
+                     num_workers: int = 0, device: str = 'cuda'):
+        """Two-way dense matching of this image against every image of ``image_list`` and preparation of the
+        observations the fit consumes (replaces sfm.py:127-138 + loader.py:78-118).  One HIP launch matches all
+        views; views failing ``n_matches / (W*H) > min_cover`` are dropped on the device; nothing is written to
+        disk unless the matches file is asked to persist."""
+        from . import engine
+        loader.prefetch_device_views(image_list + [self], device, num_workers=num_workers)
+        views = [im.device_view(device) for im in image_list]
+        target = self.device_view(device)
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device)
+        resto.match(target, views, min_cover=min_cover)
+        matches_file.attach(resto, target_image=self, image_list=list(image_list))
+
+    def match_two_way(self, other: 'Image', device: str = 'cuda', **_unused) -> 'Matches':
+        """Mutually consistent matches between this image and ``other`` (sfm.py:121-125) as explicit lists.
+        The reference's positional ``u1, v1, wP1, u2, v2, wP2`` arguments are accepted and ignored: the engine
+        recomputes the unprojections on the device."""
+        from . import engine
+        views = [other.device_view(device)]
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, 1, device)
+        resto.match(self.device_view(device), views, min_cover=-1.0)
+        q = resto.match_map(0)
+        v1, u1 = torch.where(q >= 0)
+        p2 = q[v1, u1].long()
+        W2 = other.camera.width
+        return Matches(image1=self, image2=other, u1=u1, v1=v1, u2=p2 % W2, v2=torch.div(p2, W2, rounding_mode='floor'))
+
+    def __repr__(self) -> str:
+        return f'SfMImage({self.name!r})'
+
+
+class Matches:
+    def __init__(self, image1: Image, image2: Image, u1: Tensor, v1: Tensor, u2: Tensor, v2: Tensor):
+        self.image1, self.image2 = image1, image2
+        self.u1, self.v1, self.u2, self.v2 = u1, v1, u2, v2
+
+    def map(self) -> Tensor:
+        """Dense (H1, W1, 2) map holding ``(v2, u2)`` at every matched ``(v1, u1)`` and -1 elsewhere."""
+        out = torch.full((self.image1.camera.height, self.image1.camera.width, 2), -1,
+                         device=self.u1.device, dtype=self.u1.dtype)
+        out[self.v1, self.u1, 0] = self.v2
+        out[self.v1, self.u1, 1] = self.u2
+        return out
+
+    def __and__(self, other: 'Matches') -> 'Matches':
+        """Keeps the matches of ``self`` whose reverse match in ``other`` points back to the same pixel."""
+        back = other.map()[self.v2, self.u2]
+        keep = (back[:, 0] == self.v1) & (back[:, 1] == self.u1)
+        return Matches(self.image1, self.image2, self.u1[keep], self.v1[keep], self.u2[keep], self.v2[keep])
+
+    def __len__(self) -> int:
+        return int(self.u1.shape[0])
+
+    def __repr__(self) -> str:
+        return f'Matches(image1={self.image1!r}, image2={self.image2!r}, {len(self)} matches)'
+
+
+# ---- COLMAP model -------------------------------------------------------------------------------------------------
+
+_PINHOLE_MODEL_ID = 1
+_COLMAP_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 6: 12, 7: 5, 8: 4, 9: 5, 10: 12}
+
+
+def quat_to_rotmat(qw: float, qx: float, qy: float, qz: float) -> np.ndarray:
+    """Unit quaternion -> 3x3 rotation, float64, same operation order as Eigen's ``toRotationMatrix`` (what
+    pycolmap's ``Rigid3d.rotation.matrix()`` evaluates)."""
+    tx, ty, tz = 2.0 * qx, 2.0 * qy, 2.0 * qz
+    twx, twy, twz = tx * qw, ty * qw, tz * qw
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    return np.array([[1.0 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1.0 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1.0 - (txx + tyy)]], dtype=np.float64)
+
+
+def _read_cameras(model_dir: Path) -> dict[int, tuple[str, int, int, list[float]]]:
+    cams = {}
+    if (model_dir / 'cameras.bin').exists():
+        data = (model_dir / 'cameras.bin').read_bytes()
+        (n,), off = struct.unpack_from('<Q', data, 0), 8
+        for _ in range(n):
+            cam_id, model_id, w, h = struct.unpack_from('<iiQQ', data, off)
+            off += 24
+            npar = _COLMAP_NUM_PARAMS[model_id]
+            params = list(struct.unpack_from(f'<{npar}d', data, off))
+            off += 8 * npar
+            cams[cam_id] = ('PINHOLE' if model_id == _PINHOLE_MODEL_ID else f'MODEL_{model_id}', w, h, params)
+    else:
+        for line in (model_dir / 'cameras.txt').read_text().splitlines():
+            line = line.strip()
+            if not line or line.startswith('#'):
+                continue
+            tok = line.split()
+            cams[int(tok[0])] = (tok[1], int(tok[2]), int(tok[3]), [float(x) for x in tok[4:]])
+    return cams
+
+
+def _read_images(model_dir: Path) -> dict[int, tuple[tuple[float, ...], tuple[float, ...], int, str]]:
+    images = {}
+    if (model_dir / 'images.bin').exists():
+        data = (model_dir / 'images.bin').read_bytes()
+        (n,), off = struct.unpack_from('<Q', data, 0), 8
+        for _ in range(n):
+            image_id, = struct.unpack_from('<I', data, off)
+            q = struct.unpack_from('<4d', data, off + 4)
+            t = struct.unpack_from('<3d', data, off + 36)
+            cam_id, = struct.unpack_from('<I', data, off + 60)
+            off += 64
+            end = data.index(b'\x00', off)
+            name = data[off:end].decode()
+            off = end + 1
+            (n2d,) = struct.unpack_from('<Q', data, off)
+            off += 8 + 24 * n2d
+            images[image_id] = (q, t, cam_id, name)
+    else:
+        lines = [ln for ln in (model_dir / 'images.txt').read_text().splitlines() if not ln.lstrip().startswith('#')]
+        i = 0
+        while i < len(lines):
+            if not lines[i].strip():
+                i += 1
+                continue
+            tok = lines[i].split()
+            images[int(tok[0])] = (tuple(float(x) for x in tok[1:5]), tuple(float(x) for x in tok[5:8]), int(tok[8]),
+                                   ' '.join(tok[9:]))
+            i += 2  # the following line lists the 2-D points (possibly empty)
+    return images
+
+
+class COLMAPModel:
+    def __init__(self, model_dir: Path, image_dir: Path, depth_dir: Path, image_scale: float = 1.0):
+        """Loads an undistorted COLMAP model (sfm.py:186-238): PINHOLE cameras (intrinsics rescaled by
+        ``image_scale``), images with world-from-camera poses, depth maps named ``depth_<stem>.png``."""
+        model_dir, image_dir, depth_dir = Path(model_dir), Path(image_dir), Path(depth_dir)
+        self.image_scale = image_scale
+        self.cameras: dict[int, Camera] = {}
+        for cam_id, (model, w, h, params) in sorted(_read_cameras(model_dir).items()):
+            assert model == 'PINHOLE', f'Camera {cam_id} ({model}) is not using the PINHOLE model.'
+            width, height = int(w * image_scale), int(h * image_scale)
+            sw, sh = width / w, height / h
+            fx, fy, cx, cy = params
+            K = torch.tensor([[fx * sw, 0, cx * sw], [0, fy * sh, cy * sh], [0, 0, 1]], dtype=torch.float32)
+            self.cameras[cam_id] = Camera(camera_id=cam_id, width=width, height=height, K=K)
+
+        self.images: dict[int, Image] = {}
+        for image_id, (q, t, cam_id, name) in sorted(_read_images(model_dir).items()):
+            rgb_path = image_dir / name
+            depth_path = (depth_dir / name).with_name('depth_' + rgb_path.stem + '.png')
+            cam_from_world = Pose(R=torch.tensor(quat_to_rotmat(*q), dtype=torch.float32),
+                                  t=torch.tensor(t, dtype=torch.float32).view(3, 1))
+            self.images[image_id] = Image(image_id=image_id, rgb_path=rgb_path, depth_map_path=depth_path,
+                                          pose=cam_from_world.inverse(), camera=self.cameras[cam_id])
+        self.imagename2id = {im.name: im.id for im in self.images.values()}
+
+    def __getitem__(self, image_name: str) -> Image:
+        return self.images[self.imagename2id[image_name]]
+
+    def __repr__(self) -> str:
+        return f'COLMAPModel({len(self.images)} images)'
+
+
+def write_colmap_text(model_dir: Path, K: Tensor, width: int, height: int, names: list[str], poses: list[Pose]) -> None:
+    """Writes ``cameras.txt`` / ``images.txt`` / ``points3D.txt`` for a single-camera scene whose images have the
+    given world-from-camera poses (used by the synthetic-scene tooling and the CLI tests)."""
+    model_dir = Path(model_dir)
+    model_dir.mkdir(parents=True, exist_ok=True)
+    (model_dir / 'cameras.txt').write_text(
+        '# Camera list with one line of data per camera:\n'
+        f'1 PINHOLE {width} {height} {float(K[0, 0])!r} {float(K[1, 1])!r} {float(K[0, 2])!r} {float(K[1, 2])!r}\n')
+    lines = ['# Image list with two lines of data per image:']
+    for i, (name, pose) in enumerate(zip(names, poses), start=1):
+        cfw = Pose(pose.R.double(), pose.t.double()).inverse()
+        q = rotmat_to_quat(cfw.R.numpy())
+        t = cfw.t.numpy().ravel()
+        lines.append(f'{i} ' + ' '.join(repr(float(x)) for x in (*q, *t)) + f' 1 {name}')
+        lines.append('')
+    (model_dir / 'images.txt').write_text('\n'.join(lines) + '\n')
+    (model_dir / 'points3D.txt').write_text('# 3D point list (empty)\n')
+
+
+def rotmat_to_quat(R: np.ndarray) -> np.ndarray:
+    """3x3 rotation -> unit quaternion (w, x, y, z), w >= 0."""
+    R = np.asarray(R, dtype=np.float64)
+    tr = np.trace(R)
+    if tr > 0:
+        s = 2.0 * np.sqrt(1.0 + tr)
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = 2.0 * np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k])
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q = q / np.linalg.norm(q)
+    return q if q[0] >= 0 else -q

@@ -1,0 +1,274 @@
+"""SUCRe restoration: model, optimiser loop, per-image pipeline and command line.
+
+Drop-in for the reference's ``sucre.py`` (sucre.py:35-307): ``SUCRe``, ``adam``, ``restore_image``, ``parse_args``
+and the argparse CLI keep their names, arguments, defaults, printed stages and output files
+(``<stem>_rgb.png``, ``<stem>_reconstruction.png``, ``<name>.pt`` with keys ``B, beta, gamma, J``).  The 200
+full-batch Adam iterations of ``adam`` (sucre.py:138-148) run as 200 back-to-back launches of one fused HIP
+kernel over observations that never leave HBM, with no host synchronisation until the trace is read.
+
+    python -m sucre_amd.sucre --image-dir IMAGES --depth-dir DEPTHS --model-dir COLMAP --output-dir OUT \\
+        --image-name NAME [...]        # same flags as the reference, see --help
+
+Under ``torchrun`` (WORLD_SIZE > 1) the images to restore are sharded over the ranks, one GPU each.
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+
+import numpy as np
+import torch
+from PIL import Image as PILImage
+from torch import Tensor
+
+from . import dist as sdist
+from . import loader, se3, sfm
+
+
+class SUCRe(torch.nn.Module):
+    """Image-formation model ``I = l * (J exp(-beta z) + B (1 - exp(-gamma z)))`` of one image (sucre.py:35-82).
+
+    Parameters ``B, beta, gamma`` are (3,1), initialised to 0.1; ``J`` is an (H,W,3) parameter initialised to the
+    image itself with NaN where the depth map is invalid, or -- with ``use_closed_form`` -- a plain attribute
+    recomputed from the observations."""
+
+    def __init__(self, image: sfm.Image, light_model: bool = False, use_closed_form: bool = False):
+        super().__init__()
+        if light_model:
+            raise NotImplementedError('the artificial-light model (--light-model, sucre.py:54-61) is not part of '
+                                      'this build yet: it needs per-observation camera points in the store')
+        self.image = image
+        self.light_model = light_model
+        self.use_closed_form = use_closed_form
+        self.B = torch.nn.Parameter(torch.full((3, 1), 0.1))
+        self.beta = torch.nn.Parameter(torch.full((3, 1), 0.1))
+        self.gamma = torch.nn.Parameter(torch.full((3, 1), 0.1))
+        if not use_closed_form:
+            J = image.get_rgb()
+            J[image.get_depth_map() <= 0] = torch.nan
+            self.J = torch.nn.Parameter(J)
+
+    # -- model evaluation (output stage / compatibility; the fit itself runs in the HIP engine) -------------------
+    def compute_l_z(self, cP: Tensor) -> tuple[float | Tensor, Tensor]:
+        return 1.0, cP.norm(dim=0)
+
+    @torch.no_grad()
+    def update_J(self, matches_data: loader.MatchesData, force_update: bool = False):
+        """Closed-form J from the current water parameters (sucre.py:66-77), computed by the engine."""
+        if not (self.use_closed_form or force_update):
+            return
+        resto = _restoration_of(matches_data)
+        resto.params().copy_(self.water_vector().to(resto.device))
+        resto.update_J()
+        self.J = resto.J().to(self.B.device)
+
+    def forward(self, u: Tensor, v: Tensor, cP: Tensor) -> Tensor:
+        l, z = self.compute_l_z(cP)
+        direct = self.J[v, u].T * torch.exp(-self.beta * z)
+        veil = self.B * (1 - torch.exp(-self.gamma * z))
+        return l * (direct + veil)
+
+    def water_vector(self) -> Tensor:
+        """B, beta, gamma flattened to the 9 floats the engine stores."""
+        return torch.cat([self.B.detach().flatten(), self.beta.detach().flatten(), self.gamma.detach().flatten()]).float()
+
+    # -- output stage (sucre.py:84-121) -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def plot_J(self) -> PILImage.Image:
+        """Restored image: per-channel 1-99 percentile stretch of the valid pixels, invalid pixels black."""
+        J = self.J.detach().cpu().numpy().copy()
+        ok = ~np.isnan(J).any(axis=2)
+        vals = J[ok]
+        lo, hi = np.percentile(vals, 1, axis=0), np.percentile(vals, 99, axis=0)
+        vals = np.clip(vals, lo, hi)
+        vals = vals - vals.min(axis=0)
+        vals = vals / vals.max(axis=0)
+        J[~ok] = 0.0
+        J[ok] = vals
+        return PILImage.fromarray(np.uint8(J * 255))
+
+    @torch.no_grad()
+    def plot_reconstruction(self) -> PILImage.Image:
+        """The image as the fitted model re-synthesises it from J and the depth map."""
+        dev = self.B.device
+        u, v, cP = self.image.unproject_depth_map(self.image.get_depth_map().to(dev), to_world=False)
+        out = torch.zeros((self.image.camera.height, self.image.camera.width, 3), device=dev)
+        out[v, u] = self(u=u, v=v, cP=cP).clip(0, 1).T
+        return PILImage.fromarray(np.uint8(out.cpu().numpy() * 255))
+
+    def save_plots(self, save_dir: Path, iteration: int | None = None):
+        stem = Path(self.image.name).stem
+        tag = '' if iteration is None else f'_{iteration:04d}'
+        self.plot_J().save(Path(save_dir) / f'{stem}_rgb{tag}.png')
+        self.plot_reconstruction().save(Path(save_dir) / f'{stem}_reconstruction{tag}.png')
+
+
+def _restoration_of(matches_data: loader.MatchesData):
+    resto = getattr(matches_data, 'restoration', None)
+    if resto is None:
+        raise RuntimeError('this MatchesData is not backed by the HIP engine (build it with Image.match_images + '
+                           'MatchesFile.load_matches); there is no CPU fallback for the fit')
+    return resto
+
+
+def _pull_results(sucre: SUCRe, resto) -> None:
+    p = resto.params().to(sucre.B.device)
+    with torch.no_grad():
+        sucre.B.copy_(p[0:3].view(3, 1))
+        sucre.beta.copy_(p[3:6].view(3, 1))
+        sucre.gamma.copy_(p[6:9].view(3, 1))
+        J = resto.J().to(sucre.B.device)
+        if sucre.use_closed_form:
+            sucre.J = J
+        else:
+            sucre.J.copy_(J)
+
+
+def _log_trace(trace: np.ndarray, first_iteration: int) -> None:
+    with np.printoptions(precision=4):
+        for i, row in enumerate(trace):
+            print(f'iter: {first_iteration + i:04d}, cost: {row[0]:.4e}, B: {row[1:4].astype(np.float32)}, '
+                  f'beta: {row[4:7].astype(np.float32)}, gamma: {row[7:10].astype(np.float32)}')
+
+
+def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_iter: int = 200, batch_size: int = 1,
+         save_dir: Path = None, save_interval: int = None, device: str = 'cpu', verbose: bool = True) -> SUCRe:
+    """``num_iter`` steps of ``torch.optim.Adam(lr)`` on the least-squares cost (sucre.py:124-157).
+
+    ``batch_size`` is accepted for compatibility: the engine always uses the full batch in one pass, which is
+    what the reference's accumulated mini-batch gradients add up to."""
+    print(f'Solve least squares with Adam optimizer ({num_iter} iterations).')
+    resto = _restoration_of(matches_data)
+    target = sucre.image.device_view(resto.device)
+    J0 = None if sucre.use_closed_form else sucre.J.detach()
+    resto.fit_init(target, params0=sucre.water_vector().cpu().numpy(), J0=J0)
+    if save_dir is not None and save_interval is not None:
+        stops = sorted({min(k + 1, num_iter) for k in range(0, num_iter, save_interval)} | {num_iter})
+    else:
+        stops = [num_iter]
+    done = 0
+    for stop in stops:
+        if stop > done:
+            trace = resto.fit(stop - done, lr=lr, use_closed_form=sucre.use_closed_form, finalize=(stop == num_iter))
+            if verbose:
+                _log_trace(trace.cpu().numpy(), done)
+            done = stop
+        if save_dir is not None and save_interval is not None and (done - 1) % save_interval == 0:
+            if sucre.use_closed_form and done != num_iter:
+                resto.update_J()
+            _pull_results(sucre, resto)
+            sucre.save_plots(save_dir=save_dir, iteration=done - 1)
+    _pull_results(sucre, resto)
+    return sucre
+
+
+def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool = False,
+                  use_closed_form: bool = False, min_cover: float = 0.000001, image_list: list[sfm.Image] = None,
+                  lr: float = 0.05, num_iter: int = 200, batch_size: int = 1, save_interval: int = None,
+                  params_path: Path = None, force_compute_matches: bool = False, keep_matches: bool = False,
+                  num_workers: int = 0, device: str = 'cuda'):
+    """Per-image pipeline (sucre.py:160-219): match -> prepare -> check -> load -> fit -> save."""
+    print(f'Restore {image.name}.')
+    output_dir = Path(output_dir)
+    matches_path = (output_dir / image.name).with_suffix('.h5')
+    matches_file = loader.MatchesFile(matches_path, colmap_model=colmap_model, overwrite=force_compute_matches)
+    if image_list is None:
+        image_list = list(colmap_model.images.values())
+
+    # matching costs ~1.5 ms on the GPU, so it is always recomputed; a kept matches file is only an export
+    print(f'Compute {image.name} matches.')
+    image.match_images(image_list=image_list, matches_file=matches_file, min_cover=min_cover,
+                       num_workers=num_workers, device=device)
+    print('Prepare matches for optimization.')
+    matches_file.prepare_matches(num_workers=num_workers)
+    print('Check matches integrity.')
+    matches_file.check_integrity()
+    print('Load matches.')
+    matches_data = matches_file.load_matches(pin_memory=False)
+    print(f'Total of {len(matches_data)} observations.')
+    if len(matches_data) == 0:
+        raise RuntimeError(f'{image.name}: no observation survived matching; nothing to fit')
+
+    sucre = SUCRe(image=image, light_model=light_model, use_closed_form=use_closed_form).to(device)
+    if params_path is not None:
+        sucre.load_state_dict(torch.load(params_path), strict=False)
+
+    adam(sucre=sucre, matches_data=matches_data, lr=lr, num_iter=num_iter, batch_size=batch_size,
+         save_dir=output_dir, save_interval=save_interval, device=device)
+
+    sucre.save_plots(save_dir=output_dir)
+    torch.save({**sucre.cpu().state_dict(), 'J': sucre.J.detach().cpu()}, (output_dir / image.name).with_suffix('.pt'))
+    if keep_matches:
+        print(f'Keep {matches_file.save()}.')
+    return sucre
+
+
+def parse_args(args: argparse.Namespace):
+    """Runs the CLI request (sucre.py:222-261); with WORLD_SIZE > 1 each rank restores its shard of the images."""
+    rank, local_rank, world = sdist.env_rank_world()
+    device = args.device
+    if world > 1 and str(device).startswith('cuda'):
+        device = f'cuda:{local_rank}'
+        torch.cuda.set_device(local_rank)
+    print('Loading COLMAP model.')
+    colmap_model = sfm.COLMAPModel(model_dir=args.model_dir, image_dir=args.image_dir, depth_dir=args.depth_dir,
+                                   image_scale=args.image_scale)
+    if args.image_name is not None:
+        images = [colmap_model[args.image_name]]
+    elif args.image_list is not None:
+        images = [colmap_model[name] for name in args.image_list.read_text().splitlines() if name.strip()]
+    else:
+        lo, hi = args.image_ids
+        images = [colmap_model.images[i] for i in range(lo, hi) if i in colmap_model.images]
+    images = sdist.shard_images(images, rank, world)
+
+    skipped = set(args.filter_images_path.read_text().splitlines()) if args.filter_images_path else set()
+    image_list = [im for im in colmap_model.images.values() if im.name not in skipped]
+    args.output_dir.mkdir(parents=True, exist_ok=True)
+    for image in images:
+        restore_image(image=image, colmap_model=colmap_model, output_dir=args.output_dir,
+                      light_model=args.light_model, use_closed_form=args.use_closed_form, min_cover=args.min_cover,
+                      image_list=image_list, lr=args.learning_rate, num_iter=args.num_iter,
+                      batch_size=args.batch_size, save_interval=args.save_interval, params_path=args.params_path,
+                      force_compute_matches=args.force_compute_matches, keep_matches=args.keep_matches,
+                      num_workers=args.num_workers, device=device)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    """Same flags, defaults and exclusivity group as the reference CLI (sucre.py:264-305)."""
+    p = argparse.ArgumentParser(description='SUCRe (MI355X engine).', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('--image-dir', required=True, type=Path, help='directory holding the colour images')
+    p.add_argument('--depth-dir', required=True, type=Path, help='directory holding the depth_<stem>.png maps')
+    p.add_argument('--model-dir', required=True, type=Path, help='undistorted COLMAP model (cameras/images .bin or .txt)')
+    p.add_argument('--output-dir', required=True, type=Path, help='where restored images and parameters go')
+    which = p.add_mutually_exclusive_group(required=True)
+    which.add_argument('--image-name', type=str, help='restore this single image')
+    which.add_argument('--image-list', type=Path, help='text file, one image name per line')
+    which.add_argument('--image-ids', type=int, nargs=2, metavar=('MIN_ID', 'MAX_ID'),
+                       help='restore COLMAP image ids in [MIN_ID, MAX_ID)')
+    p.add_argument('--light-model', action='store_true', help='model artificial lighting (not in this build)')
+    p.add_argument('--use-closed-form', action='store_true',
+                   help='solve J in closed form from the water parameters instead of optimising it')
+    p.add_argument('--min-cover', type=float, default=0.000001,
+                   help='drop a neighbour whose matches cover at most this fraction of the image')
+    p.add_argument('--image-scale', type=float, default=1.0, help='rescale factor applied to all images')
+    p.add_argument('--filter-images-path', type=Path, help='text file of image names never used as neighbours')
+    p.add_argument('--learning-rate', type=float, default=0.05, help='Adam learning rate')
+    p.add_argument('--num-iter', type=int, default=200, help='Adam iterations')
+    p.add_argument('--batch-size', type=int, default=5,
+                   help='accepted for compatibility; the engine always runs the full batch in one pass')
+    p.add_argument('--save-interval', type=int, help='also save the restored image every this many iterations')
+    p.add_argument('--params-path', type=Path, help='.pt file to warm-start the model parameters from')
+    p.add_argument('--force-compute-matches', action='store_true', help='discard a kept matches file first')
+    p.add_argument('--keep-matches', action='store_true', help='export the match lists next to the outputs')
+    p.add_argument('--num-workers', type=int, default=0, help='threads decoding images (0 = main thread)')
+    p.add_argument('--device', type=str, default='cuda', help='GPU to run on')
+    return p
+
+
+def main(argv=None):
+    parse_args(build_parser().parse_args(argv))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,143 @@
+"""GPU tests of the drop-in surface: the sucre.py CLI on files, sfm/loader mirrors, and the shared-water path."""
+import copy
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import oracle
+from sucre_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def write_scene(scene, root: Path):
+    """Synthetic scene -> image files + COLMAP text model, as a user of the reference would have them."""
+    from PIL import Image as PILImage
+    from sucre_amd import sfm
+    (root / 'images').mkdir(parents=True); (root / 'depth').mkdir()
+    for v in scene.views:
+        PILImage.fromarray(v.rgb_u8.numpy()).save(root / 'images' / v.name)
+        PILImage.fromarray(v.depth_u16.numpy().astype(np.uint16)).save(root / 'depth' / ('depth_' + Path(v.name).stem + '.png'))
+    sfm.write_colmap_text(root / 'model', scene.K, scene.width, scene.height, scene.names,
+                          [sfm.Pose(v.R, v.t) for v in scene.views])
+
+
+def scene_as_loaded(scene, model):
+    """The scene with the poses the COLMAP round trip produced (quaternion text is not bit-preserving)."""
+    sc = copy.copy(scene)
+    sc.views = []
+    for v in scene.views:
+        im = model[v.name]
+        sc.views.append(synth.SynthView(name=v.name, R=im.pose.R.contiguous(), t=im.pose.t.contiguous(), depth_u16=v.depth_u16, rgb_u8=v.rgb_u8))
+    return sc
+
+
+@pytest.fixture(scope='module')
+def disk_scene(tmp_path_factory):
+    from sucre_amd import sfm
+    root = tmp_path_factory.mktemp('scene')
+    scene = synth.make_scene(96, 64, 4, seed=21, far_views=1)
+    write_scene(scene, root)
+    model = sfm.COLMAPModel(root / 'model', root / 'images', root / 'depth')
+    return root, scene, model, scene_as_loaded(scene, model)
+
+
+def test_cli_end_to_end(disk_scene, tmp_path, capsys):
+    from sucre_amd import sucre
+    root, scene, model, loaded = disk_scene
+    name = scene.names[scene.target]
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(tmp_path), '--image-name', name, '--num-iter', '30', '--keep-matches', '--save-interval', '20'])
+    out = capsys.readouterr().out
+    assert 'Solve least squares with Adam optimizer (30 iterations).' in out and 'iter: 0029, cost:' in out
+    stem = Path(name).stem
+    for f in (f'{stem}_rgb.png', f'{stem}_reconstruction.png', f'{stem}_rgb_0000.png', f'{stem}_rgb_0020.png', f'{stem}.pt'):
+        assert (tmp_path / f).exists(), f
+    state = torch.load(tmp_path / f'{stem}.pt')
+    assert set(state) == {'B', 'beta', 'gamma', 'J'} and state['B'].shape == (3, 1) and state['J'].shape == (64, 96, 3)
+    # oracle on the same (as-loaded) inputs
+    _, samples = helpers.oracle_scene_samples(loaded)
+    tgt = loaded.views[loaded.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    Jo, po, to = oracle.fit(64, 96, samples, J0, num_iter=30)
+    J = state['J'].numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(Jo))
+    assert helpers.rms_per_channel(J, Jo).max() < 1e-5
+    got = np.concatenate([state['B'].numpy().ravel(), state['beta'].numpy().ravel(), state['gamma'].numpy().ravel()])
+    assert np.abs(got - po).max() < 1e-5
+    # kept matches: the reference's dataset names, the oracle's match lists
+    kept = np.load(tmp_path / f'{stem}.npz') if (tmp_path / f'{stem}.npz').exists() else None
+    if kept is not None:
+        per_view, _ = helpers.oracle_scene_samples(loaded)
+        for vname, keep, m in per_view[0]:
+            if not keep:
+                assert f'{vname}/u1' not in kept
+                continue
+            for key in ('u1', 'v1', 'u2', 'v2', 'd'):
+                assert np.array_equal(kept[f'{vname}/{key}'], getattr(m, key)), (vname, key)
+
+
+def test_match_two_way_and_matches_data_compat(disk_scene):
+    from sucre_amd import loader
+    root, scene, model, loaded = disk_scene
+    target = model[scene.names[scene.target]]
+    other = model[scene.names[0]]
+    m = target.match_two_way(other)
+    per_view, samples = helpers.oracle_scene_samples(loaded)
+    ref = per_view[0][2]
+    assert len(m) == len(ref)
+    assert np.array_equal(m.u1.cpu().numpy(), ref.u1) and np.array_equal(m.v1.cpu().numpy(), ref.v1)
+    assert np.array_equal(m.u2.cpu().numpy(), ref.u2) and np.array_equal(m.v2.cpu().numpy(), ref.v2)
+    # the reference-format iterator over the HBM store
+    image_list = list(model.images.values())
+    mf = loader.MatchesFile(Path('/tmp/unused.h5'), colmap_model=model)
+    target.match_images(image_list, mf)
+    mf.prepare_matches(); mf.check_integrity()
+    md = mf.load_matches()
+    assert len(md) == sum(len(s[0]) for s in samples) and len(mf) == len(md)
+    assert [im.name for im in mf.get_image_list()] == sorted(n for n, k, _ in per_view if k)
+    got = list(md.iter(batch_size=1, device='cpu'))
+    assert len(got) == len(samples)
+    for (u, v, cP, I), (su, sv, scP, sI) in zip(got, samples):
+        assert np.array_equal(u.numpy(), su) and np.array_equal(v.numpy(), sv) and np.array_equal(I.numpy(), sI)
+        z = np.sqrt((scP[0] * scP[0] + scP[1] * scP[1]) + scP[2] * scP[2], dtype=np.float32)
+        assert np.array_equal(cP.norm(dim=0).numpy(), z)
+
+
+def test_shared_water_split_path_vs_oracle():
+    """Two images share B, beta, gamma (the N>1 exchange, emulated in one process: the all-reduce is a sum)."""
+    from sucre_amd import engine
+    T = 15
+    backends, oimgs = [], []
+    for seed in (10, 11):
+        scene = synth.make_scene(48, 32, 3, seed=seed)
+        views = engine.device_views_from_scene(scene, 'cuda')
+        r = engine.Restoration(32, 48, len(views))
+        r.match(views[scene.target], views)
+        r.fit_init(views[scene.target])
+        backends.append(engine.HipWaterBackend(r))
+        _, samples = helpers.oracle_scene_samples(scene)
+        tgt = scene.views[scene.target]
+        oimgs.append(oracle.SharedWaterImage(32, 48, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
+    total = sum(b.n_obs() for b in backends)
+    assert total == sum(o.n_obs for o in oimgs)
+    for b in backends:
+        b.set_n_obs_total(total)
+    pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
+    for it in range(1, T + 1):
+        sums = [b.grad(it) for b in backends]
+        red = sums[0] + sums[1]                     # what dist.all_reduce(SUM) leaves on every rank
+        for s in sums:
+            s.copy_(red)
+        for b in backends:
+            b.step(it)
+        acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
+        oracle.shared_step(pstate, acc, it, total)
+    p0, p1 = backends[0].r.params().cpu().numpy(), backends[1].r.params().cpu().numpy()
+    assert np.array_equal(p0, p1)
+    assert np.abs(p0 - pstate[:9]).max() < 1e-5
+    for b, o in zip(backends, oimgs):
+        assert helpers.rms_per_channel(b.r.J().cpu().numpy(), o.J).max() < 1e-5

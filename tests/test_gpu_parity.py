@@ -62,6 +62,8 @@ def test_matching_bit_exact_vs_oracle_and_golden(golden):
     for k in range(len(golden.scene.views)):
         z, _ = r.export_view(k)
         assert np.array_equal(z.cpu().numpy() > 0, golden['match_map'][k] >= 0)
+        # explicit (u1,v1) -> (u2,v2) correspondences, bit-exact against the reference's match lists
+        assert np.array_equal(r.match_map(k).cpu().numpy(), golden['match_map'][k])
 
 
 def test_min_cover_drops_views(golden):

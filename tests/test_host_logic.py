@@ -1,0 +1,217 @@
+"""Host-side logic that needs no GPU: constants used by the kernels, API mirrors, loaders, COLMAP I/O, sharding."""
+import inspect
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from sucre_amd import dist as sdist
+from sucre_amd import loader, se3, sfm, sucre, synth
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def test_u8_to_unit_constants_are_exact_for_all_bytes():
+    """fit.hip: unit_from_u8(k) = fma(k, hi, k*lo) must equal float32(float64(k)/255) (loader.py:157,163)."""
+    hi = np.float32(1.0 / 255.0)
+    lo = np.float32(1.0 / 255.0 - np.float64(hi))
+    k = np.arange(256, dtype=np.float32)
+    t = (k * lo).astype(np.float32)
+    got = (k.astype(np.float64) * np.float64(hi) + t.astype(np.float64)).astype(np.float32)  # fma: one rounding
+    want = (np.arange(256, dtype=np.float64) / 255).astype(np.float32)
+    assert np.array_equal(got, want)
+    src = (ROOT / 'sucre_amd' / 'csrc' / 'fit.hip').read_text()
+    assert 'kInv255Hi = (float)(1.0 / 255.0)' in src and 'kInv255Lo = (float)(1.0 / 255.0 - (double)kInv255Hi)' in src
+
+
+def test_depth_quantisation_is_float_division():
+    kk = np.arange(65536)
+    assert np.array_equal((kk.astype(np.float64) / 1000).astype(np.float32), kk.astype(np.float32) / np.float32(1000))
+
+
+def test_shard_images_partitions_exactly():
+    for n in (0, 1, 7, 8, 64, 513):
+        ids = list(range(n))
+        for world in (1, 2, 3, 8):
+            parts = [sdist.shard_images(ids, r, world) for r in range(world)]
+            assert sum(parts, []) == ids                       # order-preserving, disjoint, complete
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_se3_exp_matches_rodrigues():
+    torch.manual_seed(0)
+    for _ in range(5):
+        xi = torch.randn(6) * 0.5
+        R, t = se3.exp(xi)
+        w = xi[:3].double().numpy(); p = xi[3:].double().numpy()
+        th = np.linalg.norm(w)
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        Rr = np.eye(3) + np.sin(th) / th * Wx + (1 - np.cos(th)) / th ** 2 * Wx @ Wx
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * Wx + (th - np.sin(th)) / th ** 3 * Wx @ Wx
+        assert np.allclose(R.numpy(), Rr, atol=2e-6) and np.allclose(t.numpy().ravel(), V @ p, atol=5e-6)
+        assert t.shape == (3, 1)
+    xi = torch.zeros(6, requires_grad=True)
+    R, t = se3.exp(xi)
+    (R.sum() + t.sum()).backward()                            # differentiable, like the reference's
+    assert xi.grad is not None and torch.isfinite(xi.grad).all()
+
+
+def test_pose_and_image_geometry_roundtrip():
+    scene = synth.make_scene(64, 48, 2, seed=3)
+    v = scene.views[0]
+    pose = sfm.Pose(v.R, v.t)
+    P = torch.randn(3, 50)
+    assert torch.allclose(pose.inverse().transform(pose.transform(P)), P, atol=1e-5)
+    cam = sfm.Camera(1, 64, 48, scene.K)
+    im = sfm.Image(1, Path('a.png'), Path('depth_a.png'), pose, cam)
+    depth = v.depth_f32()
+    u, vv, wP = im.unproject_depth_map(depth, to_world=True)
+    px = im.project_to_view(wP)
+    assert torch.allclose(px[0], u + 0.5, atol=1e-2) and torch.allclose(px[1], vv + 0.5, atol=1e-2)
+    assert int((depth > 0).sum()) == u.numel()
+
+
+def test_matches_container_semantics():
+    cam = sfm.Camera(1, 8, 6, torch.eye(3))
+    a = sfm.Image(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), cam)
+    b = sfm.Image(2, Path('b.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), cam)
+    m1 = sfm.Matches(a, b, u1=torch.tensor([0, 1, 2]), v1=torch.tensor([0, 0, 1]), u2=torch.tensor([3, 4, 5]), v2=torch.tensor([1, 1, 2]))
+    m2 = sfm.Matches(b, a, u1=torch.tensor([3, 4, 5]), v1=torch.tensor([1, 1, 2]), u2=torch.tensor([0, 7, 2]), v2=torch.tensor([0, 0, 1]))
+    both = m1 & m2
+    assert len(both) == 2 and both.u1.tolist() == [0, 2] and both.u2.tolist() == [3, 5]
+    mp = m1.map()
+    assert mp.shape == (6, 8, 2) and mp[0, 1].tolist() == [1, 4] and mp[5, 7].tolist() == [-1, -1]
+
+
+def test_colmap_text_and_binary_roundtrip(tmp_path):
+    import struct
+    scene = synth.make_scene(64, 48, 3, seed=5)
+    poses = [sfm.Pose(v.R, v.t) for v in scene.views]
+    sfm.write_colmap_text(tmp_path / 'txt', scene.K, 64, 48, scene.names, poses)
+    model = sfm.COLMAPModel(tmp_path / 'txt', tmp_path / 'img', tmp_path / 'depth')
+    assert [im.name for im in model.images.values()] == scene.names
+    for im, v in zip(model.images.values(), scene.views):
+        assert torch.allclose(im.pose.R, v.R, atol=1e-6) and torch.allclose(im.pose.t, v.t, atol=1e-6)
+        assert im.depth_map_path.name == 'depth_' + Path(v.name).stem + '.png'
+        assert torch.equal(im.camera.K, scene.K)
+    assert model[scene.names[1]].id == 2
+    # the same model in COLMAP's binary layout must load identically
+    bdir = tmp_path / 'bin'; bdir.mkdir()
+    K = scene.K.double()
+    (bdir / 'cameras.bin').write_bytes(struct.pack('<Q', 1) + struct.pack('<iiQQ4d', 1, 1, 64, 48, K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    blob = struct.pack('<Q', len(poses))
+    for i, (name, pose) in enumerate(zip(scene.names, poses), start=1):
+        cfw = sfm.Pose(pose.R.double(), pose.t.double()).inverse()
+        q = sfm.rotmat_to_quat(cfw.R.numpy()); t = cfw.t.numpy().ravel()
+        blob += struct.pack('<I4d3dI', i, *q, *t, 1) + name.encode() + b'\x00' + struct.pack('<Q', 1) + struct.pack('<ddq', 1.0, 2.0, -1)
+    (bdir / 'images.bin').write_bytes(blob)
+    mb = sfm.COLMAPModel(bdir, tmp_path / 'img', tmp_path / 'depth')
+    for a, b in zip(model.images.values(), mb.images.values()):
+        assert a.name == b.name and torch.allclose(a.pose.R, b.pose.R, atol=1e-6) and torch.allclose(a.pose.t, b.pose.t, atol=1e-6)
+    # image_scale rescales intrinsics like sfm.py:193-199
+    half = sfm.COLMAPModel(tmp_path / 'txt', tmp_path / 'img', tmp_path / 'depth', image_scale=0.5)
+    cam = half.cameras[1]
+    assert (cam.width, cam.height) == (32, 24) and torch.allclose(cam.K[:2], scene.K[:2] * 0.5)
+
+
+def test_quaternion_conversion_is_consistent():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        if q[0] < 0: q = -q
+        R = sfm.quat_to_rotmat(*q)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(R), 1.0)
+        assert np.allclose(sfm.rotmat_to_quat(R), q, atol=1e-12)
+
+
+def test_pixel_loaders_reproduce_reference_quantisation(tmp_path):
+    from PIL import Image as PILImage
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, size=(6, 8, 3), dtype=np.uint8)
+    depth = rng.integers(0, 65536, size=(6, 8)).astype(np.uint16)
+    PILImage.fromarray(rgb).save(tmp_path / 'a.png')
+    PILImage.fromarray(depth).save(tmp_path / 'depth_a.png')
+    got = loader.load_rgb(tmp_path / 'a.png', width=8, height=6)
+    assert got.dtype == torch.float32 and np.array_equal(got.numpy(), (rgb.astype(np.float64) / 255).astype(np.float32))
+    assert np.array_equal(loader.load_rgb_u8(tmp_path / 'a.png', 8, 6).numpy(), rgb)
+    d = loader.load_depth_map(tmp_path / 'depth_a.png', width=8, height=6)
+    assert np.array_equal(d.numpy(), (depth.astype(np.float64) / 1000).astype(np.float32))
+    with pytest.raises(NotImplementedError, match='image-scale'):
+        loader.load_rgb_u8(tmp_path / 'a.png', 4, 3)
+
+
+def test_list_backed_matches_data_keeps_reference_semantics():
+    md = loader.MatchesData()
+    md.append(torch.tensor([1, 2], dtype=torch.int16), torch.tensor([3, 4], dtype=torch.int16), torch.ones(3, 2), torch.zeros(3, 2))
+    md.append(torch.tensor([5], dtype=torch.int16), torch.tensor([6], dtype=torch.int16), torch.ones(3, 1), torch.zeros(3, 1))
+    assert len(md) == 3
+    batches = list(md.iter(batch_size=2))
+    assert len(batches) == 1 and batches[0][0].dtype == torch.int64 and batches[0][2].shape == (3, 3)
+    assert len(list(md.iter(batch_size=1))) == 2
+    img = sfm.Image(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), sfm.Camera(1, 8, 6, torch.eye(3)))
+    model = sucre.SUCRe.__new__(sucre.SUCRe)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        sucre._restoration_of(md)
+    mf = loader.MatchesFile(Path('/tmp/none.h5'))
+    assert len(mf) == 0
+    with pytest.raises(RuntimeError, match='match_images'):
+        mf.load_matches()
+
+
+def test_cli_keeps_the_reference_flags_and_defaults():
+    """sucre.py:265-305 of the reference."""
+    want = {'image_dir': None, 'depth_dir': None, 'model_dir': None, 'output_dir': None, 'image_name': None,
+            'image_list': None, 'image_ids': None, 'light_model': False, 'use_closed_form': False, 'min_cover': 1e-6,
+            'image_scale': 1.0, 'filter_images_path': None, 'learning_rate': 0.05, 'num_iter': 200, 'batch_size': 5,
+            'save_interval': None, 'params_path': None, 'force_compute_matches': False, 'keep_matches': False,
+            'num_workers': 0, 'device': 'cuda'}
+    p = sucre.build_parser()
+    ns = p.parse_args(['--image-dir', 'a', '--depth-dir', 'b', '--model-dir', 'c', '--output-dir', 'd', '--image-ids', '1', '5'])
+    got = vars(ns)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        if k not in ('image_dir', 'depth_dir', 'model_dir', 'output_dir', 'image_ids'):
+            assert got[k] == v, k
+    assert got['image_ids'] == [1, 5] and got['image_dir'] == Path('a')
+    with pytest.raises(SystemExit):
+        p.parse_args(['--image-dir', 'a', '--depth-dir', 'b', '--model-dir', 'c', '--output-dir', 'd'])
+    with pytest.raises(SystemExit):
+        p.parse_args(['--image-dir', 'a', '--depth-dir', 'b', '--model-dir', 'c', '--output-dir', 'd', '--image-name', 'x', '--image-ids', '1', '2'])
+
+
+def test_api_surface_mirrors_reference_signatures():
+    assert list(inspect.signature(sucre.adam).parameters)[:8] == ['sucre', 'matches_data', 'lr', 'num_iter', 'batch_size', 'save_dir', 'save_interval', 'device']
+    assert list(inspect.signature(sucre.restore_image).parameters) == [
+        'image', 'colmap_model', 'output_dir', 'light_model', 'use_closed_form', 'min_cover', 'image_list', 'lr',
+        'num_iter', 'batch_size', 'save_interval', 'params_path', 'force_compute_matches', 'keep_matches', 'num_workers', 'device']
+    assert list(inspect.signature(sfm.Image.match_images).parameters) == ['self', 'image_list', 'matches_file', 'min_cover', 'num_workers', 'device']
+    assert list(inspect.signature(sfm.COLMAPModel.__init__).parameters) == ['self', 'model_dir', 'image_dir', 'depth_dir', 'image_scale']
+    assert list(inspect.signature(loader.MatchesFile.__init__).parameters) == ['self', 'path', 'colmap_model', 'overwrite']
+    for name in ('MatchesSample', 'MatchesData', 'MatchesFile', 'ImageDataset', 'load_rgb', 'load_depth_map', 'load_image_list'):
+        assert hasattr(loader, name)
+    for name in ('Pose', 'Camera', 'Image', 'Matches', 'COLMAPModel'):
+        assert hasattr(sfm, name)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under sucre_amd/ may import, load or mention it."""
+    for f in (ROOT / 'sucre_amd').rglob('*'):
+        if f.suffix in ('.py', '.hip', '.h', '.cpp') or f.name == 'Makefile':
+            text = f.read_text()
+            assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), f
+            assert 'libsucre_oracle' not in text and 'sucre_oracle' not in text, f
+    bench = (ROOT / 'bench.py').read_text()
+    assert bench.count('from oracle import oracle') == 1 and 'def cpu_baseline' in bench
+
+
+def test_light_model_is_refused_loudly():
+    img = sfm.Image(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), sfm.Camera(1, 8, 6, torch.eye(3)))
+    with pytest.raises(NotImplementedError, match='light'):
+        sucre.SUCRe(img, light_model=True)
