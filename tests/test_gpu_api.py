@@ -72,7 +72,7 @@ def test_cli_end_to_end(disk_scene, tmp_path, capsys):
     kept = np.load(tmp_path / f'{stem}.npz') if (tmp_path / f'{stem}.npz').exists() else None
     if kept is not None:
         per_view, _ = helpers.oracle_scene_samples(loaded)
-        for vname, keep, m in per_view[0]:
+        for vname, keep, m in per_view:
             if not keep:
                 assert f'{vname}/u1' not in kept
                 continue
