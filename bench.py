@@ -89,7 +89,8 @@ def main():
     rank, local_rank, world = sdist.init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun)'
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP engine has no CPU fallback'
-    device = torch.device('cuda', local_rank)
+    # one GPU per rank; SUCRE_DIST_BACKEND=gloo lets several ranks share a GPU on a 1-GPU test box
+    device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     W, H, T = args.width, args.height, args.num_iter
 
@@ -137,7 +138,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -149,6 +150,13 @@ def main():
     algo_bytes = OBS_BYTES * n_obs + state_bytes  # A_fit / T, independent of how often we re-read
     achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
     cover = resto.view_counts().cpu().numpy() / float(W * H)
+
+    traffic = None
+    tf = ROOT / 'profiles' / 'r01_traffic.json'
+    if tf.exists() and not args.use_closed_form and (W, H, n_views, T) == (1920, 1080, 65, 200):
+        rec = json.loads(tf.read_text())
+        if rec.get('n_obs') == n_obs:   # same workload as the profiled one
+            traffic = rec['hbm_bytes_per_launch']
 
     if rank == 0:
         out = {
@@ -167,7 +175,8 @@ def main():
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_per_s_per_gpu':
                            args.steps / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps * 1e3 - fit_ms},
             'roofline': {'bound': 'hbm', 'kernel': 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'ms_per_launch': iter_ms,
                          'obs_passes_per_launch': obs_passes},
         }

@@ -23,13 +23,26 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('SUCRE_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    """In-place sum over ranks.  RCCL reduces device tensors directly; under gloo (CPU tests, or several ranks
+    sharing one GPU) a device tensor is staged through the host."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if t.is_cuda and dist.get_backend(group) != 'nccl':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def shard_images(image_ids: list, rank: int, world: int) -> list:
@@ -55,14 +68,12 @@ def fit_shared_water(backend: WaterBackend, num_iter: int, group=None) -> None:
     """Lock-step fit of one image per rank with shared B, beta, gamma: objective
     sum_ranks sum_obs r^2 / (3 sum_ranks n_obs).  Per iteration: local gradient pass -> all-reduce(sum) of the
     ten float64 sums -> identical Adam step on every rank (J updates stay local)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     n = torch.tensor([backend.n_obs()], dtype=torch.int64)
-    if world > 1:
-        n = n.to(backend.grad_device()) if hasattr(backend, 'grad_device') else n
-        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    if hasattr(backend, 'grad_device') and dist.is_initialized() and dist.get_backend(group) == 'nccl':
+        n = n.to(backend.grad_device())
+    all_reduce_sum(n, group)
     backend.set_n_obs_total(int(n.item()))
     for it in range(1, num_iter + 1):
         sums = backend.grad(it)
-        if world > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(sums, group)
         backend.step(it)
