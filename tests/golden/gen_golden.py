@@ -74,6 +74,15 @@ def generate(name, spec):
     fit2 = quiet(rh.reference_fit, scene, md2, target, num_iter=50, batch_size=5)
     out['J_param_50_cover80'] = fit2['J']
     out['trace_param_cover80'] = fit2['trace']
+    # shared-water extension: this image and its left neighbour fitted in lock-step with tied B, beta, gamma
+    import copy
+    other = copy.copy(scene)
+    other.target = scene.target - 1
+    shared = quiet(rh.reference_shared_water, [scene, other], num_iter=40)
+    out['shared_targets'] = np.array([scene.target, other.target])
+    out['shared_J0'], out['shared_J1'] = shared['J']
+    out['shared_trace'] = shared['trace']
+    out['shared_n_total'] = np.int64(shared['n_total'])
     np.savez_compressed(HERE / f'{name}.npz', **out)
     print(name, 'views', len(scene.views), 'n_obs', int(out['n_obs']), 'kept', out['kept'].tolist(),
           'kept@0.8', out['kept_cover80'].tolist(), 'size', (HERE / f'{name}.npz').stat().st_size)

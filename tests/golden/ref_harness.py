@@ -145,3 +145,37 @@ def reference_fit(scene, matches_data, target, num_iter: int, use_closed_form: b
         h2.remove()
     J = model.J.detach().numpy().copy()
     return dict(J=J, trace=np.asarray(trace, dtype=np.float64), snaps=snaps, model=model)
+
+
+def reference_shared_water(scenes, num_iter: int, batch_size: int = 5, lr: float = 0.05):
+    """Shared-water composition built from reference classes only: one reference SUCRe
+    module per image, their B / beta / gamma attributes bound to the SAME Parameter objects, one
+    torch.optim.Adam over the de-duplicated parameter set, every batch loss divided by the TOTAL observation count
+    (the per-image loop body of sucre.py:143-146 otherwise unchanged)."""
+    _, loader, _, sucre_mod = import_reference()
+    models, datas = [], []
+    for scene in scenes:
+        _, md, target = reference_matches(scene)
+        models.append(sucre_mod.SUCRe(image=target))
+        datas.append(md)
+    for m in models[1:]:
+        m.B, m.beta, m.gamma = models[0].B, models[0].beta, models[0].gamma
+    params, seen = [], set()
+    for m in models:
+        for p in m.parameters():
+            if id(p) not in seen:
+                seen.add(id(p)); params.append(p)
+    n_total = sum(len(d) for d in datas)
+    opt = torch.optim.Adam(params, lr=lr)
+    trace = []
+    for _ in range(num_iter):
+        opt.zero_grad()
+        cost = 0.0
+        for m, d in zip(models, datas):
+            for u, v, cP, I in d.iter(batch_size=batch_size, device='cpu'):
+                loss = torch.square(I - m(u=u, v=v, cP=cP)).sum()
+                (loss / n_total / 3).backward()
+                cost += loss.item()
+        opt.step()
+        trace.append([cost] + [float(x) for p in (models[0].B, models[0].beta, models[0].gamma) for x in p.detach().flatten()])
+    return dict(J=[m.J.detach().numpy().copy() for m in models], trace=np.asarray(trace), n_total=n_total)

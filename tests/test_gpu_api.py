@@ -141,3 +141,40 @@ def test_shared_water_split_path_vs_oracle():
     assert np.abs(p0 - pstate[:9]).max() < 1e-5
     for b, o in zip(backends, oimgs):
         assert helpers.rms_per_channel(b.r.J().cpu().numpy(), o.J).max() < 1e-5
+
+
+def test_shared_water_vs_tied_reference_modules(golden):
+    """HIP split path (sucre_fit_grad / all-reduce / sucre_fit_step) against the golden produced by two reference
+    SUCRe modules with tied B, beta, gamma Parameters."""
+    import copy
+    from sucre_amd import engine
+    t0, t1 = (int(x) for x in golden['shared_targets'])
+    rt = golden['shared_trace']
+    T = rt.shape[0]
+    backends, traces = [], []
+    views = engine.device_views_from_scene(golden.scene, 'cuda')
+    for tgt in (t0, t1):
+        r = engine.Restoration(golden.scene.height, golden.scene.width, len(views))
+        r.match(views[tgt], views)
+        r.fit_init(views[tgt])
+        tr = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
+        backends.append(engine.HipWaterBackend(r, trace=tr)); traces.append(tr)
+    total = sum(b.n_obs() for b in backends)
+    assert total == int(golden['shared_n_total'])
+    for b in backends:
+        b.set_n_obs_total(total)
+    for it in range(1, T + 1):
+        sums = [b.grad(it) for b in backends]
+        red = sums[0] + sums[1]
+        for s in sums:
+            s.copy_(red)
+        for b in backends:
+            b.step(it)
+    tr = traces[0].cpu().numpy()
+    assert np.array_equal(tr, traces[1].cpu().numpy())
+    assert np.abs(tr[:, 1:] - rt[:, 1:]).max() < 1e-5
+    assert np.abs(tr[:, 0] / rt[:, 0] - 1).max() < 1e-4
+    for b, key in zip(backends, ('shared_J0', 'shared_J1')):
+        J = b.r.J().cpu().numpy()
+        assert np.array_equal(np.isnan(J), np.isnan(golden[key]))
+        assert helpers.rms_per_channel(J, golden[key]).max() < 1e-4

@@ -87,3 +87,34 @@ def test_fit_with_dropped_views(golden):
     assert np.array_equal(np.isnan(J), np.isnan(ref))
     assert helpers.rms_per_channel(J, ref).max() < 1e-6
     assert np.abs(trace[:, 1:] - golden['trace_param_cover80'][:, 1:]).max() < 2e-6
+
+
+def _shared_scenes(golden):
+    import copy
+    t0, t1 = (int(x) for x in golden['shared_targets'])
+    a, b = copy.copy(golden.scene), copy.copy(golden.scene)
+    a.target, b.target = t0, t1
+    return [a, b]
+
+
+def test_shared_water_oracle_vs_tied_reference_modules(golden):
+    """The N>1 exchange semantics (shared B, beta, gamma; loss / total n_obs) pinned to a composition of
+    reference SUCRe modules with tied Parameters (tests/golden/ref_harness.py::reference_shared_water)."""
+    imgs = []
+    for sc in _shared_scenes(golden):
+        _, samples = helpers.oracle_scene_samples(sc)
+        tgt = sc.views[sc.target]
+        imgs.append(oracle.SharedWaterImage(sc.height, sc.width, samples,
+                                            oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
+    total = sum(im.n_obs for im in imgs)
+    assert total == int(golden['shared_n_total'])
+    rt = golden['shared_trace']
+    pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
+    for it in range(1, rt.shape[0] + 1):
+        acc = sum(im.grad(pstate[:9], it, total) for im in imgs)
+        assert abs(acc[9] / rt[it - 1, 0] - 1) < 2e-5
+        oracle.shared_step(pstate, acc, it, total)
+        assert np.abs(pstate[:9] - rt[it - 1, 1:]).max() < 2e-6
+    for im, key in zip(imgs, ('shared_J0', 'shared_J1')):
+        assert np.array_equal(np.isnan(im.J), np.isnan(golden[key]))
+        assert helpers.rms_per_channel(im.J, golden[key]).max() < 1e-6
