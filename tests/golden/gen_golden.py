@@ -56,6 +56,10 @@ def generate(name, spec):
     out['n_obs'] = np.int64(len(md))
     fit = quiet(rh.reference_fit, scene, md, target, num_iter=200, snapshots=(1, 5), batch_size=5)
     out['J_param_200'] = fit['J']
+    # output stage of the reference on its own result (sucre.py:84-112): 8-bit images, stored as arrays
+    out['plot_J_200'] = np.asarray(fit['model'].plot_J())
+    out['plot_reconstruction_200'] = np.asarray(fit['model'].plot_reconstruction())
+    out['params_200'] = fit['trace'][-1, 1:]
     out['J_param_1'] = fit['snaps'][1]
     out['J_param_5'] = fit['snaps'][5]
     out['trace_param'] = fit['trace']

@@ -215,3 +215,25 @@ def test_light_model_is_refused_loudly():
     img = sfm.Image(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), sfm.Camera(1, 8, 6, torch.eye(3)))
     with pytest.raises(NotImplementedError, match='light'):
         sucre.SUCRe(img, light_model=True)
+
+
+def test_output_stage_matches_reference_images(golden):
+    """plot_J / plot_reconstruction (sucre.py:84-112) on the reference's own fitted state give the reference's
+    own 8-bit images (golden arrays produced by the reference, tests/golden/gen_golden.py)."""
+    sc = golden.scene
+    tgt = sc.views[sc.target]
+
+    class _Img(sfm.Image):
+        def get_rgb(self): return tgt.rgb_f32()
+        def get_depth_map(self): return tgt.depth_f32()
+
+    img = _Img(1, Path(tgt.name), Path('depth_' + tgt.name), sfm.Pose(tgt.R, tgt.t), sfm.Camera(1, sc.width, sc.height, sc.K))
+    model = sucre.SUCRe(img)
+    p = torch.tensor(golden['params_200'], dtype=torch.float32)
+    with torch.no_grad():
+        model.B.copy_(p[0:3].view(3, 1)); model.beta.copy_(p[3:6].view(3, 1)); model.gamma.copy_(p[6:9].view(3, 1))
+        model.J.copy_(torch.tensor(golden['J_param_200']))
+    assert np.array_equal(np.asarray(model.plot_J()), golden['plot_J_200'])
+    rec = np.asarray(model.plot_reconstruction()).astype(np.int16)
+    ref = golden['plot_reconstruction_200'].astype(np.int16)
+    assert np.abs(rec - ref).max() <= 1 and (rec != ref).mean() < 1e-3   # float32 exp ordering may flip a rounding
