@@ -40,6 +40,8 @@ def parse():
     p.add_argument('--num-iter', type=int, default=200)
     p.add_argument('--use-closed-form', action='store_true')
     p.add_argument('--shared-water', action='store_true')
+    p.add_argument('--batch-images', type=int, default=1,
+                   help='BASELINE config 3: restore this many different images of one survey per step (1 = config 2)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=9, help='views in the CPU-baseline sample')
     p.add_argument('--cpu-iters', type=int, default=5, help='Adam iterations in the CPU-baseline sample')
@@ -94,17 +96,35 @@ def main():
     torch.cuda.set_device(device)
     W, H, T = args.width, args.height, args.num_iter
 
-    # every rank restores its own image (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
-    scene = synth.make_scene(W, H, args.neighbours, seed=rank, device=device)
-    views = engine.device_views_from_scene(scene, device)
-    tgt = views[scene.target]
-    n_views = len(views)
+    # every rank restores its own image(s) (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
+    if args.batch_images > 1:
+        side = int((args.neighbours + 1) ** 0.5) + 1
+        gx = side + 8
+        gy = side + (args.batch_images + 7) // 8 - 1
+        survey = synth.make_survey(W, H, gx, gy, seed=rank, device=device)
+        all_views = engine.device_views_from_scene(survey, device)
+        centre = [j * gx + i for j in range(side // 2, gy - side // 2) for i in range(side // 2, gx - side // 2)]
+        jobs = []
+        for idx in centre[:args.batch_images]:
+            sel = survey.neighbours(idx, args.neighbours)
+            jobs.append((all_views[idx], [all_views[q] for q in sel]))
+        assert len(jobs) == args.batch_images, (len(jobs), args.batch_images)
+        scene = survey.scene_for(centre[0], args.neighbours)
+    else:
+        scene = synth.make_scene(W, H, args.neighbours, seed=rank, device=device)
+        views = engine.device_views_from_scene(scene, device)
+        jobs = [(views[scene.target], views)]
+    n_views = len(jobs[0][1])
     resto = engine.Restoration(H, W, n_views, device=device)
     J_out = None
 
     fit_events = []
 
     def step(record):
+        for tgt, views in jobs:
+            restore_one(tgt, views, record)
+
+    def restore_one(tgt, views, record):
         nonlocal J_out
         resto.match(tgt, views, min_cover=1e-6)
         resto.fit_init(tgt)
@@ -161,19 +181,19 @@ def main():
     if rank == 0:
         out = {
             'metric': 'restored Mpixels/sec/GPU at 1080p, 64 neighbour views; % HBM roofline',
-            'value': world * args.steps * W * H / 1e6 / elapsed,
+            'value': world * args.steps * len(jobs) * W * H / 1e6 / elapsed,
             'unit': 'Mpix/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'1 image {W}x{H} x {n_views} views (64 neighbours + self) per step per GPU, '
+            'config': {'workload': f'{len(jobs)} image(s) {W}x{H} x {n_views} views (64 neighbours + self) per step per GPU, '
                                    f'{T} Adam iterations, '
                                    + ('closed-form J' if args.use_closed_form else 'J as parameter')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_per_s_per_gpu':
-                           args.steps / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps * 1e3 - fit_ms},
+                           args.steps * len(jobs) / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps / len(jobs) * 1e3 - fit_ms},
             'roofline': {'bound': 'hbm', 'kernel': 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' if traffic else None,

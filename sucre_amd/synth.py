@@ -184,3 +184,50 @@ def make_scene(width: int, height: int, n_neighbours: int, seed: int = 0, relief
         if (i, j) == (0, 0):
             target = rank
     return SynthScene(width=width, height=height, K=K, views=views, target=target, seed=seed)
+
+
+@dataclass
+class SynthSurvey:
+    """A whole lawn-mower survey: every grid camera rendered once; targets pick their neighbours from it."""
+    width: int
+    height: int
+    K: torch.Tensor
+    views: list[SynthView]
+    grid: list[tuple[int, int]]          # (i, j) grid offset of every view
+    seed: int = 0
+
+    def neighbours(self, idx: int, k: int) -> list[int]:
+        """Indices of the ``k`` views nearest to view ``idx`` (normalised grid distance, ties by name) plus
+        ``idx`` itself, in name order -- the image_list a user would pass for that target."""
+        i0, j0 = self.grid[idx]
+        order = sorted(range(len(self.views)),
+                       key=lambda q: ((self.grid[q][0] - i0) ** 2 + (self.grid[q][1] - j0) ** 2, self.views[q].name))
+        return sorted(order[:k + 1], key=lambda q: self.views[q].name)
+
+    def scene_for(self, idx: int, k: int) -> SynthScene:
+        sel = self.neighbours(idx, k)
+        return SynthScene(width=self.width, height=self.height, K=self.K, views=[self.views[q] for q in sel],
+                          target=sel.index(idx), seed=self.seed)
+
+
+def make_survey(width: int, height: int, grid_x: int, grid_y: int, seed: int = 0, relief: float = 0.15,
+                spacing: float = 0.1, invalid_frac: float = 0.01, rot_sigma: float = 0.03, pos_sigma: float = 0.1,
+                device: str | torch.device = 'cpu') -> SynthSurvey:
+    """``grid_x`` x ``grid_y`` cameras on the same grid / noise model as ``make_scene`` (boustrophedon names)."""
+    fxy = 0.78 * width
+    K = torch.tensor([[fxy, 0.0, width / 2.0], [0.0, fxy, height / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    foot_w, foot_h = 3.0 * width / fxy, 3.0 * height / fxy
+    offs = [(i if j % 2 == 0 else grid_x - 1 - i, j) for j in range(grid_y) for i in range(grid_x)]
+    n = len(offs)
+    nw = _normal_host(3 * n, 1, seed).reshape(n, 3) * rot_sigma
+    npos = _normal_host(3 * n, 2, seed).reshape(n, 3) * pos_sigma
+    views = []
+    for q, (i, j) in enumerate(offs):
+        R = _rodrigues(nw[q])
+        t = np.array([(i + npos[q, 0]) * spacing * foot_w, (j + npos[q, 1]) * spacing * foot_h, npos[q, 2] * 0.5])
+        R32 = torch.tensor(R, dtype=torch.float32)
+        t32 = torch.tensor(t, dtype=torch.float32).view(3, 1)
+        depth_mm, rgb = render_view(K, R32.double().numpy(), t32.double().numpy().ravel(), width, height, view_id=q,
+                                    seed=seed, relief=relief, invalid_frac=invalid_frac, device=device)
+        views.append(SynthView(name=f'img_{q:04d}.png', R=R32, t=t32, depth_u16=depth_mm, rgb_u8=rgb))
+    return SynthSurvey(width=width, height=height, K=K, views=views, grid=offs, seed=seed)

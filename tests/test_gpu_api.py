@@ -178,3 +178,27 @@ def test_shared_water_vs_tied_reference_modules(golden):
         J = b.r.J().cpu().numpy()
         assert np.array_equal(np.isnan(J), np.isnan(golden[key]))
         assert helpers.rms_per_channel(J, golden[key]).max() < 1e-4
+
+
+def test_survey_of_images_reuses_one_workspace():
+    """Several targets of one survey restored back to back through the same workspace (BASELINE config 3 shape):
+    every image must equal its own oracle run -- nothing may leak from the previous image."""
+    from sucre_amd import engine
+    survey = synth.make_survey(80, 48, 5, 4, seed=9)
+    dev_views = engine.device_views_from_scene(survey, 'cuda')
+    resto = engine.acquire_restoration(48, 80, 5, 'cuda')
+    for idx in (6, 7, 13, 0, 19):
+        sel = survey.neighbours(idx, 4)
+        scene = survey.scene_for(idx, 4)
+        resto.match(dev_views[idx], [dev_views[q] for q in sel])
+        resto.fit_init(dev_views[idx])
+        trace = resto.fit(10)
+        J = resto.J().cpu().numpy()
+        per_view, samples = helpers.oracle_scene_samples(scene)
+        assert resto.view_counts().cpu().numpy().tolist() == [len(m) for _, _, m in per_view]
+        tgt = scene.views[scene.target]
+        Jo, po, to = oracle.fit(48, 80, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=10)
+        assert np.array_equal(np.isnan(J), np.isnan(Jo))
+        assert helpers.rms_per_channel(J, Jo).max() < 1e-5
+        assert np.abs(trace.cpu().numpy()[:, 1:] - to[:, 1:]).max() < 1e-5
+    assert engine.acquire_restoration(48, 80, 5, 'cuda') is resto
