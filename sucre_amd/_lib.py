@@ -6,10 +6,12 @@ CPU or PyTorch fallback for the hot path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 ABI_VERSION = 1
-LIB_PATH = Path(__file__).resolve().parent / 'libsucre_hip.so'
+# SUCRE_HIP_LIB selects another build of the same ABI (experiment builds of tools/microbench.py); default = the product
+LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent / 'libsucre_hip.so'))
 
 FIT_CLOSED_FORM = 1
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)

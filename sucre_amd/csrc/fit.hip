@@ -123,7 +123,7 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 // ---------------------------------------------------------------------------------------------------------------
 // Observation streaming: per-wave LDS-DMA ring.
 //
-// Each wave consumes the chunks of views wave, wave+4, ... of the tile's list.  A chunk is copied HBM -> LDS by
+// Each wave consumes levels wave, wave+4, ... of its (sorted) tile in the compact store (csrc/compact.hip).  A chunk is copied HBM -> LDS by
 // two LDS-DMA instructions (global_load_lds_dwordx4: 64 lanes = 1 KiB of ranges, 48 lanes = 768 B of colours)
 // into one of kRing private slots; kAhead = kRing-1 chunks stay in flight behind the one being consumed.
 // The DMAs have no VGPR destination, so prefetch depth costs LDS, not registers, and hipcc can neither sink them
@@ -141,7 +141,6 @@ struct __attribute__((aligned(16))) FitLdsT {
         float red[4][6][kTilePx];        // phase 2: per-pixel sums of the four waves (ring is dead by then)
     } u;
     float jbuf[kWithJ ? 3 : 1][kWithJ ? kTilePx : 4];  // closed-form J of the tile (closed-form kernels only)
-    double wpart[4][kNumSums];
     double stot[kSumsPad];
     float wsum[4][kNumSums];
     int is_last;
@@ -187,16 +186,15 @@ __device__ __forceinline__ void wait_chunks() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAheadNow) : "memory");
 }
 
-// Number of list entries (wave, wave+4, ...) this wave consumes.
+// Number of levels (wave, wave+4, ...) this wave consumes.
 __device__ __forceinline__ uint32_t views_of_wave(uint32_t n, int wave) {
     return n > (uint32_t)wave ? (n - (uint32_t)wave + 3u) / 4u : 0u;
 }
 
 // Ring prologue: put the first kAhead chunks in flight.
 template <class FitLds>
-__device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs,
-                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane,
-                                             size_t view_stride) {
+__device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, int wave,
+                                             int lane) {
     const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
 #ifdef SUCRE_EXP_NOLOAD  // experiment build only: no DMA; the ring holds plausible constant data instead
@@ -208,20 +206,19 @@ __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restr
 #endif
 #pragma unroll
     for (uint32_t d = 0; d < (uint32_t)kAhead; ++d)
-        if (d < r) dma_chunk(tile_obs + (size_t)lst[wave + 4u * d] * view_stride, ring0 + d * kSlot, voff);
+        if (d < r) dma_chunk(tile_obs + (size_t)(wave + 4u * d) * kChunk, ring0 + d * kSlot, voff);
 }
 
 // Ring steady state + drain; stream_begin must have been called for the same (tile, wave).
 template <int kPass, class FitLds>
-__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs,
-                                             const uint32_t *__restrict__ lst, uint32_t r, int wave, int lane,
-                                             size_t view_stride, const Water &w, const float (&J)[3][4], Acc &acc) {
+__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, int wave,
+                                             int lane, const Water &w, const float (&J)[3][4], Acc &acc) {
     const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
     uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
     for (uint32_t v = 0; v < r; ++v) {
         if (v + kAhead < r)
-            dma_chunk(tile_obs + (size_t)lst[wave + 4u * (v + kAhead)] * view_stride, ring0 + slot_in * kSlot, voff);
+            dma_chunk(tile_obs + (size_t)(wave + 4u * (v + kAhead)) * kChunk, ring0 + slot_in * kSlot, voff);
         const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
         if (ahead >= (uint32_t)kAhead) wait_chunks<kAhead>();
         else if (kAhead > 2 && ahead == 2u) wait_chunks<2>();
@@ -229,7 +226,8 @@ __device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restr
         else wait_chunks<0>();
         const uint8_t *sp = &lds.u.ring[wave][slot][0];
         const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
-        const uint3 c3 = *reinterpret_cast<const uint3 *>(sp + kChunkZ + lane * 12);
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + kChunkZ) + lane;  // planar R | G | B
+        const uint3 c3 = make_uint3(cp[0], cp[64], cp[128]);
         accumulate_view<kPass>(z4, c3, w, J, acc);
         slot = slot + 1 == kRing ? 0 : slot + 1;
         slot_in = slot_in + 1 == kRing ? 0 : slot_in + 1;
@@ -267,37 +265,65 @@ __device__ __forceinline__ void reduce_pixels(FitLds &lds, const Acc &acc, int w
         out[q] = ((lds.u.red[0][q][t] + lds.u.red[1][q][t]) + lds.u.red[2][q][t]) + lds.u.red[3][q][t];
 }
 
-// Fixed-order float64 reduction of the per-tile partials (layout [kNumSums][n_tiles]) by one 256-thread
-// workgroup: sums[q] = sum_tile partials[q][tile].  Same code (hence same bits) in the fused and the split path.
-// Partials are read with agent-scope (sc1) loads: they were published by sc1 write-through stores.
-__device__ __forceinline__ void block_reduce_partials(const float *partials, int n_tiles, double (*wpart)[kNumSums],
-                                                      double *stot, double *__restrict__ sums) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double s[kNumSums];
+// Two-level, fixed-order float64 reduction of the per-tile partials (layout [kNumSums][n_tiles]):
+//   gpart[q][g] = sum of the 32 tiles of group g       (one load per lane + fixed-shape shuffle tree)
+//   sums[q]     = sum over the groups                  (4 loads per lane + the same tree)
+// The same two functions run in the fused tail (group-last / global-last workgroup) and in the split-path
+// kernel, so both paths produce the same bits.  All hand-off data move with agent-scope (sc1) accesses.
+__device__ __forceinline__ double wave_sum_fixed(double x) {  // fixed-shape tree: same bits on every run
 #pragma unroll
-    for (int q = 0; q < kNumSums; ++q) s[q] = 0.0;
-    for (int tile = t; tile < n_tiles; tile += 256) {
-#pragma unroll
-        for (int q = 0; q < kNumSums; ++q)
-            s[q] += (double)__hip_atomic_load(partials + (size_t)q * n_tiles + tile, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+// 256 threads: wave w reduces quantities q = w, w+4, w+8; lane l holds tile 32 g + l (lanes >= 32 hold 0).
+__device__ __forceinline__ void reduce_group(const float *partials, int n_tiles, int g, double *gpart, int n_groups) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = g * kGroup + lane;
+    for (int q = wave; q < kNumSums; q += 4) {
+        double x = 0.0;
+        if (lane < kGroup && tile < n_tiles)
+            x = (double)__hip_atomic_load(partials + (size_t)q * n_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = wave_sum_fixed(x);
+        if (lane == 0) __hip_atomic_store(gpart + (size_t)q * n_groups + g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int q = 0; q < kNumSums; ++q) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < kNumSums; ++q) wpart[wave][q] = s[q];
+}
+
+// 256 threads: wave w reduces quantities q = w, w+4, w+8 over all groups (lane l takes groups l, l+64, ...).
+__device__ __forceinline__ void reduce_total(const double *gpart, int n_groups, double *stot, double *__restrict__ sums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q < kNumSums; q += 4) {
+        double x = 0.0;
+        for (int g = lane; g < n_groups; g += 64)
+            x += __hip_atomic_load(gpart + (size_t)q * n_groups + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = wave_sum_fixed(x);
+        if (lane == 0) {
+            sums[q] = x;  // global copy: read by the host all-reduce in shared-water runs
+            stot[q] = x;  // LDS copy: read by water_step of the same workgroup
+        }
     }
     __syncthreads();
-    if (t < kNumSums) {
-        const double tot = ((wpart[0][t] + wpart[1][t]) + wpart[2][t]) + wpart[3][t];
-        sums[t] = tot;  // global copy: read by the host all-reduce in shared-water runs
-        stot[t] = tot;  // LDS copy: read by water_step of the same workgroup
+}
+
+// Arrival on a counter (relaxed agent-scope fetch_add by one lane behind the wave's drained stores); returns
+// true in the workgroup that arrived last, which has then done its agent acquire and re-armed the counter.
+__device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned expected, int *flag) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) {
+            const unsigned got = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (got == expected - 1u) ? 1 : 0;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+            }
+            *flag = last;
+        }
     }
     __syncthreads();
+    return *flag != 0;
 }
 
 // torch.optim.Adam step on B, beta, gamma (sucre.py:148) from the reduced sums, by lanes 0..8 of one wave;
@@ -332,14 +358,14 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
 }
 
 template <bool kClosed, bool kFused>
-__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ obs,
-                                                       const uint32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ tile_n, int n_views,
+__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
+                                                       const uint64_t *__restrict__ tile_off,
+                                                       const uint32_t *__restrict__ levels,
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
-                                                       unsigned *ticket, double *sums, double *trace_row,
-                                                       size_t tile_stride, size_t view_stride) {
+                                                       unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                                       double *trace_row) {
     __shared__ FitLdsT<kClosed> lds;  // 25.2 KB (6 workgroups/CU) without jbuf, 28.2 KB (5) with it
     const int tile = blockIdx.x;
     const int n_tiles = gridDim.x;
@@ -347,16 +373,15 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
-    const uint32_t n = tile_n[tile];
-    const uint32_t *lst = list + (size_t)tile * n_views;
-    const uint8_t *tile_obs = obs + (size_t)tile * tile_stride;
+    const uint32_t n = levels[tile];
+    const uint8_t *tile_obs = comp + tile_off[tile];
     float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
 
     const uint32_t r = views_of_wave(n, wave);
     float J[3][4];
     Acc acc;
     float tot[6];
-    stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
+    stream_begin(lds, tile_obs, r, wave, lane);
     if (kClosed) {
         // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
         zero_acc(acc);
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-        stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
+        stream_views<kPassClosedJ>(lds, tile_obs, r, wave, lane, w, J, acc);
         reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
             lds.jbuf[c][t] = Jc;
         }
         __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
-        stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
+        stream_begin(lds, tile_obs, r, wave, lane);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
@@ -384,6 +409,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         // asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's first
         // use; the empty asm makes that first use happen here, where only the prologue (issued at the same time,
         // hence landing at the same time) is outstanding: one shared start-up latency, nothing drained later.
+        // (Prefetching the tail's own J / exp_avg / exp_avg_sq here as well was measured: no gain.)
         float4 jv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
@@ -395,8 +421,8 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
 
     zero_acc(acc);
-    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
-    else stream_views<kPassGradJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
+    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, wave, lane, w, J, acc);
+    else stream_views<kPassGradJ>(lds, tile_obs, r, wave, lane, w, J, acc);
     reduce_pixels(lds, acc, wave, lane, t, tot);
 
     // pixel-parallel tail: this thread owns pixel slot t
@@ -414,9 +440,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         float *vtile = vt + (size_t)tile * 3 * kTilePx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float Jc = Jtile[c * kTilePx + t];
-            float m = mtile[c * kTilePx + t];
-            float v = vtile[c * kTilePx + t];
+            float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
             // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
             sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
             adam_update(Jc, m, v, gscale * tot[c], co);
@@ -448,48 +472,36 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
                            __HIP_MEMORY_SCOPE_AGENT);
 
     if (kFused) {
-        // Last-arriver tail: the workgroup that draws the final ticket reduces all partials and steps the water
-        // parameters, so an iteration is ONE launch.  Hand-off (Guideline 16, sc1 form): the storing wave drains
-        // vmcnt, then one of its lanes does a relaxed agent-scope fetch_add; the last arriver does one agent
-        // acquire, drains, joins a workgroup barrier, and reads the partials with sc1 loads.  Nobody spins.
-        if (t < 64) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (t == 0) {
-                const unsigned got = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = (got == (unsigned)n_tiles - 1u) ? 1 : 0;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-                }
-                lds.is_last = last;
+        // Two-level last-arriver tail, so an iteration is ONE launch and no counter sees more than 255 arrivals
+        // (one word shared by all 8160 workgroups saturates at ~88 returning atomics/us = ~93 us per launch,
+        // measured).  Hand-off per Guideline 16, sc1 form: payload stored write-through, the storing wave drains
+        // vmcnt, one lane does a relaxed agent-scope fetch_add; the last arriver acquires once.  Nobody spins.
+        const int g = tile / kGroup;
+        const unsigned gsize = (unsigned)(min((g + 1) * kGroup, n_tiles) - g * kGroup);
+        if (arrive_last(ticket + (size_t)(1 + g) * kTicketStride, gsize, &lds.is_last)) {  // workgroup-uniform
+            reduce_group(partials, n_tiles, g, gpart, n_groups);
+            if (arrive_last(ticket, (unsigned)n_groups, &lds.is_last)) {
+                reduce_total(gpart, n_groups, lds.stot, sums);
+                // every other workgroup has finished (it arrived after its last use of the parameters)
+                if (t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);
             }
-        }
-        __syncthreads();
-        if (lds.is_last) {  // workgroup-uniform
-            block_reduce_partials(partials, n_tiles, lds.wpart, lds.stot, sums);
-            // every other workgroup has finished (it took its ticket after its last use of the parameters)
-            if (t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);
         }
     }
 }
 
 // SUCRe.update_J alone (sucre.py:66-77, 156)
-__global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ obs,
-                                                       const uint32_t *__restrict__ list,
-                                                       const uint32_t *__restrict__ tile_n, int n_views,
-                                                       const float *__restrict__ params, float *__restrict__ Jt,
-                                                       size_t tile_stride, size_t view_stride) {
+__global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ comp,
+                                                       const uint64_t *__restrict__ tile_off,
+                                                       const uint32_t *__restrict__ levels,
+                                                       const float *__restrict__ params, float *__restrict__ Jt) {
     __shared__ FitLdsT<false> lds;
     const int tile = blockIdx.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(params);
-    const uint32_t n = tile_n[tile];
-    const uint32_t r = views_of_wave(n, wave);
-    const uint8_t *tile_obs = obs + (size_t)tile * tile_stride;
-    const uint32_t *lst = list + (size_t)tile * n_views;
+    const uint32_t r = views_of_wave(levels[tile], wave);
+    const uint8_t *tile_obs = comp + tile_off[tile];
     float J[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -497,19 +509,22 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
         for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
     Acc acc;
     zero_acc(acc);
-    stream_begin(lds, tile_obs, lst, r, wave, lane, view_stride);
-    stream_views<kPassClosedJ>(lds, tile_obs, lst, r, wave, lane, view_stride, w, J, acc);
+    stream_begin(lds, tile_obs, r, wave, lane);
+    stream_views<kPassClosedJ>(lds, tile_obs, r, wave, lane, w, J, acc);
     float tot[6];
     reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
     for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + t] = tot[c] / tot[3 + c];
 }
 
-__global__ __launch_bounds__(256) void reduce_sums_kernel(const float *__restrict__ partials, int n_tiles,
-                                                          double *__restrict__ sums) {
-    __shared__ double wpart[4][kNumSums];
+__global__ __launch_bounds__(256) void reduce_groups_kernel(const float *partials, int n_tiles, double *gpart,
+                                                            int n_groups) {
+    reduce_group(partials, n_tiles, blockIdx.x, gpart, n_groups);
+}
+
+__global__ __launch_bounds__(256) void reduce_sums_kernel(const double *gpart, int n_groups, double *__restrict__ sums) {
     __shared__ double stot[kSumsPad];
-    block_reduce_partials(partials, n_tiles, wpart, stot, sums);
+    reduce_total(gpart, n_groups, stot, sums);
 }
 
 __global__ __launch_bounds__(64) void param_step_kernel(const double *__restrict__ sums, float *__restrict__ pstate,
@@ -523,12 +538,15 @@ struct Params9 { float v[9]; };
 __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict__ rgb1,
                                                        const float *__restrict__ depth1,
                                                        const float *__restrict__ J0, int H, int W, int tiles_x,
-                                                       float *__restrict__ Jt, float *__restrict__ mt,
+                                                       const uint32_t *__restrict__ perm, float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *__restrict__ pstate,
-                                                       unsigned *__restrict__ ticket, const Params9 p0) {
-    const int tile = blockIdx.x, t = threadIdx.x;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int v = ty * kTile + (t >> 4), u = tx * kTile + (t & 15);
+                                                       unsigned *__restrict__ ticket, int n_tickets,
+                                                       const Params9 p0) {
+    const int tile = blockIdx.x, t = threadIdx.x;  // sorted tile / slot; perm gives the pixel that lives there
+    const uint32_t src = perm[(size_t)tile * kTilePx + t];
+    const int stile = src / kTilePx, sslot = src % kTilePx;
+    const int ty = stile / tiles_x, tx = stile - ty * tiles_x;
+    const int v = ty * kTile + (sslot >> 4), u = tx * kTile + (sslot & 15);
     const bool inside = v < H && u < W;
     const size_t o = inside ? (size_t)v * W + u : 0;
     const bool valid = inside && !(depth1[o] <= 0.0f);  // self.J[depth <= 0] = nan, sucre.py:48
@@ -542,18 +560,19 @@ __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict
         vt[i] = 0.f;
     }
     if (tile == 0 && t < 27) pstate[t] = t < 9 ? p0.v[t] : 0.f;
-    if (tile == 0 && t == 32) *ticket = 0u;
+    for (int i = tile * 256 + t; i < n_tickets; i += gridDim.x * 256) ticket[i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__ Jt, int H, int W, int tiles_x,
-                                                       float *__restrict__ J) {
-    const int tile = blockIdx.x, t = threadIdx.x;
+                                                       const uint32_t *__restrict__ invperm, float *__restrict__ J) {
+    const int tile = blockIdx.x, t = threadIdx.x;  // image tile / slot; invperm says where the pixel was sorted to
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int v = ty * kTile + (t >> 4), u = tx * kTile + (t & 15);
     if (v >= H || u >= W) return;
+    const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
     const size_t o = ((size_t)v * W + u) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) J[o + c] = Jt[((size_t)tile * 3 + c) * kTilePx + t];
+    for (int c = 0; c < 3; ++c) J[o + c] = Jt[((size_t)(dst / kTilePx) * 3 + c) * kTilePx + dst % kTilePx];
 }
 
 __global__ void set_n_obs_total_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
@@ -563,23 +582,24 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
     Params9 p0;
     for (int i = 0; i < 9; ++i) p0.v[i] = params0[i];
     hipLaunchKernelGGL(fit_init_kernel, dim3(L.n_tiles), dim3(256), 0, s, rgb1, depth1, J0, L.H, L.W, L.tiles_x,
-                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_perm), reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
                        reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_params),
-                       reinterpret_cast<unsigned *>(ws + L.off_ticket), p0);
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket), (1 + L.n_groups) * kTicketStride, p0);
     return hipGetLastError();
 }
 
 template <bool kClosed, bool kFused>
 static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
-                       reinterpret_cast<const uint32_t *>(ws + L.off_list),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_tile_n), L.n_views,
+    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
+                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
                        reinterpret_cast<float *>(ws + L.off_params),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
                        reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_partials), co,
-                       reinterpret_cast<unsigned *>(ws + L.off_ticket), reinterpret_cast<double *>(ws + L.off_sums),
-                       trace_row, L.obs_tile_stride, L.obs_view_stride);
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket),
+                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups,
+                       reinterpret_cast<double *>(ws + L.off_sums), trace_row);
 }
 
 // One whole iteration in a single launch (gradient pass + last-arriver reduction + water-parameter step).
@@ -595,8 +615,11 @@ hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &c
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
     if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, nullptr, s);
     else launch_grad_variant<false, false>(L, ws, co, nullptr, s);
-    hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(256), 0, s,
+    hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.n_groups), dim3(256), 0, s,
                        reinterpret_cast<const float *>(ws + L.off_partials), L.n_tiles,
+                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups);
+    hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(256), 0, s,
+                       reinterpret_cast<const double *>(ws + L.off_gpartials), L.n_groups,
                        reinterpret_cast<double *>(ws + L.off_sums));
     return hipGetLastError();
 }
@@ -609,17 +632,17 @@ hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, dou
 }
 
 hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s) {
-    hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
-                       reinterpret_cast<const uint32_t *>(ws + L.off_list),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_tile_n), L.n_views,
-                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J),
-                       L.obs_tile_stride, L.obs_view_stride);
+    hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
+                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
+                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J));
     return hipGetLastError();
 }
 
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s) {
     hipLaunchKernelGGL(export_J_kernel, dim3(L.n_tiles), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(ws + L.off_J), L.H, L.W, L.tiles_x, J);
+                       reinterpret_cast<const float *>(ws + L.off_J), L.H, L.W, L.tiles_x,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_invperm), J);
     return hipGetLastError();
 }
 

@@ -8,10 +8,12 @@ namespace sucre {
 constexpr int kTile = 16;            // tile edge in pixels
 constexpr int kTilePx = 256;         // pixels per tile = one 64-lane wave x 4 pixels per lane
 constexpr int kChunkZ = 1024;        // bytes: 256 float32 ranges
-constexpr int kChunkRGB = 768;       // bytes: 64 lanes x (r[4] g[4] b[4])
+constexpr int kChunkRGB = 768;       // bytes: planar R[256] G[256] B[256] uint8
 constexpr int kChunk = kChunkZ + kChunkRGB;  // 1792 bytes per (tile, view)
 constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
+constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)
+constexpr int kTicketStride = 16;    // uint32 words between tickets: every counter on its own 64-byte line
 constexpr int kMaxViews = 4096;
 
 struct Layout {
@@ -19,15 +21,26 @@ struct Layout {
     size_t off_obs;         // uint8  chunks of kChunk bytes, chunk(tile, k) at tile*obs_tile_stride + k*obs_view_stride
     size_t obs_tile_stride, obs_view_stride;
     size_t off_cnt;         // uint16 [n_tiles][n_views]   matches of view k inside the tile
-    size_t off_list;        // uint32 [n_tiles][n_views]   compacted indices of kept, non-empty views
-    size_t off_tile_n;      // uint32 [n_tiles]            length of that list
+    size_t off_comp;        // uint8  compact store: chunk (sorted tile, level) at tile_off[tile] + level*kChunk
+    size_t off_pcount;      // uint16 [n_tiles*256]        observations of every pixel over the kept views
+    size_t off_pmask;       // uint64 [n_tiles*256][mask_words]  which views observe the pixel (bit k = view k)
+    int mask_words;
+    size_t off_blockhist;   // uint32 [256 bins][n_tiles]  counting-sort histograms (bin-major), scanned in place
+    size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
+    size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)
+    size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
+    size_t off_levels;      // uint32 [n_tiles]            chunks (levels) of every sorted tile
+    size_t off_tile_off;    // uint64 [n_tiles]            byte offset of a sorted tile's first chunk in the compact store
+    size_t off_total_chunks;// uint64 [1]
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]
     size_t off_n_obs;       // uint64 [1]
     size_t off_n_obs_total; // uint64 [1]
     size_t off_params;      // float  [9] params, [9] exp_avg, [9] exp_avg_sq
     size_t off_sums;        // double [kSumsPad]
-    size_t off_ticket;      // uint32 [1]  arrival counter of the fused last-arriver reduction
+    size_t off_ticket;      // uint32 [(1 + n_groups) * kTicketStride]  arrival counters: [0] = groups done, [1+g] = tiles of group g done
+    size_t off_gpartials;   // double [kNumSums][n_groups]  per-group sums
+    int n_groups;
     size_t off_partials;    // float  [n_tiles][kNumSums]
     size_t off_J, off_m, off_v;  // float [n_tiles][3][256]
     size_t total;
@@ -51,15 +64,26 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->obs_tile_stride = nv * kChunk; L->obs_view_stride = kChunk;      // [tile][view]
 #endif
     L->off_cnt = take(nt * nv * sizeof(uint16_t));
-    L->off_list = take(nt * nv * sizeof(uint32_t));
-    L->off_tile_n = take(nt * sizeof(uint32_t));
+    L->off_comp = take(nt * nv * kChunk);
+    L->off_pcount = take(nt * kTilePx * sizeof(uint16_t));
+    L->mask_words = (n_views + 63) / 64;
+    L->off_pmask = take(nt * kTilePx * (size_t)L->mask_words * sizeof(uint64_t));
+    L->off_blockhist = take(256 * nt * sizeof(uint32_t));
+    L->off_bin_totals = take(512 * sizeof(uint32_t));
+    L->off_perm = take(nt * kTilePx * sizeof(uint32_t));
+    L->off_invperm = take(nt * kTilePx * sizeof(uint32_t));
+    L->off_levels = take(nt * sizeof(uint32_t));
+    L->off_tile_off = take(nt * sizeof(uint64_t));
+    L->off_total_chunks = take(sizeof(uint64_t));
     L->off_view_count = take(nv * sizeof(uint64_t));
     L->off_view_keep = take(nv * sizeof(uint32_t));
     L->off_n_obs = take(sizeof(uint64_t));
     L->off_n_obs_total = take(sizeof(uint64_t));
     L->off_params = take(27 * sizeof(float));
     L->off_sums = take(kSumsPad * sizeof(double));
-    L->off_ticket = take(sizeof(uint32_t));
+    L->n_groups = (L->n_tiles + kGroup - 1) / kGroup;
+    L->off_ticket = take((size_t)(1 + L->n_groups) * kTicketStride * sizeof(uint32_t));
+    L->off_gpartials = take((size_t)kNumSums * L->n_groups * sizeof(double));
     L->off_partials = take(nt * kNumSums * sizeof(float));
     L->off_J = take(nt * 3 * kTilePx * sizeof(float));
     L->off_m = take(nt * 3 * kTilePx * sizeof(float));

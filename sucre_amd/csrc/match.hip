@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
             *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
-            uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ + lane * 12);
-            c[0] = r4; c[1] = g4; c[2] = b4;
+            uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
+            c[0] = r4; c[64] = g4; c[128] = b4;
         }
     }
 }
@@ -185,34 +185,15 @@ __global__ __launch_bounds__(256) void view_count_kernel(const uint16_t *__restr
     }
 }
 
-// Per tile: compacted list of the views that are kept and have at least one match inside the tile.
-// One wave per tile.  Wave 0 of block 0 also totals n_obs = len(matches_data) (loader.py:52-53).
-__global__ __launch_bounds__(256) void tile_list_kernel(const uint16_t *__restrict__ cnt,
-                                                        const uint32_t *__restrict__ view_keep,
-                                                        const uint64_t *__restrict__ view_count, int n_tiles,
-                                                        int n_views, uint32_t *__restrict__ list,
-                                                        uint32_t *__restrict__ tile_n, uint64_t *__restrict__ n_obs,
-                                                        uint64_t *__restrict__ n_obs_total) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile < n_tiles) {
-        uint32_t n = 0;
-        for (int base = 0; base < n_views; base += 64) {
-            const int k = base + lane;
-            const bool f = k < n_views && view_keep[k] != 0 && cnt[(size_t)tile * n_views + k] > 0;
-            const unsigned long long mask = __ballot(f);
-            const uint32_t before = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (f) list[(size_t)tile * n_views + n + before] = (uint32_t)k;
-            n += __builtin_popcountll(mask);
-        }
-        if (lane == 0) tile_n[tile] = n;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        unsigned long long s = 0;
-        for (int k = lane; k < n_views; k += 64) s += view_keep[k] ? view_count[k] : 0ull;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) { *n_obs = s; *n_obs_total = s; }
-    }
+// n_obs = len(matches_data) (loader.py:52-53): matches of the kept views.
+__global__ __launch_bounds__(64) void n_obs_kernel(const uint32_t *__restrict__ view_keep,
+                                                   const uint64_t *__restrict__ view_count, int n_views,
+                                                   uint64_t *__restrict__ n_obs, uint64_t *__restrict__ n_obs_total) {
+    const int lane = threadIdx.x;
+    unsigned long long s = 0;
+    for (int k = lane; k < n_views; k += 64) s += view_keep[k] ? view_count[k] : 0ull;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) { *n_obs = s; *n_obs_total = s; }
 }
 
 __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restrict__ obs,
@@ -230,8 +211,8 @@ __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restr
     if (cnt[(size_t)tile * n_views + k] > 0) {
         const uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
         z = reinterpret_cast<const float *>(chunk)[slot];
-        const uint8_t *p = chunk + kChunkZ + (slot >> 2) * 12 + (slot & 3);
-        c[0] = p[0]; c[1] = p[4]; c[2] = p[8];
+        const uint8_t *p = chunk + kChunkZ + slot;
+        c[0] = p[0]; c[1] = p[kTilePx]; c[2] = p[2 * kTilePx];
     }
     const size_t o = (size_t)v * W + u;
     if (z_out) z_out[o] = z;
@@ -274,12 +255,11 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
     hipLaunchKernelGGL(view_count_kernel, dim3(L.n_views), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, min_cover,
                        (double)L.W * (double)L.H, vc, vk);
-    hipLaunchKernelGGL(tile_list_kernel, dim3((L.n_tiles + 3) / 4), dim3(256), 0, s, cnt, vk, vc, L.n_tiles,
-                       L.n_views, reinterpret_cast<uint32_t *>(ws + L.off_list),
-                       reinterpret_cast<uint32_t *>(ws + L.off_tile_n),
+    hipLaunchKernelGGL(n_obs_kernel, dim3(1), dim3(64), 0, s, vk, vc, L.n_views,
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return launch_compact(L, ws, s);
 }
 
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {

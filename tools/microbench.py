@@ -44,9 +44,12 @@ def layout(H, W, nv):
         nonlocal o
         offs[name] = o
         o = (o + b + 255) // 256 * 256
-    take('obs', nt * nv * 1792); take('cnt', nt * nv * 2); take('list', nt * nv * 4); take('tile_n', nt * 4)
+    take('obs', nt * nv * 1792); take('cnt', nt * nv * 2)
+    take('comp', nt * nv * 1792); take('pcount', nt * 256 * 2); take('pmask', nt * 256 * ((nv + 63) // 64) * 8); take('blockhist', 256 * nt * 4); take('bin_totals', 512 * 4)
+    take('perm', nt * 256 * 4); take('invperm', nt * 256 * 4); take('levels', nt * 4); take('tile_off', nt * 8); take('total_chunks', 8)
     take('view_count', nv * 8); take('view_keep', nv * 4); take('n_obs', 8); take('n_obs_total', 8)
-    take('params', 27 * 4); take('sums', 12 * 8); take('ticket', 4); take('partials', nt * 10 * 4)
+    ng = (nt + 31) // 32
+    take('params', 27 * 4); take('sums', 12 * 8); take('ticket', (1 + ng) * 16 * 4); take('gpartials', 10 * ng * 8); take('partials', nt * 10 * 4)
     take('J', nt * 768 * 4); take('m', nt * 768 * 4); take('v', nt * 768 * 4)
     return nt, offs, o
 
@@ -60,12 +63,15 @@ byts = 7 * n_obs + 72 * H * W
 def make_ws():
     ws = torch.zeros(total, dtype=torch.uint8, device=dev)
     g = torch.Generator(device=dev); g.manual_seed(0)
-    obs = ws[offs['obs']:offs['obs'] + nt * NV * 1792].view(nt * NV, 1792)
+    obs = ws[offs['comp']:offs['comp'] + nt * NV * 1792].view(nt * NV, 1792)   # compact store, every level full
     obs[:, :1024].view(torch.float32).copy_(2.5 + torch.rand((nt * NV, 256), device=dev, generator=g))
     obs[:, 1024:].copy_(torch.randint(0, 256, (nt * NV, 768), device=dev, generator=g, dtype=torch.uint8))
-    ws[offs['list']:offs['list'] + nt * NV * 4].view(torch.int32).view(nt, NV).copy_(
-        torch.arange(NV, device=dev, dtype=torch.int32).expand(nt, NV))
-    ws[offs['tile_n']:offs['tile_n'] + nt * 4].view(torch.int32).fill_(NV)
+    ws[offs['levels']:offs['levels'] + nt * 4].view(torch.int32).fill_(NV)
+    ws[offs['tile_off']:offs['tile_off'] + nt * 8].view(torch.int64).copy_(
+        torch.arange(nt, device=dev, dtype=torch.int64) * (NV * 1792))
+    ident = torch.arange(nt * 256, device=dev, dtype=torch.int32)
+    ws[offs['perm']:offs['perm'] + nt * 1024].view(torch.int32).copy_(ident)
+    ws[offs['invperm']:offs['invperm'] + nt * 1024].view(torch.int32).copy_(ident)
     ws[offs['n_obs']:offs['n_obs'] + 8].view(torch.int64).fill_(n_obs)
     ws[offs['n_obs_total']:offs['n_obs_total'] + 8].view(torch.int64).fill_(n_obs)
     ws[offs['params']:offs['params'] + 36].view(torch.float32).fill_(0.1)
