@@ -143,19 +143,20 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint16_t *__restrict
     invperm[src] = dst;
 }
 
-// 3a. levels of every sorted tile = the largest pixel count in it.
+// 3a. levels of every sorted tile = the largest pixel count in it; the levels below the smallest count are
+//     completely full (every slot a real observation), which lets the fit skip the validity select there.
 __global__ __launch_bounds__(256) void tile_levels_kernel(const uint16_t *__restrict__ pcount,
                                                           const uint32_t *__restrict__ perm,
-                                                          uint32_t *__restrict__ levels) {
-    __shared__ uint32_t mx[256];
+                                                          uint32_t *__restrict__ levels, uint32_t *__restrict__ full) {
+    __shared__ uint32_t mx[256], mn[256];
     const int t = threadIdx.x;
-    mx[t] = pcount[perm[(size_t)blockIdx.x * kTilePx + t]];
+    mx[t] = mn[t] = pcount[perm[(size_t)blockIdx.x * kTilePx + t]];
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) mx[t] = max(mx[t], mx[t + w]);
+        if (t < w) { mx[t] = max(mx[t], mx[t + w]); mn[t] = min(mn[t], mn[t + w]); }
         __syncthreads();
     }
-    if (t == 0) levels[blockIdx.x] = mx[0];
+    if (t == 0) { levels[blockIdx.x] = mx[0]; full[blockIdx.x] = mn[0]; }
 }
 
 // 3b. byte offset of every sorted tile's first chunk (exclusive scan of levels; one workgroup).
@@ -255,7 +256,8 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s) {
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, s, totals, bins, bin_base);
     hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, bin_base, L.n_views,
                        L.n_tiles, perm, invperm);
-    hipLaunchKernelGGL(tile_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, levels);
+    hipLaunchKernelGGL(tile_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, levels,
+                       reinterpret_cast<uint32_t *>(ws + L.off_full));
     hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks));
     hipLaunchKernelGGL(gather_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,

@@ -70,7 +70,9 @@ struct Acc {
 
 constexpr float kInv255 = (float)(1.0 / 255.0);
 
-template <int kPass>
+// kMasked = false: every slot of the chunk is a real observation (levels below the tile's smallest pixel count in
+// the compact store), so the z > 0 test and the selects are compiled out.
+template <int kPass, bool kMasked>
 __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
                                                 const float (&J)[3][4], Acc &acc) {
     const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
@@ -82,7 +84,7 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float z = zz[j];
-        const bool valid = z > 0.0f;
+        const bool valid = !kMasked || z > 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t k = (cc[c] >> (8 * j)) & 255u;
@@ -209,14 +211,14 @@ __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restr
         if (d < r) dma_chunk(tile_obs + (size_t)(wave + 4u * d) * kChunk, ring0 + d * kSlot, voff);
 }
 
-// Ring steady state + drain; stream_begin must have been called for the same (tile, wave).
-template <int kPass, class FitLds>
-__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, int wave,
-                                             int lane, const Water &w, const float (&J)[3][4], Acc &acc) {
+// Ring steady state for this wave's levels v0 <= v < v1 (of r); slot / slot_in carry the ring position across calls.
+template <int kPass, bool kMasked, class FitLds>
+__device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, uint32_t v0,
+                                             uint32_t v1, int wave, int lane, const Water &w, const float (&J)[3][4],
+                                             Acc &acc, uint32_t &slot, uint32_t &slot_in) {
     const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
-    uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
-    for (uint32_t v = 0; v < r; ++v) {
+    for (uint32_t v = v0; v < v1; ++v) {
         if (v + kAhead < r)
             dma_chunk(tile_obs + (size_t)(wave + 4u * (v + kAhead)) * kChunk, ring0 + slot_in * kSlot, voff);
         const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
@@ -228,10 +230,24 @@ __device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restr
         const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + kChunkZ) + lane;  // planar R | G | B
         const uint3 c3 = make_uint3(cp[0], cp[64], cp[128]);
-        accumulate_view<kPass>(z4, c3, w, J, acc);
+        accumulate_view<kPass, kMasked>(z4, c3, w, J, acc);
         slot = slot + 1 == kRing ? 0 : slot + 1;
         slot_in = slot_in + 1 == kRing ? 0 : slot_in + 1;
     }
+}
+
+// Ring steady state + drain; stream_begin must have been called for the same (tile, wave).  The levels below
+// nfull (the tile's smallest pixel count) hold 256 real observations each: they run the select-free loop; the
+// few levels above it run the masked one.  Two separate loops on purpose: as one loop with a uniform branch hipcc
+// if-converted both bodies into one (41 selects, 127 VGPRs).
+template <int kPass, class FitLds>
+__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r,
+                                             uint32_t nfull, int wave, int lane, const Water &w,
+                                             const float (&J)[3][4], Acc &acc) {
+    uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
+    const uint32_t rf = min(r, views_of_wave(nfull, wave));
+    stream_range<kPass, false>(lds, tile_obs, r, 0u, rf, wave, lane, w, J, acc, slot, slot_in);
+    stream_range<kPass, true>(lds, tile_obs, r, rf, r, wave, lane, w, J, acc, slot, slot_in);
     wait_chunks<0>();  // nothing of ours is in flight past this point
 }
 static_assert(kAhead == 2 || kAhead == 3, "wait ladder in stream_views covers kAhead 2 and 3");
@@ -361,6 +377,7 @@ template <bool kClosed, bool kFused>
 __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
                                                        const uint64_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ levels,
+                                                       const uint32_t *__restrict__ full,
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
-    const uint32_t n = levels[tile];
+    const uint32_t n = levels[tile], nfull = full[tile];
     const uint8_t *tile_obs = comp + tile_off[tile];
     float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
 
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-        stream_views<kPassClosedJ>(lds, tile_obs, r, wave, lane, w, J, acc);
+        stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
         reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -421,8 +438,8 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
 
     zero_acc(acc);
-    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, wave, lane, w, J, acc);
-    else stream_views<kPassGradJ>(lds, tile_obs, r, wave, lane, w, J, acc);
+    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+    else stream_views<kPassGradJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
     reduce_pixels(lds, acc, wave, lane, t, tot);
 
     // pixel-parallel tail: this thread owns pixel slot t
@@ -493,6 +510,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
 __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ comp,
                                                        const uint64_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ levels,
+                                                       const uint32_t *__restrict__ full,
                                                        const float *__restrict__ params, float *__restrict__ Jt) {
     __shared__ FitLdsT<false> lds;
     const int tile = blockIdx.x;
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(params);
-    const uint32_t r = views_of_wave(levels[tile], wave);
+    const uint32_t r = views_of_wave(levels[tile], wave), nfull = full[tile];
     const uint8_t *tile_obs = comp + tile_off[tile];
     float J[3][4];
 #pragma unroll
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
     Acc acc;
     zero_acc(acc);
     stream_begin(lds, tile_obs, r, wave, lane);
-    stream_views<kPassClosedJ>(lds, tile_obs, r, wave, lane, w, J, acc);
+    stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
     float tot[6];
     reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
@@ -593,6 +611,7 @@ static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co
     hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_full),
                        reinterpret_cast<float *>(ws + L.off_params),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
@@ -635,6 +654,7 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s) {
     hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_full),
                        reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J));
     return hipGetLastError();
 }

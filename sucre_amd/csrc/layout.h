@@ -29,7 +29,8 @@ struct Layout {
     size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
     size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)
     size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
-    size_t off_levels;      // uint32 [n_tiles]            chunks (levels) of every sorted tile
+    size_t off_levels;      // uint32 [n_tiles]            chunks (levels) of every sorted tile (= largest pixel count in it)
+    size_t off_full;        // uint32 [n_tiles]            levels with all 256 slots occupied (= smallest pixel count)
     size_t off_tile_off;    // uint64 [n_tiles]            byte offset of a sorted tile's first chunk in the compact store
     size_t off_total_chunks;// uint64 [1]
     size_t off_view_count;  // uint64 [n_views]
@@ -73,6 +74,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_perm = take(nt * kTilePx * sizeof(uint32_t));
     L->off_invperm = take(nt * kTilePx * sizeof(uint32_t));
     L->off_levels = take(nt * sizeof(uint32_t));
+    L->off_full = take(nt * sizeof(uint32_t));
     L->off_tile_off = take(nt * sizeof(uint64_t));
     L->off_total_chunks = take(sizeof(uint64_t));
     L->off_view_count = take(nv * sizeof(uint64_t));

@@ -46,7 +46,7 @@ def layout(H, W, nv):
         o = (o + b + 255) // 256 * 256
     take('obs', nt * nv * 1792); take('cnt', nt * nv * 2)
     take('comp', nt * nv * 1792); take('pcount', nt * 256 * 2); take('pmask', nt * 256 * ((nv + 63) // 64) * 8); take('blockhist', 256 * nt * 4); take('bin_totals', 512 * 4)
-    take('perm', nt * 256 * 4); take('invperm', nt * 256 * 4); take('levels', nt * 4); take('tile_off', nt * 8); take('total_chunks', 8)
+    take('perm', nt * 256 * 4); take('invperm', nt * 256 * 4); take('levels', nt * 4); take('full', nt * 4); take('tile_off', nt * 8); take('total_chunks', 8)
     take('view_count', nv * 8); take('view_keep', nv * 4); take('n_obs', 8); take('n_obs_total', 8)
     ng = (nt + 31) // 32
     take('params', 27 * 4); take('sums', 12 * 8); take('ticket', (1 + ng) * 16 * 4); take('gpartials', 10 * ng * 8); take('partials', nt * 10 * 4)
@@ -67,6 +67,7 @@ def make_ws():
     obs[:, :1024].view(torch.float32).copy_(2.5 + torch.rand((nt * NV, 256), device=dev, generator=g))
     obs[:, 1024:].copy_(torch.randint(0, 256, (nt * NV, 768), device=dev, generator=g, dtype=torch.uint8))
     ws[offs['levels']:offs['levels'] + nt * 4].view(torch.int32).fill_(NV)
+    ws[offs['full']:offs['full'] + nt * 4].view(torch.int32).fill_(NV)
     ws[offs['tile_off']:offs['tile_off'] + nt * 8].view(torch.int64).copy_(
         torch.arange(nt, device=dev, dtype=torch.int64) * (NV * 1792))
     ident = torch.arange(nt * 256, device=dev, dtype=torch.int32)
