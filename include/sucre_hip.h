@@ -20,10 +20,11 @@
  *     256-byte aligned.  Its internal layout (observation store, Adam state, ...) is private; the few regions a
  *     host needs to read back are located with sucre_ws_offset().
  *
- * Data layout in HBM: the target image is cut into 16x16-pixel tiles.  The observation
- * store holds, for every (tile, view) pair, one 1792-byte chunk = 256 float32 ranges z=||cP|| (0 = no
- * observation) + 256 x 3 uint8 colours, replacing the reference's 28-byte (u,v,cP,I) records
- * (loader.py:33-53, 103-118) and its HDF5 spill.  J and the Adam moments are tile-major float32 planes.
+ * Data layout in HBM: the target image is cut into 16x16-pixel tiles.  Matching writes,
+ * for every (tile, view) pair, one 1792-byte chunk = 256 float32 ranges z=||cP|| (0 = no observation) + 256 x 3
+ * uint8 colours (7 B/observation instead of the reference's 28-byte (u,v,cP,I) records, loader.py:33-53,103-118,
+ * and its HDF5 spill); sucre_finalize_matches then compacts them per pixel, sorted by observation count, into the
+ * store the fit streams.  J and the Adam moments are float32 planes in that sorted pixel order.
  */
 #ifndef SUCRE_HIP_H
 #define SUCRE_HIP_H
@@ -102,8 +103,8 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
                     int32_t *map_dev, void *stream);
 
 /*
- * The `len(matches) / (W*H) > min_cover` rule (sfm.py:136) for every view, n_obs, and the per-tile view lists
- * the fit iterates over.  Call once after all sucre_match_views calls.
+ * The `len(matches) / (W*H) > min_cover` rule (sfm.py:136) for every view, n_obs, and the count-sorted per-pixel
+ * compaction of the kept observations that the fit iterates over.  Call once after all sucre_match_views calls.
  */
 int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream);
 
