@@ -377,99 +377,110 @@ template <bool kClosed, bool kFused>
 __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
                                                        const uint64_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ levels,
-                                                       const uint32_t *__restrict__ full,
+                                                       const uint32_t *__restrict__ full, int n_tiles,
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
                                                        unsigned *ticket, double *gpart, int n_groups, double *sums,
                                                        double *trace_row) {
     __shared__ FitLdsT<kClosed> lds;  // 25.2 KB (6 workgroups/CU) without jbuf, 28.2 KB (5) with it
-    const int tile = blockIdx.x;
-    const int n_tiles = gridDim.x;
+    const int n_blocks = gridDim.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
-    const uint32_t n = levels[tile], nfull = full[tile];
-    const uint8_t *tile_obs = comp + tile_off[tile];
-    float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
 
-    const uint32_t r = views_of_wave(n, wave);
-    float J[3][4];
+    // The workgroup is persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the compact store's tiles are
+    // sorted heaviest first, so this deal is balanced).  The per-thread global sums simply keep accumulating across
+    // its tiles; the shuffle reduction, the sc1 publish and the ticket hand-off -- measured at ~40 us per launch when
+    // done once per tile (bisected with early-return builds) -- happen once per workgroup.
     Acc acc;
-    float tot[6];
-    stream_begin(lds, tile_obs, r, wave, lane);
-    if (kClosed) {
-        // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
-        zero_acc(acc);
+    zero_acc(acc);
+    float sBetaAcc[3] = {0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
+        const uint32_t n = levels[tile], nfull = full[tile];
+        const uint8_t *tile_obs = comp + tile_off[tile];
+        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+        const uint32_t r = views_of_wave(n, wave);
+        float J[3][4];
+        float tot[6];
+        stream_begin(lds, tile_obs, r, wave, lane);
+        if (kClosed) {
+            // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
+            Acc cj;
+            zero_acc(cj);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
+            stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, cj);
+            reduce_pixels(lds, cj, wave, lane, t, tot);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float Jc = tot[c] / tot[3 + c];  // 0/0 = NaN where nothing was observed
+                Jtile[c * kTilePx + t] = Jc;
+                lds.jbuf[c][t] = Jc;
+            }
+            __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
+            stream_begin(lds, tile_obs, r, wave, lane);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
+                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+            }
+        } else {
+            // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count
+            // the asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's
+            // first use; the empty asm makes that first use happen here, where only the prologue (issued at the same
+            // time, hence landing at the same time) is outstanding: one shared start-up latency per tile.
+            float4 jv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
+                J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
+            }
+        }
+
+        // per-pixel sums restart with every tile; the global sums (sB, sGZ, cost) carry on
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-        stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
+        if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+        else stream_views<kPassGradJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
         reduce_pixels(lds, acc, wave, lane, t, tot);
+
+        // pixel-parallel tail: this thread owns pixel slot t
+        if (kClosed) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float Jc = tot[c] / tot[3 + c];  // 0/0 = NaN where nothing was observed
-            Jtile[c * kTilePx + t] = Jc;
-            lds.jbuf[c][t] = Jc;
+            for (int c = 0; c < 3; ++c) {
+                const float Jc = lds.jbuf[c][t];
+                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
+            }
+        } else {
+            float *mtile = mt + (size_t)tile * 3 * kTilePx;
+            float *vtile = vt + (size_t)tile * 3 * kTilePx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
+                // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
+                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
+                adam_update(Jc, m, v, gscale * tot[c], co);
+                Jtile[c * kTilePx + t] = Jc;
+                mtile[c * kTilePx + t] = m;
+                vtile[c * kTilePx + t] = v;
+            }
         }
-        __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
-        stream_begin(lds, tile_obs, r, wave, lane);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
-            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
-        }
-    } else {
-        // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count the
-        // asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's first
-        // use; the empty asm makes that first use happen here, where only the prologue (issued at the same time,
-        // hence landing at the same time) is outstanding: one shared start-up latency, nothing drained later.
-        // (Prefetching the tail's own J / exp_avg / exp_avg_sq here as well was measured: no gain.)
-        float4 jv[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
-            J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
-        }
+        __syncthreads();  // `red` (and jbuf) retired before the next tile's ring prologue overwrites the LDS
     }
 
-    zero_acc(acc);
-    if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-    else stream_views<kPassGradJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-    reduce_pixels(lds, acc, wave, lane, t, tot);
-
-    // pixel-parallel tail: this thread owns pixel slot t
-    float sBeta[3];
-    if (kClosed) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float Jc = lds.jbuf[c][t];
-            sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
-        }
-    } else {
-        const float scale = (1.0f / 3.0f) / (float)(*n_obs_total);  // (loss / n_obs / 3).backward(), sucre.py:145
-        const float gscale = -2.0f * scale;
-        float *mtile = mt + (size_t)tile * 3 * kTilePx;
-        float *vtile = vt + (size_t)tile * 3 * kTilePx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
-            // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
-            sBeta[c] = (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
-            adam_update(Jc, m, v, gscale * tot[c], co);
-            Jtile[c * kTilePx + t] = Jc;
-            mtile[c * kTilePx + t] = m;
-            vtile[c * kTilePx + t] = v;
-        }
-    }
-
-    // ten tile sums: wave shuffle tree, then the four waves in fixed order
+    // ten workgroup sums: wave shuffle tree, then the four waves in fixed order
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
-                         sBeta[0], sBeta[1], sBeta[2], acc.cost};
+                         sBetaAcc[0], sBetaAcc[1], sBetaAcc[2], acc.cost};
 #pragma unroll
     for (int q = 0; q < kNumSums; ++q) {
 #pragma unroll
@@ -480,23 +491,23 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int q = 0; q < kNumSums; ++q) lds.wsum[wave][q] = s[q];
     }
     __syncthreads();
-    // Publish the tile's partials with agent-scope write-through (sc1) stores: they need no release fence
+    // Publish the workgroup's partials with agent-scope write-through (sc1) stores: they need no release fence
     // (a release = L2 write-back in EVERY workgroup measured +260 us per launch; cdna_hip_programming.md section 5,
     // 'In-launch split-K reduction').
     if (t < kNumSums)
-        __hip_atomic_store(partials + (size_t)t * n_tiles + tile,
+        __hip_atomic_store(partials + (size_t)t * n_blocks + blockIdx.x,
                            ((lds.wsum[0][t] + lds.wsum[1][t]) + lds.wsum[2][t]) + lds.wsum[3][t], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 
     if (kFused) {
-        // Two-level last-arriver tail, so an iteration is ONE launch and no counter sees more than 255 arrivals
-        // (one word shared by all 8160 workgroups saturates at ~88 returning atomics/us = ~93 us per launch,
-        // measured).  Hand-off per Guideline 16, sc1 form: payload stored write-through, the storing wave drains
-        // vmcnt, one lane does a relaxed agent-scope fetch_add; the last arriver acquires once.  Nobody spins.
-        const int g = tile / kGroup;
-        const unsigned gsize = (unsigned)(min((g + 1) * kGroup, n_tiles) - g * kGroup);
+        // Two-level last-arriver tail, so an iteration is ONE launch and no counter sees more than 48 arrivals
+        // (one word shared by 8160 arrivals saturated at ~88 returning atomics/us, measured).  Hand-off per
+        // Guideline 16, sc1 form: payload stored write-through, the storing wave drains vmcnt, one lane does a relaxed
+        // agent-scope fetch_add; the last arriver acquires once.  Nobody spins.
+        const int g = blockIdx.x / kGroup;
+        const unsigned gsize = (unsigned)(min((g + 1) * kGroup, n_blocks) - g * kGroup);
         if (arrive_last(ticket + (size_t)(1 + g) * kTicketStride, gsize, &lds.is_last)) {  // workgroup-uniform
-            reduce_group(partials, n_tiles, g, gpart, n_groups);
+            reduce_group(partials, n_blocks, g, gpart, n_groups);
             if (arrive_last(ticket, (unsigned)n_groups, &lds.is_last)) {
                 reduce_total(gpart, n_groups, lds.stot, sums);
                 // every other workgroup has finished (it arrived after its last use of the parameters)
@@ -608,10 +619,10 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
 
 template <bool kClosed, bool kFused>
 static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
+    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_full),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
                        reinterpret_cast<float *>(ws + L.off_params),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
@@ -635,7 +646,7 @@ hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, uns
     if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, nullptr, s);
     else launch_grad_variant<false, false>(L, ws, co, nullptr, s);
     hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.n_groups), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(ws + L.off_partials), L.n_tiles,
+                       reinterpret_cast<const float *>(ws + L.off_partials), L.n_blocks,
                        reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups);
     hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(256), 0, s,
                        reinterpret_cast<const double *>(ws + L.off_gpartials), L.n_groups,

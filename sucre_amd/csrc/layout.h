@@ -14,6 +14,8 @@ constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
 constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)
 constexpr int kTicketStride = 16;    // uint32 words between tickets: every counter on its own 64-byte line
+constexpr int kFitGrid = 1536;       // persistent fit workgroups (6 per CU x 256 CUs); a constant, so the reduction
+                                     // order -- hence every result bit -- does not depend on the device
 constexpr int kMaxViews = 4096;
 
 struct Layout {
@@ -41,8 +43,8 @@ struct Layout {
     size_t off_sums;        // double [kSumsPad]
     size_t off_ticket;      // uint32 [(1 + n_groups) * kTicketStride]  arrival counters: [0] = groups done, [1+g] = tiles of group g done
     size_t off_gpartials;   // double [kNumSums][n_groups]  per-group sums
-    int n_groups;
-    size_t off_partials;    // float  [n_tiles][kNumSums]
+    int n_blocks, n_groups; // fit grid (min(n_tiles, kFitGrid)) and its 32-workgroup reduction groups
+    size_t off_partials;    // float  [kNumSums][n_blocks]  one partial per fit workgroup
     size_t off_J, off_m, off_v;  // float [n_tiles][3][256]
     size_t total;
 };
@@ -83,7 +85,8 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_n_obs_total = take(sizeof(uint64_t));
     L->off_params = take(27 * sizeof(float));
     L->off_sums = take(kSumsPad * sizeof(double));
-    L->n_groups = (L->n_tiles + kGroup - 1) / kGroup;
+    L->n_blocks = L->n_tiles < kFitGrid ? L->n_tiles : kFitGrid;
+    L->n_groups = (L->n_blocks + kGroup - 1) / kGroup;
     L->off_ticket = take((size_t)(1 + L->n_groups) * kTicketStride * sizeof(uint32_t));
     L->off_gpartials = take((size_t)kNumSums * L->n_groups * sizeof(double));
     L->off_partials = take(nt * kNumSums * sizeof(float));

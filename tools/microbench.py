@@ -48,7 +48,7 @@ def layout(H, W, nv):
     take('comp', nt * nv * 1792); take('pcount', nt * 256 * 2); take('pmask', nt * 256 * ((nv + 63) // 64) * 8); take('blockhist', 256 * nt * 4); take('bin_totals', 512 * 4)
     take('perm', nt * 256 * 4); take('invperm', nt * 256 * 4); take('levels', nt * 4); take('full', nt * 4); take('tile_off', nt * 8); take('total_chunks', 8)
     take('view_count', nv * 8); take('view_keep', nv * 4); take('n_obs', 8); take('n_obs_total', 8)
-    ng = (nt + 31) // 32
+    ng = (min(nt, 1536) + 31) // 32
     take('params', 27 * 4); take('sums', 12 * 8); take('ticket', (1 + ng) * 16 * 4); take('gpartials', 10 * ng * 8); take('partials', nt * 10 * 4)
     take('J', nt * 768 * 4); take('m', nt * 768 * 4); take('v', nt * 768 * 4)
     return nt, offs, o
