@@ -236,3 +236,48 @@ def test_split_grad_step_path_equals_fused(golden):
         torch.cuda.synchronize()
         assert np.array_equal(trace.cpu().numpy(), t1)
         assert np.array_equal(r.J().cpu().numpy(), J1, equal_nan=True)
+
+
+@pytest.mark.timeout(600)
+def test_config5_shape_properties():
+    """BASELINE config 5 shape (3840x2160, 256 neighbours + self = 257 views; 7 B/obs store): more than 255 views
+    (quantised counting-sort bins, 5 mask words per pixel), ~30 GB workspace, 64-bit offsets."""
+    from sucre_amd import engine, synth
+    W, H, NN = 3840, 2160, 256
+    scene = synth.make_scene(W, H, NN, seed=2, device='cuda', spacing=0.05)
+    views = engine.device_views_from_scene(scene, 'cuda')
+    tgt = views[scene.target]
+    r = engine.Restoration(H, W, len(views))
+    r.match(tgt, views)
+    counts = r.view_counts().cpu().numpy()
+    keep = r.view_keep().cpu().numpy().astype(bool)
+    valid1 = tgt.depth > 0
+    assert len(views) == 257 and counts[scene.target] == int(valid1.sum())
+    assert r.n_obs() == int(counts[keep].sum()) and r.n_obs() > 5e8
+    for k in (0, 100, 256):
+        z, _ = r.export_view(k)
+        assert int((z > 0).sum()) == counts[k] and not bool(((z > 0) & ~valid1).any())
+        assert torch.equal(r.match_map(k) >= 0, z > 0)
+    r.fit_init(tgt)
+    t1 = r.fit(4)
+    J = r.J()
+    assert torch.equal(torch.isnan(J).any(dim=2), ~valid1)
+    cost = t1[:, 0].cpu().numpy()
+    assert np.all(np.isfinite(cost)) and cost[-1] < cost[0]
+    # one iteration of the same state against a float64 torch evaluation of the cost on a sample of views
+    r.fit_init(tgt)
+    t2 = r.fit(4)
+    assert torch.equal(t1, t2) and torch.equal(torch.nan_to_num(J), torch.nan_to_num(r.J()))
+    # cost of iteration 0 = sum over all observations of (I - (J0 a + B(1-g)))^2 with B=beta=gamma=0.1
+    J0 = (tgt.rgb.double() / 255)
+    total = 0.0
+    for k in range(len(views)):
+        if not keep[k]:
+            continue
+        z, rgb = r.export_view(k)
+        m = z > 0
+        zz = z[m].double()[:, None]
+        a = torch.exp(-0.1 * zz)
+        res = rgb[m].double() / 255 - (J0[m] * a + 0.1 * (1 - a))
+        total += float((res * res).sum())
+    assert abs(cost[0] / total - 1) < 1e-5
