@@ -103,6 +103,16 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
                     int32_t *map_dev, void *stream);
 
 /*
+ * Alternative to sucre_match_views for one view: loads an explicit match list -- one group of a matches file
+ * written by the reference (loader.py:68-76: u1, v1 int16; the ranges z = ||K2^-1 d [u2+.5, v2+.5, 1]|| of
+ * loader.py:113 + sucre.py:53 and the colours I*255 as uint8, n x 3) -- into view k of the observation store,
+ * replacing whatever the view held.  This is how a kept matches file (--keep-matches, sucre.py:185) is consumed
+ * without re-matching.  Follow with sucre_finalize_matches as usual.
+ */
+int sucre_import_view(void *ws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
+                      const float *z_dev, const uint8_t *rgb_dev, int64_t n, void *stream);
+
+/*
  * The `len(matches) / (W*H) > min_cover` rule (sfm.py:136) for every view, n_obs, and the count-sorted per-pixel
  * compaction of the kept observations that the fit iterates over.  Call once after all sucre_match_views calls.
  */

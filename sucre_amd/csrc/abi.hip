@@ -113,6 +113,17 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
     return check_hip(launch_match_map(L, *target, views_dev, k, map_dev, static_cast<hipStream_t>(stream)), "sucre_match_map");
 }
 
+int sucre_import_view(void *ws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
+                      const float *z_dev, const uint8_t *rgb_dev, int64_t n, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
+    if (n < 0) return fail(SUCRE_ERR_RANGE, "negative observation count %lld", (long long)n);
+    if (n > 0 && (!u1_dev || !v1_dev || !z_dev || !rgb_dev)) return fail(SUCRE_ERR_ARG, "NULL match list");
+    return check_hip(launch_import_view(L, static_cast<uint8_t *>(ws), k, u1_dev, v1_dev, z_dev, rgb_dev, (long long)n,
+                                        static_cast<hipStream_t>(stream)), "sucre_import_view");
+}
+
 int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;

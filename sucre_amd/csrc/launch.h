@@ -30,6 +30,8 @@ hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target
                         int k0, int k1, hipStream_t s);
 hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
                             int32_t *map, hipStream_t s);
+hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
+                              const uint8_t *rgb, long long n, hipStream_t s);
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s);
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s);
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);

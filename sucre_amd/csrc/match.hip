@@ -224,6 +224,57 @@ __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restr
     }
 }
 
+// ---- import of an explicit match list (e.g. one group of a matches file written by the reference, loader.py:68-76)
+// into the dense store: clear view k, scatter the observations, recount the tiles.
+__global__ __launch_bounds__(256) void clear_view_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
+                                                         int n_views, int k, size_t tile_stride, size_t view_stride) {
+    const int tile = blockIdx.x;
+    reinterpret_cast<float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0) cnt[(size_t)tile * n_views + k] = 0;
+}
+
+__global__ __launch_bounds__(256) void import_view_kernel(uint8_t *__restrict__ obs, int k, int tiles_x, int H, int W,
+                                                          size_t tile_stride, size_t view_stride,
+                                                          const int16_t *__restrict__ u1, const int16_t *__restrict__ v1,
+                                                          const float *__restrict__ z, const uint8_t *__restrict__ rgb,
+                                                          long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int u = u1[i], v = v1[i];
+    if (u < 0 || v < 0 || u >= W || v >= H) return;  // check_integrity (loader.py:96-98) rejects these upstream
+    const int tile = (v / kTile) * tiles_x + (u / kTile);
+    const int slot = (v % kTile) * kTile + (u % kTile);
+    uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
+    reinterpret_cast<float *>(chunk)[slot] = z[i];
+    chunk[kChunkZ + slot] = rgb[i * 3 + 0];
+    chunk[kChunkZ + kTilePx + slot] = rgb[i * 3 + 1];
+    chunk[kChunkZ + 2 * kTilePx + slot] = rgb[i * 3 + 2];
+}
+
+__global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
+                                                         int n_views, int k, size_t tile_stride, size_t view_stride) {
+    __shared__ int part[4];
+    const int tile = blockIdx.x;
+    const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[threadIdx.x];
+    const int c = __builtin_popcountll(__ballot(z > 0.0f));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
+}
+
+hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
+                              const uint8_t *rgb, long long n, hipStream_t s) {
+    auto *cnt = reinterpret_cast<uint16_t *>(ws + L.off_cnt);
+    hipLaunchKernelGGL(clear_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
+                       L.obs_tile_stride, L.obs_view_stride);
+    if (n > 0)
+        hipLaunchKernelGGL(import_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws + L.off_obs, k,
+                           L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n);
+    hipLaunchKernelGGL(count_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
+                       L.obs_tile_stride, L.obs_view_stride);
+    return hipGetLastError();
+}
+
 static CamDev to_cam(const sucre_view_t &v) {
     CamDev c;
     for (int i = 0; i < 9; ++i) { c.K[i] = v.K[i]; c.Kinv[i] = v.Kinv[i]; c.R[i] = v.R[i]; c.Rinv[i] = v.Rinv[i]; }

@@ -94,6 +94,25 @@ class Restoration:
                                                   0, n, _stream_ptr()))
             _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
 
+    def import_matches(self, target: DeviceView, lists: list, min_cover: float = -1.0) -> None:
+        """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
+        (int16[n], int16[n], float32[n], uint8[n,3]) -- what one group of a reference matches file provides after
+        ``cP = unproject_depth(u2, v2, d)`` and ``z = ||cP||`` (loader.py:103-118, sucre.py:53)."""
+        assert len(lists) == self.n_views
+        self._keepalive = [target, lists]
+        self._views_dev = None
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            for k, (u1, v1, z, rgb) in enumerate(lists):
+                u1 = u1.to(self.device, torch.int16).contiguous(); v1 = v1.to(self.device, torch.int16).contiguous()
+                z = z.to(self.device, torch.float32).contiguous(); rgb = rgb.to(self.device, torch.uint8).contiguous()
+                assert rgb.shape == (u1.numel(), 3) and z.numel() == u1.numel() == v1.numel()
+                self._keepalive.append((u1, v1, z, rgb))
+                _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
+                                                      C.c_void_p(z.data_ptr()), C.c_void_p(rgb.data_ptr()),
+                                                      u1.numel(), _stream_ptr()))
+            _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
+
     def match_map(self, k: int) -> torch.Tensor:
         """(H,W) int32: linear pixel index v2*W2+u2 in view k matched to every target pixel, -1 = none
         (dense form of sfm.Matches).  ``match`` must have been called (it uploads the view table)."""

@@ -20,6 +20,8 @@ import torch
 from torch import Tensor
 from torch.utils.data import DataLoader, Dataset
 
+from . import h5bridge
+
 MatchesSample = namedtuple('MatchesSample', ['u', 'v', 'cP', 'I'])
 
 
@@ -262,17 +264,36 @@ class MatchesFile:
             groups[im.name] = dict(u1=u1.short().cpu().numpy(), v1=v1.short().cpu().numpy(),
                                    u2=u2.short().cpu().numpy(), v2=v2.short().cpu().numpy(),
                                    d=view.depth[v2, u2].cpu().numpy(), I=I.cpu().numpy())
-        try:
-            import h5py
-            with h5py.File(self.path, 'w', libver='latest') as f:
-                for name, ds in groups.items():
-                    g = f.create_group(name)
-                    for key, val in ds.items():
-                        g.create_dataset(key, data=val)
-            return self.path
-        except ImportError:
-            np.savez(self._npz_path, **{f'{name}/{key}': val for name, ds in groups.items() for key, val in ds.items()})
-            return self._npz_path
+        if h5bridge.available():
+            return h5bridge.write_groups(self.path, groups)
+        np.savez(self._npz_path, **{f'{name}/{key}': val for name, ds in groups.items() for key, val in ds.items()})
+        return self._npz_path
+
+    def on_disk(self) -> bool:
+        """True when a matches file written earlier (by this engine or by the reference) can be loaded."""
+        return self.path.exists() and h5bridge.available()
+
+    def load_file(self, target_image, device='cuda') -> None:
+        """Consumes an existing HDF5 matches file instead of matching (what the reference does when the file is
+        already there, sucre.py:185): every group becomes one view of the engine's store.  cP / z are rebuilt like
+        loader.py:113 + sucre.py:53 (float32, same operation order as the match kernel)."""
+        from . import engine
+        groups = h5bridge.read_groups(self.path)
+        images, lists = [], []
+        for name, ds in groups.items():
+            im = self.colmap_model[name]
+            for key in h5bridge.DATASETS:
+                arr = ds[key]
+                assert not np.isnan(arr).any(), f'In {self.path}, dataset /{name}/{key} contains NaN(s).'
+            u2, v2 = torch.tensor(ds['u2']), torch.tensor(ds['v2'])
+            cP = im.unproject_depth(u=u2, v=v2, d=torch.tensor(ds['d']))
+            z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
+            rgb = torch.tensor(np.rint(ds['I'].astype(np.float64) * 255).astype(np.uint8).T.copy())
+            images.append(im)
+            lists.append((torch.tensor(ds['u1']), torch.tensor(ds['v1']), z, rgb))
+        resto = engine.acquire_restoration(target_image.camera.height, target_image.camera.width, len(lists), device)
+        resto.import_matches(target_image.device_view(device), lists)
+        self.attach(resto, target_image=target_image, image_list=images)
 
     def __len__(self) -> int:
         return self.restoration.n_obs() if self.restoration is not None else 0

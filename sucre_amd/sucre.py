@@ -175,12 +175,14 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
     if image_list is None:
         image_list = list(colmap_model.images.values())
 
-    # matching costs ~1.5 ms on the GPU, so it is always recomputed; a kept matches file is only an export
-    print(f'Compute {image.name} matches.')
-    image.match_images(image_list=image_list, matches_file=matches_file, min_cover=min_cover,
-                       num_workers=num_workers, device=device)
-    print('Prepare matches for optimization.')
-    matches_file.prepare_matches(num_workers=num_workers)
+    if force_compute_matches or not matches_file.on_disk():
+        print(f'Compute {image.name} matches.')
+        image.match_images(image_list=image_list, matches_file=matches_file, min_cover=min_cover,
+                           num_workers=num_workers, device=device)
+        print('Prepare matches for optimization.')
+        matches_file.prepare_matches(num_workers=num_workers)
+    else:  # a kept matches file (ours or the reference's): consumed as is, like sucre.py:185
+        matches_file.load_file(image, device=device)
     print('Check matches integrity.')
     matches_file.check_integrity()
     print('Load matches.')
@@ -199,7 +201,11 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
     sucre.save_plots(save_dir=output_dir)
     torch.save({**sucre.cpu().state_dict(), 'J': sucre.J.detach().cpu()}, (output_dir / image.name).with_suffix('.pt'))
     if keep_matches:
-        print(f'Keep {matches_file.save()}.')
+        if matches_file.restoration._views_dev is not None:   # freshly matched (not loaded from this very file)
+            print(f'Keep {matches_file.save()}.')
+    elif matches_path.exists():
+        print(f'Erase {matches_path}.')
+        matches_path.unlink()
     return sucre
 
 

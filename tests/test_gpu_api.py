@@ -68,16 +68,30 @@ def test_cli_end_to_end(disk_scene, tmp_path, capsys):
     assert helpers.rms_per_channel(J, Jo).max() < 1e-5
     got = np.concatenate([state['B'].numpy().ravel(), state['beta'].numpy().ravel(), state['gamma'].numpy().ravel()])
     assert np.abs(got - po).max() < 1e-5
-    # kept matches: the reference's dataset names, the oracle's match lists
-    kept = np.load(tmp_path / f'{stem}.npz') if (tmp_path / f'{stem}.npz').exists() else None
-    if kept is not None:
-        per_view, _ = helpers.oracle_scene_samples(loaded)
-        for vname, keep, m in per_view:
-            if not keep:
-                assert f'{vname}/u1' not in kept
-                continue
-            for key in ('u1', 'v1', 'u2', 'v2', 'd'):
-                assert np.array_equal(kept[f'{vname}/{key}'], getattr(m, key)), (vname, key)
+    # kept matches: a real HDF5 file in the reference's layout holding the oracle's match lists
+    from sucre_amd import h5bridge
+    assert h5bridge.available() and (tmp_path / f'{stem}.h5').exists()
+    kept = h5bridge.read_groups(tmp_path / f'{stem}.h5')
+    per_view, samples = helpers.oracle_scene_samples(loaded)
+    assert list(kept) == sorted(n for n, k, _ in per_view if k)
+    for (vname, keep, m), view in zip(per_view, loaded.views):
+        if not keep:
+            continue
+        g = kept[vname]
+        for key in ('u1', 'v1', 'u2', 'v2', 'd'):
+            assert g[key].dtype == getattr(m, key).dtype and np.array_equal(g[key], getattr(m, key)), (vname, key)
+        assert g['I'].dtype == np.float32 and np.array_equal(g['I'], oracle.gather_rgb(view.rgb_u8.numpy(), m.u2, m.v2))
+    # second run: the kept file is consumed instead of matching (sucre.py:185) and gives the same restoration
+    out2 = tmp_path / 'again'
+    import shutil
+    out2.mkdir(); shutil.copy(tmp_path / f'{stem}.h5', out2 / f'{stem}.h5')
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(out2), '--image-name', name, '--num-iter', '30', '--keep-matches'])
+    txt = capsys.readouterr().out
+    assert 'Compute' not in txt and 'Total of' in txt
+    state2 = torch.load(out2 / f'{stem}.pt')
+    assert helpers.rms_per_channel(state2['J'].numpy(), J).max() < 1e-6
+    assert torch.allclose(state2['B'], state['B'], atol=1e-6) and (out2 / f'{stem}.h5').exists()
 
 
 def test_match_two_way_and_matches_data_compat(disk_scene):

@@ -237,3 +237,25 @@ def test_output_stage_matches_reference_images(golden):
     rec = np.asarray(model.plot_reconstruction()).astype(np.int16)
     ref = golden['plot_reconstruction_200'].astype(np.int16)
     assert np.abs(rec - ref).max() <= 1 and (rec != ref).mean() < 1e-3   # float32 exp ordering may flip a rounding
+
+
+def test_h5_bridge_writes_the_reference_layout(tmp_path):
+    """loader.py:68-76: one group per neighbour; u1,v1,u2,v2 int16, d float32, I float32 (3,n); groups iterate
+    in name order.  Verified by reading the file back with h5py itself (in-process or under the helper python)."""
+    from sucre_amd import h5bridge
+    if not h5bridge.available():
+        pytest.skip('no h5py in this environment')
+    rng = np.random.default_rng(0)
+    groups = {}
+    for name, n in (('img_0002.png', 7), ('img_0000.png', 0), ('img_0001.png', 3)):
+        groups[name] = dict(u1=rng.integers(0, 64, n).astype(np.int16), v1=rng.integers(0, 48, n).astype(np.int16),
+                            u2=rng.integers(0, 64, n).astype(np.int16), v2=rng.integers(0, 48, n).astype(np.int16),
+                            d=rng.random(n).astype(np.float32) + 1, I=rng.random((3, n)).astype(np.float32))
+    path = h5bridge.write_groups(tmp_path / 'm.h5', groups)
+    assert path.read_bytes()[:8] == b'\\x89HDF\\r\\n\\x1a\\n'            # a real HDF5 container
+    back = h5bridge.read_groups(path)
+    assert list(back) == sorted(groups)
+    for name, ds in groups.items():
+        assert set(back[name]) == set(h5bridge.DATASETS)
+        for k, v in ds.items():
+            assert back[name][k].dtype == v.dtype and back[name][k].shape == v.shape and np.array_equal(back[name][k], v)
