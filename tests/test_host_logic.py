@@ -252,7 +252,7 @@ def test_h5_bridge_writes_the_reference_layout(tmp_path):
                             u2=rng.integers(0, 64, n).astype(np.int16), v2=rng.integers(0, 48, n).astype(np.int16),
                             d=rng.random(n).astype(np.float32) + 1, I=rng.random((3, n)).astype(np.float32))
     path = h5bridge.write_groups(tmp_path / 'm.h5', groups)
-    assert path.read_bytes()[:8] == b'\\x89HDF\\r\\n\\x1a\\n'            # a real HDF5 container
+    assert path.read_bytes()[:8] == b'\x89HDF\r\n\x1a\n'            # a real HDF5 container
     back = h5bridge.read_groups(path)
     assert list(back) == sorted(groups)
     for name, ds in groups.items():
