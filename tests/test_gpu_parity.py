@@ -281,3 +281,57 @@ def test_config5_shape_properties():
         res = rgb[m].double() / 255 - (J0[m] * a + 0.1 * (1 - a))
         total += float((res * res).sum())
     assert abs(cost[0] / total - 1) < 1e-5
+
+
+def _oracle_vs_engine_matches(target_view, target_K, tH, tW, others):
+    """others: list of (SynthView-like, K, H, W).  Compares engine counts / maps with the oracle per view."""
+    from sucre_amd import engine
+    dev = 'cuda'
+    def dv(v, K, H, W):
+        return engine.DeviceView(depth=v.depth_f32().to(dev).contiguous(), rgb=v.rgb_u8.to(dev).contiguous(), K=K, R=v.R, t=v.t)
+    tgt = dv(target_view, target_K, tH, tW)
+    views = [dv(v, K, H, W) for v, K, H, W in others]
+    r = engine.Restoration(tH, tW, len(views))
+    r.match(tgt, views)
+    cam1 = oracle.make_cam(tH, tW, **helpers.cam_matrices(target_K, target_view.R, target_view.t))
+    out = []
+    for k, (v, K, H, W) in enumerate(others):
+        cam2 = oracle.make_cam(H, W, **helpers.cam_matrices(K, v.R, v.t))
+        m = oracle.match_view(target_view.depth_f32().numpy(), cam1, v.depth_f32().numpy(), cam2)
+        ref = np.full((tH, tW), -1, np.int32)
+        ref[m.v1.astype(np.int64), m.u1.astype(np.int64)] = m.v2.astype(np.int32) * W + m.u2.astype(np.int32)
+        assert np.array_equal(r.match_map(k).cpu().numpy(), ref), k
+        out.append(len(m))
+    assert r.view_counts().cpu().numpy().tolist() == out
+    return r, out
+
+
+def test_views_with_other_camera_sizes_and_cameras_looking_away():
+    """Neighbours may come from other cameras (other W, H, K: match_one_way uses other.camera, sfm.py:117), and the
+    reference has no in-front-of-camera test: whatever torch does for points behind a camera,
+    the engine must do too."""
+    from sucre_amd import synth
+    a = synth.make_scene(96, 64, 3, seed=31)
+    b = synth.make_scene(128, 80, 3, seed=31)          # same poses (same seed), larger sensor & focal length
+    tgt = a.views[a.target]
+    flipped = synth.SynthView(name='flip.png', R=(tgt.R @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))).contiguous(), t=tgt.t,
+                              depth_u16=tgt.depth_u16, rgb_u8=tgt.rgb_u8)   # looks up, away from the seabed
+    others = [(v, a.K, 64, 96) for v in a.views] + [(v, b.K, 80, 128) for v in b.views] + [(flipped, a.K, 64, 96)]
+    r, counts = _oracle_vs_engine_matches(tgt, a.K, 64, 96, others)
+    assert counts[a.target] > 0 and sum(counts[len(a.views):-1]) > 0
+
+
+def test_min_cover_is_a_strict_inequality(golden):
+    """sfm.py:136: len(matches) / (W*H) > min_cover; a view sitting exactly on the threshold is dropped."""
+    from sucre_amd import engine
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    n = golden['n_matches']
+    k = int(np.argsort(n)[len(n) // 2])
+    thr = int(n[k]) / (sc.width * sc.height)
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views, min_cover=thr)
+    keep = r.view_keep().cpu().numpy().astype(bool)
+    assert keep.tolist() == [int(x) / (sc.width * sc.height) > thr for x in n] and not keep[k]
+    r.match(views[sc.target], views, min_cover=np.nextafter(thr, 0.0))
+    assert bool(r.view_keep().cpu().numpy()[k])
