@@ -199,3 +199,30 @@ def shared_step(pstate: np.ndarray, sums: np.ndarray, step: int, n_obs_total: in
     lib().oracle_shared_step.restype = None
     lib().oracle_shared_step(_p(pstate, C.c_float), _p(sums, C.c_double), C.c_int(step), C.c_double(lr),
                              C.c_int64(n_obs_total))
+
+
+def se3_exp(xi) -> tuple[np.ndarray, np.ndarray]:
+    """se3.exp (se3.py:22-27)."""
+    xi = np.ascontiguousarray(xi, np.float32)
+    R, t = np.zeros(9, np.float32), np.zeros(3, np.float32)
+    lib().oracle_se3_exp(_p(xi, C.c_float), _p(R, C.c_float), _p(t, C.c_float))
+    return R.reshape(3, 3), t.reshape(3, 1)
+
+
+def fit_light(H: int, W: int, samples, J0: np.ndarray, params0=None, num_iter: int = 200, lr: float = 0.05):
+    """sucre.adam with light_model=True (sucre.py:54-61, 124-157).  params: B, beta, gamma, cam2light[6], sigma[4].
+    Returns (J, params (19,), trace (num_iter, 20))."""
+    s = _Samples(samples)
+    J = np.ascontiguousarray(J0, np.float32).copy()
+    if params0 is None:
+        params = np.concatenate([np.full(9, 0.1), np.zeros(6), [1, 0, 0, 1]]).astype(np.float32)
+    else:
+        params = np.ascontiguousarray(params0, np.float32).copy()
+    trace = np.zeros((num_iter, 20), np.float64)
+    lib().oracle_fit_light.restype = C.c_int
+    rc = lib().oracle_fit_light(C.c_int(H), C.c_int(W), C.c_int(s.n), _p(s.counts, C.c_int64), s.us, s.vs, s.cPs, s.Is,
+                                _p(J, C.c_float), _p(params, C.c_float), C.c_int(num_iter), C.c_double(lr),
+                                _p(trace, C.c_double))
+    if rc != 0:
+        raise MemoryError('oracle_fit_light')
+    return J, params, trace

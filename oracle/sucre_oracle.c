@@ -365,3 +365,196 @@ void oracle_shared_step(float *pstate, const double *sums, int step, double lr, 
     for (int k = 0; k < 9; ++k)
         adam_step(&pstate[k], &pstate[9 + k], &pstate[18 + k], (float)(sums[k] * (double)scale), &co);
 }
+
+/* =====================================================================================================================
+ * Artificial-light model (--light-model; sucre.py:54-61 with se3.exp, se3.py:22-27).  TEST INFRASTRUCTURE ONLY.
+ *
+ *   R, t = se3.exp(cam2light);  Sigma = sigma^T sigma;  lP = R cP + t;  lp = lP.xy / lP.z
+ *   l = exp(-(lp^T Sigma^-1 lp) / 2);   z = ||cP|| + ||lP||;   Ihat = l (J a + B (1 - g))
+ *
+ * The reference differentiates this with autograd; the oracle uses the analytic gradient:
+ *   E = J a + B(1-g),  dI = dL/dIhat = -2 r s,   dl = sum_c dI E,   dz = sum_c dI l (-beta J a + gamma B g)
+ *   dlP = dz lP/||lP|| + (dlp/dlP)^T (dl * (-l M lp)),  M = Sigma^-1;   dt = sum dlP;   dR = sum dlP cP^T
+ *   dM = sum dl (-l/2) lp lp^T;   dSigma = -M^T dM M^T;   dsigma = sigma (dSigma + dSigma^T)
+ *   dxi_i = <[dR dt; 0 0], D exp(hat(xi))[G_i]>   (directional derivative via the 8x8 block exponential)
+ * Parameter vector (19): B[3], beta[3], gamma[3], cam2light[6], sigma[4] (row-major 2x2).
+ * ===================================================================================================================*/
+
+static void mat_mul(const double *A, const double *B, double *C, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * n + j];
+            C[i * n + j] = s;
+        }
+}
+
+/* exp(A) for a small n x n matrix (n <= 8): scaling and squaring with a degree-18 Taylor series, float64 */
+static void mat_exp(const double *A, double *E, int n) {
+    double nrm = 0.0, S[64], T[64], P[64];
+    for (int i = 0; i < n * n; ++i) nrm = fmax(nrm, fabs(A[i]));
+    int sq = 0;
+    while (nrm > 0.25) { nrm *= 0.5; ++sq; }
+    const double sc = ldexp(1.0, -sq);
+    for (int i = 0; i < n * n; ++i) S[i] = A[i] * sc;
+    for (int i = 0; i < n * n; ++i) { E[i] = (i % (n + 1) == 0) ? 1.0 : 0.0; T[i] = E[i]; }
+    for (int k = 1; k <= 18; ++k) {
+        mat_mul(T, S, P, n);
+        for (int i = 0; i < n * n; ++i) { T[i] = P[i] / k; E[i] += T[i]; }
+    }
+    for (int s = 0; s < sq; ++s) { mat_mul(E, E, P, n); memcpy(E, P, sizeof(double) * n * n); }
+}
+
+static void se3_hat(const double xi[6], double A[16]) {
+    const double w1 = xi[0], w2 = xi[1], w3 = xi[2];
+    const double M[16] = {0, -w3, w2, xi[3], w3, 0, -w1, xi[4], -w2, w1, 0, xi[5], 0, 0, 0, 0};
+    memcpy(A, M, sizeof(M));
+}
+
+/* se3.exp (se3.py:22-27): twist -> R (row-major 3x3), t */
+void oracle_se3_exp(const float *xi, float *R, float *t) {
+    double x[6], A[16], E[16];
+    for (int i = 0; i < 6; ++i) x[i] = xi[i];
+    se3_hat(x, A);
+    mat_exp(A, E, 4);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = (float)E[i * 4 + j]; t[i] = (float)E[i * 4 + 3]; }
+}
+
+/* dxi[i] = sum_jk dT[j][k] * (D exp(hat(xi))[G_i])[j][k], dT = [dR dt; 0 0] */
+static void se3_exp_backward(const double xi[6], const double dR[9], const double dt[3], double dxi[6]) {
+    double A[16];
+    se3_hat(xi, A);
+    for (int i = 0; i < 6; ++i) {
+        double e[6] = {0, 0, 0, 0, 0, 0}, G[16], BM[64], EX[64];
+        e[i] = 1.0;
+        se3_hat(e, G);
+        memset(BM, 0, sizeof(BM));
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                BM[r * 8 + c] = A[r * 4 + c];
+                BM[(r + 4) * 8 + c + 4] = A[r * 4 + c];
+                BM[r * 8 + c + 4] = G[r * 4 + c];
+            }
+        mat_exp(BM, EX, 8);  /* upper-right 4x4 block = directional derivative */
+        double s = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) s += dR[r * 3 + c] * EX[r * 8 + c + 4];
+            s += dt[r] * EX[r * 8 + 7];
+        }
+        dxi[i] = s;
+    }
+}
+
+typedef struct { float R[9], t[3], M[4]; } light_t;
+
+static void light_setup(const float *p, light_t *L) {
+    oracle_se3_exp(p + 9, L->R, L->t);
+    const float *sg = p + 15;  /* sigma row-major: [s00 s01; s10 s11]; Sigma = sigma^T sigma */
+    const float S00 = sg[0] * sg[0] + sg[2] * sg[2], S01 = sg[0] * sg[1] + sg[2] * sg[3];
+    const float S10 = S01, S11 = sg[1] * sg[1] + sg[3] * sg[3];
+    const float det = S00 * S11 - S01 * S10;
+    L->M[0] = S11 / det; L->M[1] = -S01 / det; L->M[2] = -S10 / det; L->M[3] = S00 / det;
+}
+
+/* l and total range of one observation (sucre.py:52-64); also returns lP, lp, ||lP|| for the gradient */
+static inline void light_eval(const light_t *L, const float cP[3], float *l, float *z, float lP[3], float lp[2], float *nl) {
+    rigid(L->R, L->t, cP, lP);
+    lp[0] = lP[0] / lP[2];
+    lp[1] = lP[1] / lP[2];
+    const float q = lp[0] * (L->M[0] * lp[0] + L->M[1] * lp[1]) + lp[1] * (L->M[2] * lp[0] + L->M[3] * lp[1]);
+    *l = expf(-q / 2.0f);
+    *nl = sqrtf(lP[0] * lP[0] + lP[1] * lP[1] + lP[2] * lP[2]);
+    *z = sqrtf(cP[0] * cP[0] + cP[1] * cP[1] + cP[2] * cP[2]) + *nl;
+}
+
+/*
+ * sucre.adam with light_model=True, J as parameter (sucre.py:124-157).  params: 19 floats in/out.
+ * trace: num_iter x 20 doubles (cost, 19 parameters after the step).
+ */
+int oracle_fit_light(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                     const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
+                     float *params, int num_iter, double lr, double *trace) {
+    const size_t npx = (size_t)H * W * 3;
+    int64_t n_obs = 0;
+    for (int s = 0; s < n_samples; ++s) n_obs += counts[s];
+    float *gJ = (float *)calloc(npx, sizeof(float));
+    float *mJ = (float *)calloc(npx, sizeof(float)), *vJ = (float *)calloc(npx, sizeof(float));
+    if (!gJ || !mJ || !vJ) return -1;
+    float mP[19] = {0}, vP[19] = {0};
+    const float scale = (1.0f / 3.0f) / (float)n_obs;
+    float *B = params, *beta = params + 3, *gamma = params + 6;
+    for (int it = 0; it < num_iter; ++it) {
+        light_t L;
+        light_setup(params, &L);
+        memset(gJ, 0, sizeof(float) * npx);
+        double g[19] = {0}, dR[9] = {0}, dt[3] = {0}, dM[4] = {0}, cost = 0.0;
+        for (int s = 0; s < n_samples; ++s) {
+            const int64_t n = counts[s];
+            for (int64_t i = 0; i < n; ++i) {
+                const float cP[3] = {cPs[s][i], cPs[s][n + i], cPs[s][2 * n + i]};
+                float l, z, lP[3], lp[2], nl;
+                light_eval(&L, cP, &l, &z, lP, lp, &nl);
+                const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
+                double dl = 0.0, dz = 0.0;
+                for (int c = 0; c < 3; ++c) {
+                    const float a = expf(-beta[c] * z), gg = expf(-gamma[c] * z);
+                    const float Jc = J[px + c];
+                    const float E = Jc * a + B[c] * (1.0f - gg);
+                    const float r = Is[s][c * n + i] - l * E;
+                    const float dI = -2.0f * r * scale;
+                    cost += (double)r * (double)r;
+                    gJ[px + c] += dI * l * a;
+                    g[c] += (double)(dI * l * (1.0f - gg));
+                    g[3 + c] += (double)(dI * l * Jc * a * -z);
+                    g[6 + c] += (double)(dI * l * B[c] * gg * z);
+                    dl += (double)dI * (double)E;
+                    dz += (double)dI * (double)l * ((double)(-beta[c] * Jc * a) + (double)(gamma[c] * B[c] * gg));
+                }
+                /* through l = exp(-lp^T M lp / 2) and z = ... + ||lP|| */
+                const double Mlp0 = (double)L.M[0] * lp[0] + (double)L.M[1] * lp[1];
+                const double Mtlp0 = (double)L.M[0] * lp[0] + (double)L.M[2] * lp[1];   /* (M + M^T) lp / 2 halves */
+                const double Mlp1 = (double)L.M[2] * lp[0] + (double)L.M[3] * lp[1];
+                const double Mtlp1 = (double)L.M[1] * lp[0] + (double)L.M[3] * lp[1];
+                const double dlp0 = dl * (-(double)l / 2.0) * (Mlp0 + Mtlp0);
+                const double dlp1 = dl * (-(double)l / 2.0) * (Mlp1 + Mtlp1);
+                const double Z = lP[2];
+                double dlP[3];
+                dlP[0] = dz * lP[0] / nl + dlp0 / Z;
+                dlP[1] = dz * lP[1] / nl + dlp1 / Z;
+                dlP[2] = dz * lP[2] / nl - (dlp0 * lP[0] + dlp1 * lP[1]) / (Z * Z);
+                for (int a = 0; a < 3; ++a) {
+                    dt[a] += dlP[a];
+                    for (int b = 0; b < 3; ++b) dR[a * 3 + b] += dlP[a] * (double)cP[b];
+                }
+                const double k = dl * (-(double)l / 2.0);
+                dM[0] += k * lp[0] * lp[0]; dM[1] += k * lp[0] * lp[1];
+                dM[2] += k * lp[1] * lp[0]; dM[3] += k * lp[1] * lp[1];
+            }
+        }
+        /* cam2light */
+        double xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = params[9 + i];
+        se3_exp_backward(xi, dR, dt, g + 9);
+        /* sigma: M = Sigma^-1, Sigma = sigma^T sigma */
+        {
+            const double M[4] = {L.M[0], L.M[1], L.M[2], L.M[3]};
+            /* dSigma = -M^T dM M^T */
+            double Mt[4] = {M[0], M[2], M[1], M[3]}, T1[4], dS[4];
+            mat_mul(Mt, dM, T1, 2);
+            mat_mul(T1, Mt, dS, 2);
+            for (int i = 0; i < 4; ++i) dS[i] = -dS[i];
+            const double sg[4] = {params[15], params[16], params[17], params[18]};
+            const double sym[4] = {2 * dS[0], dS[1] + dS[2], dS[1] + dS[2], 2 * dS[3]};
+            mat_mul(sg, sym, g + 15, 2);   /* dsigma = sigma (dSigma + dSigma^T) */
+        }
+        const adam_coef_t co = adam_coef(it + 1, lr, 0.9, 0.999, 1e-8);
+        for (int k = 0; k < 19; ++k) adam_step(&params[k], &mP[k], &vP[k], (float)g[k], &co);
+        for (size_t i = 0; i < npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
+        if (trace) {
+            trace[it * 20] = cost;
+            for (int k = 0; k < 19; ++k) trace[it * 20 + 1 + k] = (double)params[k];
+        }
+    }
+    free(gJ); free(mJ); free(vJ);
+    return 0;
+}

@@ -78,6 +78,10 @@ def generate(name, spec):
     fit2 = quiet(rh.reference_fit, scene, md2, target, num_iter=50, batch_size=5)
     out['J_param_50_cover80'] = fit2['J']
     out['trace_param_cover80'] = fit2['trace']
+    # artificial-light model (--light-model): 19 parameters + J, 200 Adam steps
+    fitl = quiet(rh.reference_fit, scene, md, target, num_iter=200, light_model=True, batch_size=5)
+    out['J_light_200'] = fitl['J']
+    out['trace_light'] = fitl['trace']
     # shared-water extension: this image and its left neighbour fitted in lock-step with tied B, beta, gamma
     import copy
     other = copy.copy(scene)
