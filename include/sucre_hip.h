@@ -160,6 +160,26 @@ int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void
 int sucre_export_view(const void *ws, int H, int W, int n_views, int k, float *z_dev, uint8_t *rgb_dev,
                       void *stream);
 
+/*
+ * ---- artificial-light model: --light-model, SUCRe.compute_l_z with se3.exp (sucre.py:54-61, se3.py:22-27) ------------
+ * The model needs the camera-frame point cP of every observation (loader.py:113), which the 7-byte store does not
+ * keep, so this mode uses a second caller-owned buffer `lws` of sucre_light_workspace_bytes() bytes (256-byte
+ * aligned) next to `ws`: three float32 planes per chunk + the 19 parameters B[3], beta[3], gamma[3],
+ * cam2light[6], sigma[4] (row-major 2x2; sucre.py:41-46) and their Adam state.  The *_light entry points replace
+ * their namesakes; J, sucre_export_J, sucre_export_view, sucre_match_map and SUCRE_WS_* work unchanged on `ws`.
+ * params0: 19 host floats (the reference starts from 0.1 x 9, 0 x 6, identity).  trace_dev: T x 20 float64
+ * (cost, then the 19 parameters after the step).  The parameters live at sucre_light_params_offset() in `lws`.
+ */
+size_t sucre_light_workspace_bytes(int H, int W, int n_views);
+int64_t sucre_light_params_offset(int H, int W, int n_views);
+int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                            const sucre_view_t *views_dev, int k0, int k1, void *stream);
+int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream);
+int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
+                         const float *params0, const float *J0_dev, void *stream);
+int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
+                        double beta2, double eps, double *trace_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

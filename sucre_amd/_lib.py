@@ -45,6 +45,12 @@ SIGNATURES = {
     'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'sucre_export_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'sucre_light_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
+    'sucre_light_params_offset': (C.c_int64, [_i, _i, _i]),
+    'sucre_match_views_light': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_finalize_matches_light': (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
+    'sucre_fit_init_light': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
+    'sucre_fit_run_light': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp]),
 }
 
 _lib = None

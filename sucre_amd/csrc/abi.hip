@@ -213,4 +213,76 @@ int sucre_export_view(const void *ws, int H, int W, int n_views, int k, float *z
                                         static_cast<hipStream_t>(stream)), "sucre_export_view");
 }
 
+/* ---- artificial-light model (--light-model) ------------------------------------------------------------------ */
+
+size_t sucre_light_workspace_bytes(int H, int W, int n_views) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) { fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views); return 0; }
+    return light_workspace_bytes(L);
+}
+
+int64_t sucre_light_params_offset(int H, int W, int n_views) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) return fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views);
+    return light_params_offset(L);
+}
+
+static int check_lws(const void *lws) {
+    if (!lws) return fail(SUCRE_ERR_ARG, "light workspace is NULL");
+    if (!aligned(lws, 256)) return fail(SUCRE_ERR_ARG, "light workspace must be 256-byte aligned");
+    return SUCRE_OK;
+}
+
+int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                            const sucre_view_t *views_dev, int k0, int k1, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (!target || !views_dev || !target->depth) return fail(SUCRE_ERR_ARG, "target / views_dev / target depth is NULL");
+    if (target->H != H || target->W != W) return fail(SUCRE_ERR_ARG, "target is %dx%d, expected %dx%d", target->W, target->H, W, H);
+    if (k0 < 0 || k1 > n_views || k0 >= k1) return fail(SUCRE_ERR_RANGE, "view range [%d,%d) outside [0,%d)", k0, k1, n_views);
+    return check_hip(launch_match(L, static_cast<uint8_t *>(ws), *target, views_dev, k0, k1, static_cast<hipStream_t>(stream),
+                                  light_ext_dense(L, static_cast<uint8_t *>(lws))), "sucre_match_views_light");
+}
+
+int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
+    auto *l = static_cast<uint8_t *>(lws);
+    return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream),
+                                     light_ext_dense(L, l), light_ext_comp(L, l)), "sucre_finalize_matches_light");
+}
+
+int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
+                         const float *params0, const float *J0_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (!depth1_dev || !params0) return fail(SUCRE_ERR_ARG, "depth1_dev / params0 is NULL");
+    if (!rgb1_dev && !J0_dev) return fail(SUCRE_ERR_ARG, "need rgb1_dev or J0_dev");
+    auto s = static_cast<hipStream_t>(stream);
+    if (int rc = check_hip(launch_fit_init(L, static_cast<uint8_t *>(ws), rgb1_dev, depth1_dev, params0, J0_dev, s),
+                           "sucre_fit_init_light/J")) return rc;
+    return check_hip(launch_light_init(L, static_cast<uint8_t *>(lws), params0, s), "sucre_fit_init_light");
+}
+
+int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
+                        double beta2, double eps, double *trace_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
+    if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
+    if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
+    for (int it = 0; it < T; ++it) {
+        const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
+        if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co,
+                                                 trace_dev ? trace_dev + (size_t)it * 20 : nullptr,
+                                                 static_cast<hipStream_t>(stream)), "sucre_fit_run_light")) return rc;
+    }
+    return SUCRE_OK;
+}
+
 }  // extern "C"

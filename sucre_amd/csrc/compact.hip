@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
                                                      const uint64_t *__restrict__ pmask, int mask_words,
                                                      const uint32_t *__restrict__ levels,
                                                      const uint64_t *__restrict__ tile_off,
-                                                     uint8_t *__restrict__ comp) {
+                                                     uint8_t *__restrict__ comp, int n_views,
+                                                     const uint8_t *__restrict__ ext_dense,
+                                                     uint8_t *__restrict__ ext_comp) {
     const int dtile = blockIdx.x, t = threadIdx.x;
     const uint32_t nl = levels[dtile];
     if (nl == 0) return;
@@ -232,12 +234,19 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
                 o[kChunkZ + t] = r[b];
                 o[kChunkZ + kTilePx + t] = g[b];
                 o[kChunkZ + 2 * kTilePx + t] = bl[b];
+                if (ext_dense) {  // light model: carry the camera point along (same chunk numbering, kExtChunk stride)
+                    const float *se = reinterpret_cast<const float *>(
+                        ext_dense + ((size_t)stile * n_views + (kk[b] >= 0 ? kk[b] : 0)) * kExtChunk);
+                    float *de = reinterpret_cast<float *>(ext_comp + (tile_off[dtile] / kChunk + l0 + b) * kExtChunk);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + t] = kk[b] >= 0 ? se[pl * kTilePx + ss] : 0.0f;
+                }
             }
         }
     }
 }
 
-hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s) {
+hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *keep = reinterpret_cast<const uint32_t *>(ws + L.off_view_keep);
     auto *pcount = reinterpret_cast<uint16_t *>(ws + L.off_pcount);
@@ -261,7 +270,8 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s) {
     hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks));
     hipLaunchKernelGGL(gather_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                       L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp);
+                       L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
+                       ext_dense, ext_comp);
     return hipGetLastError();
 }
 

@@ -14,30 +14,9 @@
 // With L = sum r^2 / (3 n_obs) and s = (1/3)/n_obs (sucre.py:145):
 //   dL/dJ[p]  = -2 s sum_k r a          dL/dB     = -2 s sum r (1 - g)
 //   dL/dbeta  = +2 s sum_p J sum_k r a z    dL/dgamma = -2 s B sum r g z        (per channel)
-#include "launch.h"
+#include "fit_math.h"
 
 namespace sucre {
-
-constexpr float kLog2e = 1.44269504088896340736f;
-// float32(float64(k)/255) for every uint8 k (loader.py:157,163) as fma(k, hi, k*lo); checked for all 256 values
-// in tests/test_host_logic.py and on the GPU by tests/test_gpu_parity.py.
-constexpr float kInv255Hi = (float)(1.0 / 255.0);
-constexpr float kInv255Lo = (float)(1.0 / 255.0 - (double)kInv255Hi);
-
-__device__ __forceinline__ float unit_from_u8(uint32_t k) {
-    const float kf = (float)k;
-    return __builtin_fmaf(kf, kInv255Hi, kf * kInv255Lo);
-}
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay), float32
-__device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const AdamCoef &co) {
-    m = __builtin_fmaf(co.w1, g - m, m);
-    v = (v * co.beta2) + (co.w2 * g) * g;
-    const float denom = sqrtf(v) / co.bc2_sqrt + co.eps;
-    p = p + (co.step_size_neg * m) / denom;
-}
 
 struct Water {
     float B[3], nb[3], ng[3];  // B, -beta*log2(e), -gamma*log2(e)

@@ -27,13 +27,15 @@ struct AdamCoef {
 AdamCoef adam_coef(int step, double lr, double beta1, double beta2, double eps);
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s);
+                        int k0, int k1, hipStream_t s, uint8_t *ext = nullptr);
 hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
                             int32_t *map, hipStream_t s);
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
                               const uint8_t *rgb, long long n, hipStream_t s);
-hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s);
-hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s);
+hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s,
+                           const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr);
+hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense = nullptr,
+                          uint8_t *ext_comp = nullptr);
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);
 
 hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,
@@ -45,5 +47,14 @@ hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, dou
 hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s);
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
 hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
+
+// artificial-light model (light.hip)
+size_t light_workspace_bytes(const Layout &L);
+int64_t light_params_offset(const Layout &L);
+uint8_t *light_ext_dense(const Layout &L, uint8_t *lws);
+uint8_t *light_ext_comp(const Layout &L, uint8_t *lws);
+hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params19, hipStream_t s);
+hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, double *trace_row,
+                             hipStream_t s);
 
 }  // namespace sucre

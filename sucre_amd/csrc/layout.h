@@ -10,6 +10,7 @@ constexpr int kTilePx = 256;         // pixels per tile = one 64-lane wave x 4 p
 constexpr int kChunkZ = 1024;        // bytes: 256 float32 ranges
 constexpr int kChunkRGB = 768;       // bytes: planar R[256] G[256] B[256] uint8
 constexpr int kChunk = kChunkZ + kChunkRGB;  // 1792 bytes per (tile, view)
+constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
 constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
 constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)

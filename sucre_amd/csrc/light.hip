@@ -1,0 +1,408 @@
+// Artificial-light model (--light-model) for gfx950: sucre.py:54-61 with se3.exp (se3.py:22-27).
+//
+//   R, t = se3.exp(cam2light);  Sigma = sigma^T sigma;  lP = R cP + t;  lp = lP.xy / lP.z
+//   l = exp(-(lp^T Sigma^-1 lp) / 2);   z = ||cP|| + ||lP||;   Ihat = l (J a + B (1 - g))
+//
+// The reference differentiates this with autograd; here the gradient is analytic (same formulas as the CPU oracle,
+// oracle/sucre_oracle.c::oracle_fit_light).  The model needs the camera-frame point cP of every observation, which
+// the 7-byte store of the default path does not keep, so this mode works on an EXTENSION workspace `lws`:
+// three float planes (cP.x, cP.y, cP.z) per chunk -- written by match_kernel, carried through the compaction --
+// plus the 19 parameters (B, beta, gamma, cam2light[6], sigma[4]), their Adam moments, and the reduction buffers.
+// Everything of the default path (J planes, compact store, perm, levels) is reused from the main workspace.
+//
+// One iteration = light_grad_kernel (persistent workgroups like fit_grad_kernel; 26 sums) -> light_reduce_kernel
+// (fixed-order float64) -> light_step_kernel (chain rule through Sigma^-1 and through the matrix exponential --
+// six 8x8 block exponentials evaluated in parallel in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1).
+// This mode is built for correctness first: plain loads instead of the LDS-DMA ring.
+#include "fit_math.h"
+
+namespace sucre {
+
+constexpr int kLightSums = 26;   // sB[3] sGZ[3] sBeta[3] cost | dR[9] dt[3] dM[4]
+constexpr int kLightParams = 19;
+
+struct LightLayout {
+    size_t off_ext_dense, off_ext_comp;   // float [chunk][3][256]
+    size_t off_params;                    // float [19] params, [19] exp_avg, [19] exp_avg_sq
+    size_t off_geom;                      // float [16]: R[9], t[3], M[4] = Sigma^-1 (row-major)
+    size_t off_partials;                  // float [26][n_blocks]
+    size_t off_sums;                      // double [26]
+    size_t total;
+};
+
+static bool make_light_layout(const Layout &L, LightLayout *X) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    const size_t chunks = (size_t)L.n_tiles * L.n_views;
+    X->off_ext_dense = take(chunks * kExtChunk);
+    X->off_ext_comp = take(chunks * kExtChunk);
+    X->off_params = take(3 * kLightParams * sizeof(float));
+    X->off_geom = take(16 * sizeof(float));
+    X->off_partials = take((size_t)kLightSums * L.n_blocks * sizeof(float));
+    X->off_sums = take(kLightSums * sizeof(double));
+    X->total = o;
+    return true;
+}
+
+// ---- small dense linear algebra in LDS: nmat independent 8x8 float64 products, one thread per output element ------
+__device__ __forceinline__ void block_mul(const double (*A)[64], const double (*B)[64], double (*C)[64], int nmat,
+                                          double post_scale) {
+    const int m = threadIdx.x >> 6, e = threadIdx.x & 63, r = e >> 3, c = e & 7;
+    if (m < nmat) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += A[m][r * 8 + k] * B[m][k * 8 + c];
+        C[m][e] = s * post_scale;
+    }
+    __syncthreads();
+}
+
+// E[m] = exp(S0[m]) for nmat 8x8 matrices: scaling by 2^-6, degree-12 Taylor, six squarings.  512 threads.
+__device__ __forceinline__ void block_exp(double (*S)[64], double (*T)[64], double (*E)[64], double (*P)[64], int nmat) {
+    const int m = threadIdx.x >> 6, e = threadIdx.x & 63;
+    if (m < nmat) {
+        S[m][e] *= 1.0 / 64.0;
+        const double id = (e % 9 == 0) ? 1.0 : 0.0;
+        T[m][e] = id;
+        E[m][e] = id;
+    }
+    __syncthreads();
+    for (int k = 1; k <= 12; ++k) {
+        block_mul(T, S, P, nmat, 1.0 / k);
+        if (m < nmat) { T[m][e] = P[m][e]; E[m][e] += P[m][e]; }
+        __syncthreads();
+    }
+    for (int q = 0; q < 6; ++q) {
+        block_mul(E, E, P, nmat, 1.0);
+        if (m < nmat) E[m][e] = P[m][e];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void hat_into(const double xi[6], double *A /*8x8 block matrix*/, int row0, int col0) {
+    const double h[16] = {0, -xi[2], xi[1], xi[3], xi[2], 0, -xi[0], xi[4], -xi[1], xi[0], 0, xi[5], 0, 0, 0, 0};
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) A[(row0 + r) * 8 + col0 + c] = h[r * 4 + c];
+}
+
+// geom (R, t, M) from the parameters; 512 threads, uses matrix 0 of the LDS buffers.
+__device__ __forceinline__ void light_geometry(const float *params, float *geom, double (*S)[64], double (*T)[64],
+                                               double (*E)[64], double (*P)[64]) {
+    if (threadIdx.x < 64) S[0][threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = params[9 + i];
+        hat_into(xi, S[0], 0, 0);
+    }
+    __syncthreads();
+    block_exp(S, T, E, P, 1);
+    if (threadIdx.x < 12) {
+        const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+        if (c < 3) geom[r * 3 + c] = (float)E[0][r * 8 + c];
+        else geom[9 + r] = (float)E[0][r * 8 + 3];
+    }
+    if (threadIdx.x == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
+        const float *sg = params + 15;
+        const float S00 = sg[0] * sg[0] + sg[2] * sg[2], S01 = sg[0] * sg[1] + sg[2] * sg[3];
+        const float S11 = sg[1] * sg[1] + sg[3] * sg[3];
+        const float det = S00 * S11 - S01 * S01;
+        geom[12] = S11 / det; geom[13] = -S01 / det; geom[14] = -S01 / det; geom[15] = S00 / det;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void light_init_kernel(float *pstate, float *geom, const float *p0) {
+    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
+    if (threadIdx.x < 3 * kLightParams) pstate[threadIdx.x] = threadIdx.x < kLightParams ? p0[threadIdx.x] : 0.f;
+    __syncthreads();
+    light_geometry(pstate, geom, S, T, E, P);
+}
+
+// ---- gradient pass ---------------------------------------------------------------------------------------------------
+struct LightAcc {
+    float pa[3][4], pb[3][4];      // per pixel-channel: sum r l a ; sum r l a z
+    float s[kLightSums];           // thread-level global sums (slots 6..8 = sBeta are filled per tile)
+};
+
+__global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restrict__ comp, const uint8_t *__restrict__ ext,
+                                                         const uint64_t *__restrict__ tile_off,
+                                                         const uint32_t *__restrict__ levels, int n_tiles,
+                                                         const float *__restrict__ pstate, const float *__restrict__ geom,
+                                                         const uint64_t *__restrict__ n_obs_total,
+                                                         float *__restrict__ Jt, float *__restrict__ mt,
+                                                         float *__restrict__ vt, float *__restrict__ partials,
+                                                         const AdamCoef co) {
+    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
+    __shared__ float wsum[4][kLightSums];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n_blocks = gridDim.x;
+    float B[3], nb[3], ng[3], beta[3], gamma[3], R[9], tl[3], M[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        B[c] = pstate[c]; beta[c] = pstate[3 + c]; gamma[c] = pstate[6 + c];
+        nb[c] = -beta[c] * kLog2e; ng[c] = -gamma[c] * kLog2e;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = geom[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tl[i] = geom[9 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M[i] = geom[12 + i];
+    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));
+
+    LightAcc acc;
+#pragma unroll
+    for (int q = 0; q < kLightSums; ++q) acc.s[q] = 0.f;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
+        const uint32_t n = levels[tile];
+        const uint8_t *tobs = comp + tile_off[tile];
+        const uint8_t *text = ext + (tile_off[tile] / kChunk) * kExtChunk;
+        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+        float J[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
+        }
+        for (uint32_t lv = wave; lv < n; lv += 4) {
+            const uint8_t *ch = tobs + (size_t)lv * kChunk;
+            const float *ex = reinterpret_cast<const float *>(text + (size_t)lv * kExtChunk);
+            const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + kChunkZ) + lane;
+            const uint32_t cc[3] = {cp[0], cp[64], cp[128]};
+            const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
+            const float4 y4 = *reinterpret_cast<const float4 *>(ex + kTilePx + lane * 4);
+            const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kTilePx + lane * 4);
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!(zz[j] > 0.0f)) continue;  // padding slot
+                const float cP[3] = {xx[j], yy[j], ww[j]};
+                // sucre.py:55-61
+                float lP[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], R[a * 3] * cP[0])) + tl[a];
+                const float lp0 = lP[0] / lP[2], lp1 = lP[1] / lP[2];
+                const float q = lp0 * (M[0] * lp0 + M[1] * lp1) + lp1 * (M[2] * lp0 + M[3] * lp1);
+                const float l = fast_exp2(q * (-0.5f * kLog2e));
+                const float nl = sqrtf(lP[0] * lP[0] + lP[1] * lP[1] + lP[2] * lP[2]);
+                const float z = zz[j] + nl;
+                float dl = 0.f, dz = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float a = fast_exp2(z * nb[c]), g = fast_exp2(z * ng[c]);
+                    const float omg = 1.0f - g;
+                    const float E = __builtin_fmaf(J[c][j], a, B[c] * omg);
+                    const float I = unit_from_u8((cc[c] >> (8 * j)) & 255u);
+                    const float r = I - l * E;
+                    const float rl = r * l;
+                    acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
+                    acc.pa[c][j] = __builtin_fmaf(rl, a, acc.pa[c][j]);
+                    acc.pb[c][j] = __builtin_fmaf(rl * z, a, acc.pb[c][j]);
+                    acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
+                    acc.s[3 + c] = __builtin_fmaf(rl * z, g, acc.s[3 + c]);
+                    dl = __builtin_fmaf(r, E, dl);
+                    dz = __builtin_fmaf(rl, gamma[c] * B[c] * g - beta[c] * J[c][j] * a, dz);
+                }
+                // chain rule into lP (common factor -2 s applied in the step kernel)
+                const float k = dl * (-0.5f * l);
+                const float dlp0 = k * ((M[0] * lp0 + M[1] * lp1) + (M[0] * lp0 + M[2] * lp1));
+                const float dlp1 = k * ((M[2] * lp0 + M[3] * lp1) + (M[1] * lp0 + M[3] * lp1));
+                const float iz = 1.0f / lP[2], inl = 1.0f / nl;
+                float dlP[3];
+                dlP[0] = dz * lP[0] * inl + dlp0 * iz;
+                dlP[1] = dz * lP[1] * inl + dlp1 * iz;
+                dlP[2] = dz * lP[2] * inl - (dlp0 * lP[0] + dlp1 * lP[1]) * iz * iz;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    acc.s[19 + a] += dlP[a];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
+                }
+                acc.s[22] = __builtin_fmaf(k * lp0, lp0, acc.s[22]);
+                acc.s[23] = __builtin_fmaf(k * lp0, lp1, acc.s[23]);
+                acc.s[24] = __builtin_fmaf(k * lp1, lp0, acc.s[24]);
+                acc.s[25] = __builtin_fmaf(k * lp1, lp1, acc.s[25]);
+            }
+        }
+        // per-pixel sums of the four waves (fixed order), then the pixel-parallel Adam step on J
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) = make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
+            *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) = make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
+        }
+        __syncthreads();
+        float *mtile = mt + (size_t)tile * 3 * kTilePx, *vtile = vt + (size_t)tile * 3 * kTilePx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ta = ((red[0][c][t] + red[1][c][t]) + red[2][c][t]) + red[3][c][t];
+            const float tb = ((red[0][3 + c][t] + red[1][3 + c][t]) + red[2][3 + c][t]) + red[3][3 + c][t];
+            float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
+            acc.s[6 + c] += (tb == 0.0f) ? 0.0f : Jc * tb;
+            adam_update(Jc, m, v, gscale * ta, co);
+            Jtile[c * kTilePx + t] = Jc; mtile[c * kTilePx + t] = m; vtile[c * kTilePx + t] = v;
+        }
+        __syncthreads();
+    }
+    // workgroup sums: shuffle tree, then the four waves in fixed order
+#pragma unroll
+    for (int q = 0; q < kLightSums; ++q) {
+        float x = acc.s[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) wsum[wave][q] = x;
+    }
+    __syncthreads();
+    if (t < kLightSums) partials[(size_t)t * n_blocks + blockIdx.x] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
+}
+
+// sums[q] = sum over workgroups, float64, fixed order.
+__global__ __launch_bounds__(256) void light_reduce_kernel(const float *__restrict__ partials, int n_blocks,
+                                                           double *__restrict__ sums) {
+    __shared__ double w4[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int q = 0; q < kLightSums; ++q) {
+        double x = 0.0;
+        for (int b = t; b < n_blocks; b += 256) x += (double)partials[(size_t)q * n_blocks + b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) w4[wave] = x;
+        __syncthreads();
+        if (t == 0) sums[q] = ((w4[0] + w4[1]) + w4[2]) + w4[3];
+        __syncthreads();
+    }
+}
+
+// Gradients of the 19 parameters from the sums, Adam, next geometry, log row.  512 threads.
+__global__ __launch_bounds__(512) void light_step_kernel(const double *__restrict__ sums, float *pstate, float *geom,
+                                                         const uint64_t *__restrict__ n_obs_total, const AdamCoef co,
+                                                         double *__restrict__ trace_row) {
+    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
+    __shared__ double grad[kLightParams];
+    const int tid = threadIdx.x;
+    const double f = -2.0 * (double)((1.0f / 3.0f) / (float)(*n_obs_total));   // dL/dIhat = f * r
+    // block matrices [[A, G_i], [0, A]]: the upper-right block of the exponential is D exp(A)[G_i]
+    if (tid < 384) S[tid >> 6][tid & 63] = 0.0;
+    __syncthreads();
+    if (tid < 6) {
+        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i) xi[i] = pstate[9 + i];
+        ei[tid] = 1.0;
+        hat_into(xi, S[tid], 0, 0);
+        hat_into(xi, S[tid], 4, 4);
+        hat_into(ei, S[tid], 0, 4);
+    }
+    __syncthreads();
+    block_exp(S, T, E, P, 6);
+    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp[G_i]>
+        double s = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * E[tid][r * 8 + 4 + c];
+            s += sums[19 + r] * E[tid][r * 8 + 7];
+        }
+        grad[9 + tid] = f * s;
+    }
+    if (tid == 6) {  // water parameters (same combinations as water_step of the default path)
+        for (int c = 0; c < 3; ++c) {
+            grad[c] = f * sums[c];
+            grad[3 + c] = -f * sums[6 + c];
+            grad[6 + c] = f * (double)pstate[c] * sums[3 + c];
+        }
+    }
+    if (tid == 7) {  // sigma: M = Sigma^-1, Sigma = sigma^T sigma;  dSigma = -M^T dM M^T;  dsigma = sigma (dSigma + dSigma^T)
+        const double M[4] = {geom[12], geom[13], geom[14], geom[15]};
+        const double dM[4] = {f * sums[22], f * sums[23], f * sums[24], f * sums[25]};
+        const double Mt[4] = {M[0], M[2], M[1], M[3]};
+        double T1[4], dS[4];
+        T1[0] = Mt[0] * dM[0] + Mt[1] * dM[2]; T1[1] = Mt[0] * dM[1] + Mt[1] * dM[3];
+        T1[2] = Mt[2] * dM[0] + Mt[3] * dM[2]; T1[3] = Mt[2] * dM[1] + Mt[3] * dM[3];
+        dS[0] = -(T1[0] * Mt[0] + T1[1] * Mt[2]); dS[1] = -(T1[0] * Mt[1] + T1[1] * Mt[3]);
+        dS[2] = -(T1[2] * Mt[0] + T1[3] * Mt[2]); dS[3] = -(T1[2] * Mt[1] + T1[3] * Mt[3]);
+        const double sym[4] = {2 * dS[0], dS[1] + dS[2], dS[1] + dS[2], 2 * dS[3]};
+        const double sg[4] = {pstate[15], pstate[16], pstate[17], pstate[18]};
+        grad[15] = sg[0] * sym[0] + sg[1] * sym[2]; grad[16] = sg[0] * sym[1] + sg[1] * sym[3];
+        grad[17] = sg[2] * sym[0] + sg[3] * sym[2]; grad[18] = sg[2] * sym[1] + sg[3] * sym[3];
+    }
+    __syncthreads();
+    if (tid < kLightParams) {
+        float p = pstate[tid], m = pstate[kLightParams + tid], v = pstate[2 * kLightParams + tid];
+        adam_update(p, m, v, (float)grad[tid], co);
+        pstate[tid] = p; pstate[kLightParams + tid] = m; pstate[2 * kLightParams + tid] = v;
+        if (trace_row) trace_row[1 + tid] = (double)p;
+    }
+    if (tid == 32 && trace_row) trace_row[0] = sums[9];
+    __syncthreads();
+    light_geometry(pstate, geom, S, T, E, P);
+}
+
+struct LightParams19 { float v[kLightParams]; };
+
+__global__ void light_params_upload_kernel(float *dst, const LightParams19 p) {
+    if (threadIdx.x < kLightParams) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+size_t light_workspace_bytes(const Layout &L) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    return X.total;
+}
+
+int64_t light_params_offset(const Layout &L) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    return (int64_t)X.off_params;
+}
+
+uint8_t *light_ext_dense(const Layout &L, uint8_t *lws) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    return lws + X.off_ext_dense;
+}
+
+uint8_t *light_ext_comp(const Layout &L, uint8_t *lws) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    return lws + X.off_ext_comp;
+}
+
+hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params19, hipStream_t s) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    LightParams19 p;
+    for (int i = 0; i < kLightParams; ++i) p.v[i] = params19[i];
+    float *pstate = reinterpret_cast<float *>(lws + X.off_params);
+    float *scratch = reinterpret_cast<float *>(lws + X.off_sums);  // 19 floats staged in the (still unused) sums area
+    hipLaunchKernelGGL(light_params_upload_kernel, dim3(1), dim3(64), 0, s, scratch, p);
+    hipLaunchKernelGGL(light_init_kernel, dim3(1), dim3(512), 0, s, pstate, reinterpret_cast<float *>(lws + X.off_geom),
+                       scratch);
+    return hipGetLastError();
+}
+
+hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, double *trace_row,
+                             hipStream_t s) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    float *pstate = reinterpret_cast<float *>(lws + X.off_params);
+    float *geom = reinterpret_cast<float *>(lws + X.off_geom);
+    float *partials = reinterpret_cast<float *>(lws + X.off_partials);
+    double *sums = reinterpret_cast<double *>(lws + X.off_sums);
+    auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
+    hipLaunchKernelGGL(light_grad_kernel, dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp, lws + X.off_ext_comp,
+                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_levels), L.n_tiles, pstate, geom, nobs,
+                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
+                       reinterpret_cast<float *>(ws + L.off_v), partials, co);
+    hipLaunchKernelGGL(light_reduce_kernel, dim3(1), dim3(256), 0, s, partials, L.n_blocks, sums);
+    hipLaunchKernelGGL(light_step_kernel, dim3(1), dim3(512), 0, s, sums, pstate, geom, nobs, co, trace_row);
+    return hipGetLastError();
+}
+
+}  // namespace sucre

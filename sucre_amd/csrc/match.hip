@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                                                     const float *__restrict__ depth1, const CamDev c1,
                                                     const sucre_view_t *__restrict__ views, int n_views, int k0,
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
-                                                    size_t tile_stride, size_t view_stride) {
+                                                    size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext) {
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
         const uint8_t *__restrict__ rgb2 = vw->rgb;
         const float W2f = (float)vw->W, H2f = (float)vw->H;
-        float zo[4];
+        float zo[4], cx[4], cy[4], cz[4];
         uint32_t r4 = 0, g4 = 0, b4 = 0;
         int total = 0;
 #pragma unroll
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             bool m = ok1[j];
             float z = 0.0f;
             uint32_t r = 0, g = 0, b = 0;
+            float c2[3] = {0.f, 0.f, 0.f};
             if (m) {
                 size_t q;
-                float c2[3];
                 m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                 }
             }
             zo[j] = z;
+            cx[j] = m ? c2[0] : 0.f; cy[j] = m ? c2[1] : 0.f; cz[j] = m ? c2[2] : 0.f;
             r4 |= r << (8 * j);
             g4 |= g << (8 * j);
             b4 |= b << (8 * j);
@@ -138,6 +139,12 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
             c[0] = r4; c[64] = g4; c[128] = b4;
+            if (ext) {  // light model only: the camera-frame point cP of every observation (loader.py:113), 3 planes
+                uint8_t *e = ext + ((size_t)tile * n_views + k) * kExtChunk;
+                *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(cx[0], cx[1], cx[2], cx[3]);
+                *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(cy[0], cy[1], cy[2], cy[3]);
+                *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(cz[0], cz[1], cz[2], cz[3]);
+            }
         }
     }
 }
@@ -284,12 +291,12 @@ static CamDev to_cam(const sucre_view_t &v) {
 }
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s) {
+                        int k0, int k1, hipStream_t s, uint8_t *ext) {
     const int tiles_per_xcd = (L.n_tiles + 7) / 8;
     const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
     hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
                        reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
-                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride);
+                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext);
     return hipGetLastError();
 }
 
@@ -300,7 +307,8 @@ hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const s
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s) {
+hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s, const uint8_t *ext_dense,
+                           uint8_t *ext_comp) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *vc = reinterpret_cast<uint64_t *>(ws + L.off_view_count);
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
@@ -310,7 +318,7 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_compact(L, ws, s);
+    return launch_compact(L, ws, s, ext_dense, ext_comp);
 }
 
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {

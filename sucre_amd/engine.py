@@ -52,8 +52,9 @@ class Restoration:
     """Workspace + launch sequence for one target image (replaces the HDF5 spill and the host-resident
     MatchesData of the reference, loader.py:56-130)."""
 
-    def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda'):
+    def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda', light: bool = False):
         self.lib = _lib.load()
+        self.light = bool(light)
         self.H, self.W, self.n_views = int(height), int(width), int(n_views)
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -63,6 +64,11 @@ class Restoration:
             raise _lib.SucreError(self.lib.sucre_last_error().decode())
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
+        self.lws = None
+        if self.light:  # extension workspace of the artificial-light model (camera points + 19 parameters)
+            lbytes = self.lib.sucre_light_workspace_bytes(self.H, self.W, self.n_views)
+            self.lws = torch.empty(lbytes, dtype=torch.uint8, device=self.device)
+            assert self.lws.data_ptr() % 256 == 0
         self._views_dev = None
         self._keepalive = []
         self.trace = None
@@ -90,9 +96,15 @@ class Restoration:
         self._keepalive = [target, views]
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
-                                                  0, n, _stream_ptr()))
-            _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
+            if self.light:
+                lws = C.c_void_p(self.lws.data_ptr())
+                _lib.check(self.lib.sucre_match_views_light(ws, lws, H, W, n, C.byref(tgt),
+                                                            C.c_void_p(self._views_dev.data_ptr()), 0, n, _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches_light(ws, lws, H, W, n, float(min_cover), _stream_ptr()))
+            else:
+                _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
+                                                      0, n, _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
 
     def import_matches(self, target: DeviceView, lists: list, min_cover: float = -1.0) -> None:
         """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
@@ -146,8 +158,10 @@ class Restoration:
 
     # -- fit (sucre.py:36-82, 124-157) --------------------------------------------------------------------------
     def fit_init(self, target: DeviceView, params0=None, J0: torch.Tensor | None = None) -> None:
-        p0 = np.full(9, 0.1, np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(9)
-        p0c = (C.c_float * 9)(*p0.tolist())
+        npar = 19 if self.light else 9
+        default = np.concatenate([np.full(9, 0.1), np.zeros(6), [1.0, 0.0, 0.0, 1.0]])[:npar]  # sucre.py:41-46
+        p0 = default.astype(np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(npar)
+        p0c = (C.c_float * npar)(*p0.tolist())
         j0 = None
         if J0 is not None:
             j0 = J0.to(self.device, torch.float32).contiguous()
@@ -155,9 +169,14 @@ class Restoration:
             self._keepalive.append(j0)
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.sucre_fit_init(ws, H, W, n, C.c_void_p(target.rgb.data_ptr()),
-                                               C.c_void_p(target.depth.data_ptr()), p0c,
-                                               C.c_void_p(j0.data_ptr()) if j0 is not None else None, _stream_ptr()))
+            j0p = C.c_void_p(j0.data_ptr()) if j0 is not None else None
+            if self.light:
+                _lib.check(self.lib.sucre_fit_init_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
+                                                         C.c_void_p(target.rgb.data_ptr()),
+                                                         C.c_void_p(target.depth.data_ptr()), p0c, j0p, _stream_ptr()))
+            else:
+                _lib.check(self.lib.sucre_fit_init(ws, H, W, n, C.c_void_p(target.rgb.data_ptr()),
+                                                   C.c_void_p(target.depth.data_ptr()), p0c, j0p, _stream_ptr()))
         self.steps_done = 0
 
     def fit(self, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
@@ -166,14 +185,22 @@ class Restoration:
         device trace (cost, B, beta, gamma per iteration) or None.  In closed-form mode the C ABI appends the
         final ``update_J`` of sucre.py:156 to every ``sucre_fit_run`` call; that is idempotent, so a fit split
         into several calls (``finalize`` is kept for readability) ends in the same state."""
-        trace = torch.zeros((num_iter, 10), dtype=torch.float64, device=self.device) if record_trace else None
+        width = 20 if self.light else 10
+        trace = torch.zeros((num_iter, width), dtype=torch.float64, device=self.device) if record_trace else None
         flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
         ws, H, W, n = self._geom
+        tp = C.c_void_p(trace.data_ptr()) if trace is not None else None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.sucre_fit_run(ws, H, W, n, self.steps_done, int(num_iter), float(lr), float(betas[0]),
-                                              float(betas[1]), float(eps), flags,
-                                              C.c_void_p(trace.data_ptr()) if trace is not None else None,
-                                              _stream_ptr()))
+            if self.light:
+                if use_closed_form:
+                    raise NotImplementedError('--light-model together with --use-closed-form is not built yet')
+                _lib.check(self.lib.sucre_fit_run_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self.steps_done,
+                                                        int(num_iter), float(lr), float(betas[0]), float(betas[1]),
+                                                        float(eps), tp, _stream_ptr()))
+            else:
+                _lib.check(self.lib.sucre_fit_run(ws, H, W, n, self.steps_done, int(num_iter), float(lr),
+                                                  float(betas[0]), float(betas[1]), float(eps), flags, tp,
+                                                  _stream_ptr()))
         self.steps_done += int(num_iter)
         self.trace = trace
         return trace
@@ -184,7 +211,10 @@ class Restoration:
             _lib.check(self.lib.sucre_update_J(ws, H, W, n, _stream_ptr()))
 
     def params(self) -> torch.Tensor:
-        """B[3], beta[3], gamma[3] on the device."""
+        """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
+        if self.light:
+            off = self.lib.sucre_light_params_offset(self.H, self.W, self.n_views)
+            return self.lws[off:off + 76].view(torch.float32)
         return self._region(_lib.WS_PARAMS, torch.float32, 9)
 
     def J(self) -> torch.Tensor:
@@ -243,15 +273,15 @@ class HipWaterBackend:
 _POOL: dict = {}
 
 
-def acquire_restoration(height: int, width: int, n_views: int, device='cuda') -> Restoration:
+def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False) -> Restoration:
     """Workspace pool: one Restoration per (geometry, device), reused image after image (the 1080p x 65-view
     workspace is ~1 GB; re-allocating it per image would serialise on the allocator)."""
     dev = torch.device(device)
     if dev.type == 'cuda' and dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
-    key = (int(height), int(width), int(n_views), str(dev))
+    key = (int(height), int(width), int(n_views), str(dev), bool(light))
     if key not in _POOL:
-        _POOL[key] = Restoration(height, width, n_views, device=dev)
+        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light)
     return _POOL[key]
 
 

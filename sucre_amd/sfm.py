@@ -102,16 +102,17 @@ class Image:
 
     # -- matching ---------------------------------------------------------------------------------------------------
     def match_images(self, image_list: list['Image'], matches_file: 'loader.MatchesFile', min_cover: float = 0.000001,
-                     num_workers: int = 0, device: str = 'cuda'):
+                     num_workers: int = 0, device: str = 'cuda', light_model: bool = False):
         """Two-way dense matching of this image against every image of ``image_list`` and preparation of the
         observations the fit consumes (replaces sfm.py:127-138 + loader.py:78-118).  One HIP launch matches all
         views; views failing ``n_matches / (W*H) > min_cover`` are dropped on the device; nothing is written to
-        disk unless the matches file is asked to persist."""
+        disk unless the matches file is asked to persist.  ``light_model`` (not a reference argument) also keeps the
+        camera-frame point of every observation, which the artificial-light model needs."""
         from . import engine
         loader.prefetch_device_views(image_list + [self], device, num_workers=num_workers)
         views = [im.device_view(device) for im in image_list]
         target = self.device_view(device)
-        resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device)
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device, light=light_model)
         resto.match(target, views, min_cover=min_cover)
         matches_file.attach(resto, target_image=self, image_list=list(image_list))
 

@@ -34,15 +34,17 @@ class SUCRe(torch.nn.Module):
 
     def __init__(self, image: sfm.Image, light_model: bool = False, use_closed_form: bool = False):
         super().__init__()
-        if light_model:
-            raise NotImplementedError('the artificial-light model (--light-model, sucre.py:54-61) is not part of '
-                                      'this build yet: it needs per-observation camera points in the store')
+        if light_model and use_closed_form:
+            raise NotImplementedError('--light-model together with --use-closed-form is not built yet')
         self.image = image
         self.light_model = light_model
         self.use_closed_form = use_closed_form
         self.B = torch.nn.Parameter(torch.full((3, 1), 0.1))
         self.beta = torch.nn.Parameter(torch.full((3, 1), 0.1))
         self.gamma = torch.nn.Parameter(torch.full((3, 1), 0.1))
+        if light_model:  # light pose (twist, light-from-camera) and the 2x2 factor of the beam-shape matrix
+            self.cam2light = torch.nn.Parameter(torch.zeros(6))
+            self.sigma = torch.nn.Parameter(torch.eye(2))
         if not use_closed_form:
             J = image.get_rgb()
             J[image.get_depth_map() <= 0] = torch.nan
@@ -50,7 +52,16 @@ class SUCRe(torch.nn.Module):
 
     # -- model evaluation (output stage / compatibility; the fit itself runs in the HIP engine) -------------------
     def compute_l_z(self, cP: Tensor) -> tuple[float | Tensor, Tensor]:
-        return 1.0, cP.norm(dim=0)
+        """Illumination factor l and total light path z of camera-frame points (3, n) (sucre.py:52-64)."""
+        z = cP.norm(dim=0)
+        if not self.light_model:
+            return 1.0, z
+        R, t = se3.exp(self.cam2light)
+        lP = R @ cP + t                                   # points in the light's frame
+        lp = lP[:2] / lP[2]                               # (2, n) direction from the light axis
+        Minv = (self.sigma.T @ self.sigma).inverse()
+        q = (lp * (Minv @ lp)).sum(dim=0)                 # lp^T Sigma^-1 lp per point
+        return torch.exp(-q / 2), z + lP.norm(dim=0)
 
     @torch.no_grad()
     def update_J(self, matches_data: loader.MatchesData, force_update: bool = False):
@@ -69,8 +80,9 @@ class SUCRe(torch.nn.Module):
         return l * (direct + veil)
 
     def water_vector(self) -> Tensor:
-        """B, beta, gamma flattened to the 9 floats the engine stores."""
-        return torch.cat([self.B.detach().flatten(), self.beta.detach().flatten(), self.gamma.detach().flatten()]).float()
+        """B, beta, gamma (+ cam2light, sigma with the light model) flattened to the floats the engine stores."""
+        parts = [self.B, self.beta, self.gamma] + ([self.cam2light, self.sigma] if self.light_model else [])
+        return torch.cat([p.detach().flatten() for p in parts]).float()
 
     # -- output stage (sucre.py:84-121) -----------------------------------------------------------------------------
     @torch.no_grad()
@@ -96,11 +108,24 @@ class SUCRe(torch.nn.Module):
         out[v, u] = self(u=u, v=v, cP=cP).clip(0, 1).T
         return PILImage.fromarray(np.uint8(out.cpu().numpy() * 255))
 
+    @torch.no_grad()
+    def plot_l(self) -> PILImage.Image:
+        """Illumination factor over the image, jet colour map (sucre.py:96-104)."""
+        import matplotlib.pyplot as plt
+        dev = self.cam2light.device
+        u, v, cP = self.image.unproject_depth_map(self.image.get_depth_map().to(dev), to_world=False)
+        l, _ = self.compute_l_z(cP)
+        lmap = torch.zeros((self.image.camera.height, self.image.camera.width), device=dev)
+        lmap[v, u] = l
+        return PILImage.fromarray(np.uint8(plt.colormaps['jet'](lmap.cpu().numpy())[:, :, :3] * 255))
+
     def save_plots(self, save_dir: Path, iteration: int | None = None):
         stem = Path(self.image.name).stem
         tag = '' if iteration is None else f'_{iteration:04d}'
         self.plot_J().save(Path(save_dir) / f'{stem}_rgb{tag}.png')
         self.plot_reconstruction().save(Path(save_dir) / f'{stem}_reconstruction{tag}.png')
+        if self.light_model:
+            self.plot_l().save(Path(save_dir) / f'{stem}_vignetting{tag}.png')
 
 
 def _restoration_of(matches_data: loader.MatchesData):
@@ -117,6 +142,9 @@ def _pull_results(sucre: SUCRe, resto) -> None:
         sucre.B.copy_(p[0:3].view(3, 1))
         sucre.beta.copy_(p[3:6].view(3, 1))
         sucre.gamma.copy_(p[6:9].view(3, 1))
+        if sucre.light_model:
+            sucre.cam2light.copy_(p[9:15])
+            sucre.sigma.copy_(p[15:19].view(2, 2))
         J = resto.J().to(sucre.B.device)
         if sucre.use_closed_form:
             sucre.J = J
@@ -139,6 +167,9 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
     what the reference's accumulated mini-batch gradients add up to."""
     print(f'Solve least squares with Adam optimizer ({num_iter} iterations).')
     resto = _restoration_of(matches_data)
+    if sucre.light_model and not resto.light:
+        raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
+                           'needs were not kept (call Image.match_images(..., light_model=True))')
     target = sucre.image.device_view(resto.device)
     J0 = None if sucre.use_closed_form else sucre.J.detach()
     resto.fit_init(target, params0=sucre.water_vector().cpu().numpy(), J0=J0)
@@ -175,10 +206,10 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
     if image_list is None:
         image_list = list(colmap_model.images.values())
 
-    if force_compute_matches or not matches_file.on_disk():
+    if force_compute_matches or light_model or not matches_file.on_disk():
         print(f'Compute {image.name} matches.')
         image.match_images(image_list=image_list, matches_file=matches_file, min_cover=min_cover,
-                           num_workers=num_workers, device=device)
+                           num_workers=num_workers, device=device, light_model=light_model)
         print('Prepare matches for optimization.')
         matches_file.prepare_matches(num_workers=num_workers)
     else:  # a kept matches file (ours or the reference's): consumed as is, like sucre.py:185
@@ -252,7 +283,7 @@ def build_parser() -> argparse.ArgumentParser:
     which.add_argument('--image-list', type=Path, help='text file, one image name per line')
     which.add_argument('--image-ids', type=int, nargs=2, metavar=('MIN_ID', 'MAX_ID'),
                        help='restore COLMAP image ids in [MIN_ID, MAX_ID)')
-    p.add_argument('--light-model', action='store_true', help='model artificial lighting (not in this build)')
+    p.add_argument('--light-model', action='store_true', help='model artificial lighting (light pose + beam shape)')
     p.add_argument('--use-closed-form', action='store_true',
                    help='solve J in closed form from the water parameters instead of optimising it')
     p.add_argument('--min-cover', type=float, default=0.000001,

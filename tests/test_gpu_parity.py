@@ -335,3 +335,41 @@ def test_min_cover_is_a_strict_inequality(golden):
     assert keep.tolist() == [int(x) / (sc.width * sc.height) > thr for x in n] and not keep[k]
     r.match(views[sc.target], views, min_cover=np.nextafter(thr, 0.0))
     assert bool(r.view_keep().cpu().numpy()[k])
+
+
+def _fit_light_engine(scene, T):
+    from sucre_amd import engine
+    views = engine.device_views_from_scene(scene, 'cuda')
+    r = engine.Restoration(scene.height, scene.width, len(views), light=True)
+    r.match(views[scene.target], views)
+    r.fit_init(views[scene.target])
+    trace = r.fit(T)
+    torch.cuda.synchronize()
+    return r, r.J().cpu().numpy(), r.params().cpu().numpy(), trace.cpu().numpy()
+
+
+def test_light_model_vs_oracle_short(golden):
+    """--light-model: first iterations against the oracle (tight: same analytic gradient, same inputs)."""
+    sc = golden.scene
+    r, J, params, trace = _fit_light_engine(sc, 10)
+    _, samples = helpers.oracle_scene_samples(sc)
+    tgt = sc.views[sc.target]
+    Jo, po, to = oracle.fit_light(sc.height, sc.width, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=10)
+    assert r.n_obs() == sum(len(s[0]) for s in samples)
+    assert abs(trace[0, 0] / to[0, 0] - 1) < 1e-6
+    assert np.abs(trace[:, 1:10] - to[:, 1:10]).max() < 2e-5
+    assert np.abs(trace[:, 10:] - to[:, 10:]).max() < 1e-3      # cam2light gradients sit at Adam's eps scale
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 2e-5
+    assert np.array_equal(params, trace[-1, 1:].astype(np.float32))
+
+
+def test_light_model_vs_reference_golden(golden):
+    """200 iterations against the reference's autograd run; tolerances = the reference's own batch-order noise in
+    this mode (parameters up to 1.1e-3, J 1.5e-5 RMS, cost 2e-3; tests/test_oracle_golden.py)."""
+    r, J, params, trace = _fit_light_engine(golden.scene, 200)
+    rt = golden['trace_light']
+    assert np.abs(trace[:, 1:10] - rt[:, 1:10]).max() < 3e-4
+    assert np.abs(trace[:, 10:] - rt[:, 10:]).max() < 3e-3
+    assert np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 5e-3
+    assert np.array_equal(np.isnan(J), np.isnan(golden['J_light_200']))
+    assert helpers.rms_per_channel(J, golden['J_light_200']).max() < RMS_BAR

@@ -19,7 +19,7 @@ def _f32(x):
 
 
 def test_u8_to_unit_constants_are_exact_for_all_bytes():
-    """fit.hip: unit_from_u8(k) = fma(k, hi, k*lo) must equal float32(float64(k)/255) (loader.py:157,163)."""
+    """fit_math.h: unit_from_u8(k) = fma(k, hi, k*lo) must equal float32(float64(k)/255) (loader.py:157,163)."""
     hi = np.float32(1.0 / 255.0)
     lo = np.float32(1.0 / 255.0 - np.float64(hi))
     k = np.arange(256, dtype=np.float32)
@@ -27,7 +27,7 @@ def test_u8_to_unit_constants_are_exact_for_all_bytes():
     got = (k.astype(np.float64) * np.float64(hi) + t.astype(np.float64)).astype(np.float32)  # fma: one rounding
     want = (np.arange(256, dtype=np.float64) / 255).astype(np.float32)
     assert np.array_equal(got, want)
-    src = (ROOT / 'sucre_amd' / 'csrc' / 'fit.hip').read_text()
+    src = (ROOT / 'sucre_amd' / 'csrc' / 'fit_math.h').read_text()
     assert 'kInv255Hi = (float)(1.0 / 255.0)' in src and 'kInv255Lo = (float)(1.0 / 255.0 - (double)kInv255Hi)' in src
 
 
@@ -211,10 +211,26 @@ def test_product_package_never_touches_the_oracle():
     assert bench.count('from oracle import oracle') == 1 and 'def cpu_baseline' in bench
 
 
-def test_light_model_is_refused_loudly():
-    img = sfm.Image(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), sfm.Camera(1, 8, 6, torch.eye(3)))
-    with pytest.raises(NotImplementedError, match='light'):
-        sucre.SUCRe(img, light_model=True)
+def test_light_model_torch_side_matches_reference_formula():
+    """SUCRe.compute_l_z with the light model (sucre.py:52-64), used by the output stage."""
+    class _Img(sfm.Image):
+        def get_rgb(self): return torch.rand(6, 8, 3)
+        def get_depth_map(self): return torch.ones(6, 8)
+    img = _Img(1, Path('a.png'), Path('d.png'), sfm.Pose(torch.eye(3), torch.zeros(3, 1)), sfm.Camera(1, 8, 6, torch.eye(3)))
+    m = sucre.SUCRe(img, light_model=True)
+    assert m.cam2light.shape == (6,) and torch.equal(m.sigma.detach(), torch.eye(2)) and m.water_vector().numel() == 19
+    with torch.no_grad():
+        m.cam2light.copy_(torch.tensor([0.02, -0.01, 0.03, 0.1, -0.2, 0.05])); m.sigma.copy_(torch.tensor([[1.2, 0.1], [-0.2, 0.9]]))
+    cP = torch.tensor([[0.3, -0.5, 1.0], [0.2, 0.4, -0.1], [3.0, 2.5, 3.2]])
+    l, z = m.compute_l_z(cP)
+    R, t = se3.exp(m.cam2light)
+    lP = R @ cP + t
+    lp = (lP[:2] / lP[2]).T.unsqueeze(2)
+    Sigma = m.sigma.T @ m.sigma
+    want = torch.exp(-torch.flatten(lp.transpose(1, 2) @ Sigma.inverse() @ lp) / 2)
+    assert torch.allclose(l, want, atol=1e-7) and torch.allclose(z, cP.norm(dim=0) + lP.norm(dim=0), atol=1e-6)
+    with pytest.raises(NotImplementedError, match='closed-form'):
+        sucre.SUCRe(img, light_model=True, use_closed_form=True)
 
 
 def test_output_stage_matches_reference_images(golden):
