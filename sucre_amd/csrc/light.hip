@@ -3,8 +3,8 @@
 //   R, t = se3.exp(cam2light);  Sigma = sigma^T sigma;  lP = R cP + t;  lp = lP.xy / lP.z
 //   l = exp(-(lp^T Sigma^-1 lp) / 2);   z = ||cP|| + ||lP||;   Ihat = l (J a + B (1 - g))
 //
-// The reference differentiates this with autograd; here the gradient is analytic (same formulas as the CPU oracle,
-// oracle/sucre_oracle.c::oracle_fit_light).  The model needs the camera-frame point cP of every observation, which
+// The reference differentiates this with autograd; here the gradient is analytic (derivation in DESIGN.md).
+// The model needs the camera-frame point cP of every observation, which
 // the 7-byte store of the default path does not keep, so this mode works on an EXTENSION workspace `lws`:
 // three float planes (cP.x, cP.y, cP.z) per chunk -- written by match_kernel, carried through the compaction --
 // plus the 19 parameters (B, beta, gamma, cam2light[6], sigma[4]), their Adam moments, and the reduction buffers.
