@@ -40,6 +40,7 @@ def parse():
     p.add_argument('--num-iter', type=int, default=200)
     p.add_argument('--use-closed-form', action='store_true')
     p.add_argument('--shared-water', action='store_true')
+    p.add_argument('--light-model', action='store_true', help='artificial-light model (19 parameters, 19 B/obs)')
     p.add_argument('--batch-images', type=int, default=1,
                    help='BASELINE config 3: restore this many different images of one survey per step (1 = config 2)')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -115,7 +116,7 @@ def main():
         views = engine.device_views_from_scene(scene, device)
         jobs = [(views[scene.target], views)]
     n_views = len(jobs[0][1])
-    resto = engine.Restoration(H, W, n_views, device=device)
+    resto = engine.Restoration(H, W, n_views, device=device, light=args.light_model)
     J_out = None
 
     fit_events = []
@@ -167,13 +168,13 @@ def main():
     iter_ms = fit_ms / T
     obs_passes = 2 if args.use_closed_form else 1  # closed form streams the observations twice (J, then gradient)
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
-    algo_bytes = OBS_BYTES * n_obs + state_bytes  # A_fit / T, independent of how often we re-read
+    algo_bytes = (OBS_BYTES + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
     achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
     cover = resto.view_counts().cpu().numpy() / float(W * H)
 
     traffic = None
     tf = ROOT / 'profiles' / 'r01_traffic.json'
-    if tf.exists() and not args.use_closed_form and (W, H, n_views, T) == (1920, 1080, 65, 200):
+    if tf.exists() and not args.use_closed_form and not args.light_model and (W, H, n_views, T) == (1920, 1080, 65, 200):
         rec = json.loads(tf.read_text())
         if rec.get('n_obs') == n_obs:   # same workload as the profiled one
             traffic = rec['hbm_bytes_per_launch']
@@ -190,11 +191,12 @@ def main():
             'config': {'workload': f'{len(jobs)} image(s) {W}x{H} x {n_views} views (64 neighbours + self) per step per GPU, '
                                    f'{T} Adam iterations, '
                                    + ('closed-form J' if args.use_closed_form else 'J as parameter')
+                                   + (', artificial-light model' if args.light_model else '')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_per_s_per_gpu':
                            args.steps * len(jobs) / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps / len(jobs) * 1e3 - fit_ms},
-            'roofline': {'bound': 'hbm', 'kernel': 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'light_grad_kernel' if args.light_model else 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'ms_per_launch': iter_ms,
