@@ -177,8 +177,11 @@ int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, cons
 int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream);
 int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
                          const float *params0, const float *J0_dev, void *stream);
+/* closed-form J with the illumination factor in absorption and backscatter (sucre.py:66-77 with light_model) */
+int sucre_update_J_light(void *ws, void *lws, int H, int W, int n_views, void *stream);
 int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
-                        double beta2, double eps, double *trace_dev, void *stream);
+                        double beta2, double eps, unsigned flags /* SUCRE_FIT_CLOSED_FORM or 0 */, double *trace_dev,
+                        void *stream);
 
 #ifdef __cplusplus
 }

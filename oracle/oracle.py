@@ -209,11 +209,12 @@ def se3_exp(xi) -> tuple[np.ndarray, np.ndarray]:
     return R.reshape(3, 3), t.reshape(3, 1)
 
 
-def fit_light(H: int, W: int, samples, J0: np.ndarray, params0=None, num_iter: int = 200, lr: float = 0.05):
+def fit_light(H: int, W: int, samples, J0, params0=None, num_iter: int = 200, lr: float = 0.05,
+              use_closed_form: bool = False):
     """sucre.adam with light_model=True (sucre.py:54-61, 124-157).  params: B, beta, gamma, cam2light[6], sigma[4].
     Returns (J, params (19,), trace (num_iter, 20))."""
     s = _Samples(samples)
-    J = np.ascontiguousarray(J0, np.float32).copy()
+    J = np.ascontiguousarray(J0, np.float32).copy() if J0 is not None else np.zeros((H, W, 3), np.float32)
     if params0 is None:
         params = np.concatenate([np.full(9, 0.1), np.zeros(6), [1, 0, 0, 1]]).astype(np.float32)
     else:
@@ -222,7 +223,7 @@ def fit_light(H: int, W: int, samples, J0: np.ndarray, params0=None, num_iter: i
     lib().oracle_fit_light.restype = C.c_int
     rc = lib().oracle_fit_light(C.c_int(H), C.c_int(W), C.c_int(s.n), _p(s.counts, C.c_int64), s.us, s.vs, s.cPs, s.Is,
                                 _p(J, C.c_float), _p(params, C.c_float), C.c_int(num_iter), C.c_double(lr),
-                                _p(trace, C.c_double))
+                                C.c_int(int(use_closed_form)), _p(trace, C.c_double))
     if rc != 0:
         raise MemoryError('oracle_fit_light')
     return J, params, trace

@@ -467,13 +467,43 @@ static inline void light_eval(const light_t *L, const float cP[3], float *l, flo
     *z = sqrtf(cP[0] * cP[0] + cP[1] * cP[1] + cP[2] * cP[2]) + *nl;
 }
 
+/* SUCRe.update_J with the light model (sucre.py:66-77): absorption = l a, backscatter = l B (1-g) */
+int oracle_update_J_light(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                          const int16_t *const *vs, const float *const *cPs, const float *const *Is,
+                          const float *params, float *J) {
+    const size_t npx = (size_t)H * W * 3;
+    float *num = (float *)calloc(npx, sizeof(float)), *den = (float *)calloc(npx, sizeof(float));
+    if (!num || !den) { free(num); free(den); return -1; }
+    light_t L;
+    light_setup(params, &L);
+    const float *B = params, *beta = params + 3, *gamma = params + 6;
+    for (int s = 0; s < n_samples; ++s) {
+        const int64_t n = counts[s];
+        for (int64_t i = 0; i < n; ++i) {
+            const float cP[3] = {cPs[s][i], cPs[s][n + i], cPs[s][2 * n + i]};
+            float l, z, lP[3], lp[2], nl;
+            light_eval(&L, cP, &l, &z, lP, lp, &nl);
+            const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
+            for (int c = 0; c < 3; ++c) {
+                const float a = l * expf(-beta[c] * z);
+                const float b = l * B[c] * (1.0f - expf(-gamma[c] * z));
+                num[px + c] += (Is[s][c * n + i] - b) * a;
+                den[px + c] += a * a;
+            }
+        }
+    }
+    for (size_t i = 0; i < npx; ++i) J[i] = num[i] / den[i];
+    free(num); free(den);
+    return 0;
+}
+
 /*
- * sucre.adam with light_model=True, J as parameter (sucre.py:124-157).  params: 19 floats in/out.
+ * sucre.adam with light_model=True (sucre.py:124-157); use_closed_form as in oracle_fit.  params: 19 floats in/out.
  * trace: num_iter x 20 doubles (cost, 19 parameters after the step).
  */
 int oracle_fit_light(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
                      const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
-                     float *params, int num_iter, double lr, double *trace) {
+                     float *params, int num_iter, double lr, int use_closed_form, double *trace) {
     const size_t npx = (size_t)H * W * 3;
     int64_t n_obs = 0;
     for (int s = 0; s < n_samples; ++s) n_obs += counts[s];
@@ -484,6 +514,7 @@ int oracle_fit_light(int H, int W, int n_samples, const int64_t *counts, const i
     const float scale = (1.0f / 3.0f) / (float)n_obs;
     float *B = params, *beta = params + 3, *gamma = params + 6;
     for (int it = 0; it < num_iter; ++it) {
+        if (use_closed_form && oracle_update_J_light(H, W, n_samples, counts, us, vs, cPs, Is, params, J) != 0) return -1;
         light_t L;
         light_setup(params, &L);
         memset(gJ, 0, sizeof(float) * npx);
@@ -549,12 +580,14 @@ int oracle_fit_light(int H, int W, int n_samples, const int64_t *counts, const i
         }
         const adam_coef_t co = adam_coef(it + 1, lr, 0.9, 0.999, 1e-8);
         for (int k = 0; k < 19; ++k) adam_step(&params[k], &mP[k], &vP[k], (float)g[k], &co);
-        for (size_t i = 0; i < npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
+        if (!use_closed_form)
+            for (size_t i = 0; i < npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
         if (trace) {
             trace[it * 20] = cost;
             for (int k = 0; k < 19; ++k) trace[it * 20 + 1 + k] = (double)params[k];
         }
     }
     free(gJ); free(mJ); free(vJ);
+    if (use_closed_form) return oracle_update_J_light(H, W, n_samples, counts, us, vs, cPs, Is, params, J);
     return 0;
 }

@@ -50,7 +50,8 @@ SIGNATURES = {
     'sucre_match_views_light': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
     'sucre_finalize_matches_light': (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     'sucre_fit_init_light': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
-    'sucre_fit_run_light': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp]),
+    'sucre_update_J_light': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'sucre_fit_run_light': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp, _vp]),
 }
 
 _lib = None

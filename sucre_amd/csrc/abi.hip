@@ -268,20 +268,32 @@ int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const u
     return check_hip(launch_light_init(L, static_cast<uint8_t *>(lws), params0, s), "sucre_fit_init_light");
 }
 
+int sucre_update_J_light(void *ws, void *lws, int H, int W, int n_views, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
+                                           static_cast<hipStream_t>(stream)), "sucre_update_J_light");
+}
+
 int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
-                        double beta2, double eps, double *trace_dev, void *stream) {
+                        double beta2, double eps, unsigned flags, double *trace_dev, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (int rc = check_lws(lws)) return rc;
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
+    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
-        if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co,
+        if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co, flags,
                                                  trace_dev ? trace_dev + (size_t)it * 20 : nullptr,
                                                  static_cast<hipStream_t>(stream)), "sucre_fit_run_light")) return rc;
     }
+    if (flags & SUCRE_FIT_CLOSED_FORM)  // the final update_J of sucre.py:156
+        return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
+                                               static_cast<hipStream_t>(stream)), "sucre_fit_run_light/update_J");
     return SUCRE_OK;
 }
 

@@ -119,12 +119,54 @@ __global__ __launch_bounds__(512) void light_init_kernel(float *pstate, float *g
     light_geometry(pstate, geom, S, T, E, P);
 }
 
+// geometry of whatever parameters are stored now (the caller may have written them since the last step)
+__global__ __launch_bounds__(512) void light_geometry_kernel(const float *pstate, float *geom) {
+    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
+    light_geometry(pstate, geom, S, T, E, P);
+}
+
 // ---- gradient pass ---------------------------------------------------------------------------------------------------
 struct LightAcc {
     float pa[3][4], pb[3][4];      // per pixel-channel: sum r l a ; sum r l a z
     float s[kLightSums];           // thread-level global sums (slots 6..8 = sBeta are filled per tile)
 };
 
+// l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
+struct LightObs { float l, z, nl, lp0, lp1, lP[3]; };
+
+__device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const float (&R)[9], const float (&tl)[3],
+                                              const float (&M)[4]) {
+    LightObs o;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        o.lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], R[a * 3] * cP[0])) + tl[a];
+    o.lp0 = o.lP[0] / o.lP[2];
+    o.lp1 = o.lP[1] / o.lP[2];
+    const float q = o.lp0 * (M[0] * o.lp0 + M[1] * o.lp1) + o.lp1 * (M[2] * o.lp0 + M[3] * o.lp1);
+    o.l = fast_exp2(q * (-0.5f * kLog2e));
+    o.nl = sqrtf(o.lP[0] * o.lP[0] + o.lP[1] * o.lP[1] + o.lP[2] * o.lP[2]);
+    o.z = zc + o.nl;
+    return o;
+}
+
+struct LightChunk { float zz[4], xx[4], yy[4], ww[4]; uint32_t cc[3]; };
+
+__device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *tobs, const uint8_t *text, uint32_t lv, int lane) {
+    const uint8_t *ch = tobs + (size_t)lv * kChunk;
+    const float *ex = reinterpret_cast<const float *>(text + (size_t)lv * kExtChunk);
+    const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + kChunkZ) + lane;
+    const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
+    const float4 y4 = *reinterpret_cast<const float4 *>(ex + kTilePx + lane * 4);
+    const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kTilePx + lane * 4);
+    LightChunk c = {{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
+                    {cp[0], cp[64], cp[128]}};
+    return c;
+}
+
+// kClosed: J is re-solved in closed form at the top of the iteration (sucre.py:141, 66-77 with absorption = l a,
+// backscatter = l B (1 - g)) and is a constant of the gradient; kJOnly: only that closed-form J (final update_J).
+template <bool kClosed, bool kJOnly>
 __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restrict__ comp, const uint8_t *__restrict__ ext,
                                                          const uint64_t *__restrict__ tile_off,
                                                          const uint32_t *__restrict__ levels, int n_tiles,
@@ -134,6 +176,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                                                          float *__restrict__ vt, float *__restrict__ partials,
                                                          const AdamCoef co) {
     __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
+    __shared__ __attribute__((aligned(16))) float jbuf[3][kTilePx];
     __shared__ float wsum[4][kLightSums];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -162,45 +205,77 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         const uint8_t *text = ext + (tile_off[tile] / kChunk) * kExtChunk;
         float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
         float J[3][4];
+        if (kClosed) {
+            // closed-form J of the tile: numerator / denominator per pixel-channel over all levels
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
-            J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
+            for (uint32_t lv = wave; lv < n; lv += 4) {
+                const LightChunk k = load_light_chunk(tobs, text, lv, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!(k.zz[j] > 0.0f)) continue;
+                    const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
+                    const LightObs o = light_obs(cP, k.zz[j], R, tl, M);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float a = o.l * fast_exp2(o.z * nb[c]);
+                        const float b = o.l * B[c] * (1.0f - fast_exp2(o.z * ng[c]));
+                        const float I = unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
+                        acc.pa[c][j] = __builtin_fmaf(I - b, a, acc.pa[c][j]);
+                        acc.pb[c][j] = __builtin_fmaf(a, a, acc.pb[c][j]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) = make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
+                *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) = make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float num = ((red[0][c][t] + red[1][c][t]) + red[2][c][t]) + red[3][c][t];
+                const float den = ((red[0][3 + c][t] + red[1][3 + c][t]) + red[2][3 + c][t]) + red[3][3 + c][t];
+                const float Jc = num / den;  // 0/0 = NaN where nothing was observed
+                Jtile[c * kTilePx + t] = Jc;
+                jbuf[c][t] = Jc;
+            }
+            __syncthreads();
+            if (kJOnly) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(&jbuf[c][lane * 4]);
+                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
-        }
         for (uint32_t lv = wave; lv < n; lv += 4) {
-            const uint8_t *ch = tobs + (size_t)lv * kChunk;
-            const float *ex = reinterpret_cast<const float *>(text + (size_t)lv * kExtChunk);
-            const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
-            const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + kChunkZ) + lane;
-            const uint32_t cc[3] = {cp[0], cp[64], cp[128]};
-            const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
-            const float4 y4 = *reinterpret_cast<const float4 *>(ex + kTilePx + lane * 4);
-            const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kTilePx + lane * 4);
-            const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
-            const float yy[4] = {y4.x, y4.y, y4.z, y4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+            const LightChunk k = load_light_chunk(tobs, text, lv, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (!(zz[j] > 0.0f)) continue;  // padding slot
-                const float cP[3] = {xx[j], yy[j], ww[j]};
-                // sucre.py:55-61
-                float lP[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], R[a * 3] * cP[0])) + tl[a];
-                const float lp0 = lP[0] / lP[2], lp1 = lP[1] / lP[2];
-                const float q = lp0 * (M[0] * lp0 + M[1] * lp1) + lp1 * (M[2] * lp0 + M[3] * lp1);
-                const float l = fast_exp2(q * (-0.5f * kLog2e));
-                const float nl = sqrtf(lP[0] * lP[0] + lP[1] * lP[1] + lP[2] * lP[2]);
-                const float z = zz[j] + nl;
+                if (!(k.zz[j] > 0.0f)) continue;  // padding slot
+                const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
+                const LightObs o = light_obs(cP, k.zz[j], R, tl, M);
+                const float l = o.l, z = o.z;
                 float dl = 0.f, dz = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float a = fast_exp2(z * nb[c]), g = fast_exp2(z * ng[c]);
                     const float omg = 1.0f - g;
                     const float E = __builtin_fmaf(J[c][j], a, B[c] * omg);
-                    const float I = unit_from_u8((cc[c] >> (8 * j)) & 255u);
+                    const float I = unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
                     const float r = I - l * E;
                     const float rl = r * l;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
@@ -212,27 +287,27 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     dz = __builtin_fmaf(rl, gamma[c] * B[c] * g - beta[c] * J[c][j] * a, dz);
                 }
                 // chain rule into lP (common factor -2 s applied in the step kernel)
-                const float k = dl * (-0.5f * l);
-                const float dlp0 = k * ((M[0] * lp0 + M[1] * lp1) + (M[0] * lp0 + M[2] * lp1));
-                const float dlp1 = k * ((M[2] * lp0 + M[3] * lp1) + (M[1] * lp0 + M[3] * lp1));
-                const float iz = 1.0f / lP[2], inl = 1.0f / nl;
+                const float kk = dl * (-0.5f * l);
+                const float dlp0 = kk * ((M[0] * o.lp0 + M[1] * o.lp1) + (M[0] * o.lp0 + M[2] * o.lp1));
+                const float dlp1 = kk * ((M[2] * o.lp0 + M[3] * o.lp1) + (M[1] * o.lp0 + M[3] * o.lp1));
+                const float iz = 1.0f / o.lP[2], inl = 1.0f / o.nl;
                 float dlP[3];
-                dlP[0] = dz * lP[0] * inl + dlp0 * iz;
-                dlP[1] = dz * lP[1] * inl + dlp1 * iz;
-                dlP[2] = dz * lP[2] * inl - (dlp0 * lP[0] + dlp1 * lP[1]) * iz * iz;
+                dlP[0] = dz * o.lP[0] * inl + dlp0 * iz;
+                dlP[1] = dz * o.lP[1] * inl + dlp1 * iz;
+                dlP[2] = dz * o.lP[2] * inl - (dlp0 * o.lP[0] + dlp1 * o.lP[1]) * iz * iz;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     acc.s[19 + a] += dlP[a];
 #pragma unroll
                     for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
                 }
-                acc.s[22] = __builtin_fmaf(k * lp0, lp0, acc.s[22]);
-                acc.s[23] = __builtin_fmaf(k * lp0, lp1, acc.s[23]);
-                acc.s[24] = __builtin_fmaf(k * lp1, lp0, acc.s[24]);
-                acc.s[25] = __builtin_fmaf(k * lp1, lp1, acc.s[25]);
+                acc.s[22] = __builtin_fmaf(kk * o.lp0, o.lp0, acc.s[22]);
+                acc.s[23] = __builtin_fmaf(kk * o.lp0, o.lp1, acc.s[23]);
+                acc.s[24] = __builtin_fmaf(kk * o.lp1, o.lp0, acc.s[24]);
+                acc.s[25] = __builtin_fmaf(kk * o.lp1, o.lp1, acc.s[25]);
             }
         }
-        // per-pixel sums of the four waves (fixed order), then the pixel-parallel Adam step on J
+        // per-pixel sums of the four waves (fixed order), then the pixel-parallel tail
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -245,13 +320,18 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         for (int c = 0; c < 3; ++c) {
             const float ta = ((red[0][c][t] + red[1][c][t]) + red[2][c][t]) + red[3][c][t];
             const float tb = ((red[0][3 + c][t] + red[1][3 + c][t]) + red[2][3 + c][t]) + red[3][3 + c][t];
-            float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
-            acc.s[6 + c] += (tb == 0.0f) ? 0.0f : Jc * tb;
-            adam_update(Jc, m, v, gscale * ta, co);
-            Jtile[c * kTilePx + t] = Jc; mtile[c * kTilePx + t] = m; vtile[c * kTilePx + t] = v;
+            if (kClosed) {
+                acc.s[6 + c] += (tb == 0.0f) ? 0.0f : jbuf[c][t] * tb;
+            } else {
+                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
+                acc.s[6 + c] += (tb == 0.0f) ? 0.0f : Jc * tb;
+                adam_update(Jc, m, v, gscale * ta, co);
+                Jtile[c * kTilePx + t] = Jc; mtile[c * kTilePx + t] = m; vtile[c * kTilePx + t] = v;
+            }
         }
         __syncthreads();
     }
+    if (kJOnly) return;
     // workgroup sums: shuffle tree, then the four waves in fixed order
 #pragma unroll
     for (int q = 0; q < kLightSums; ++q) {
@@ -386,8 +466,29 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     return hipGetLastError();
 }
 
-hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, double *trace_row,
-                             hipStream_t s) {
+template <bool kClosed, bool kJOnly>
+static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
+                              hipStream_t s) {
+    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+                       lws + X.off_ext_comp, reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_levels), L.n_tiles,
+                       reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
+                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
+                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(lws + X.off_partials), co);
+}
+
+hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, hipStream_t s) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(512), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
+                       reinterpret_cast<float *>(lws + X.off_geom));
+    launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, unsigned flags,
+                             double *trace_row, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
     float *pstate = reinterpret_cast<float *>(lws + X.off_params);
@@ -395,11 +496,8 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
     float *partials = reinterpret_cast<float *>(lws + X.off_partials);
     double *sums = reinterpret_cast<double *>(lws + X.off_sums);
     auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
-    hipLaunchKernelGGL(light_grad_kernel, dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp, lws + X.off_ext_comp,
-                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_levels), L.n_tiles, pstate, geom, nobs,
-                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
-                       reinterpret_cast<float *>(ws + L.off_v), partials, co);
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, co, s);
+    else launch_light_grad<false, false>(L, X, ws, lws, co, s);
     hipLaunchKernelGGL(light_reduce_kernel, dim3(1), dim3(256), 0, s, partials, L.n_blocks, sums);
     hipLaunchKernelGGL(light_step_kernel, dim3(1), dim3(512), 0, s, sums, pstate, geom, nobs, co, trace_row);
     return hipGetLastError();

@@ -27,6 +27,15 @@ class DeviceView:
     name: str = ''
 
     def to_struct(self) -> _lib.SucreView:
+        """sucre_view_t of this view (cached: the matrices are derived once per view, not once per target image)."""
+        cached = self.__dict__.get('_struct')
+        if cached is not None and cached[0] == (self.depth.data_ptr(), self.rgb.data_ptr()):
+            return cached[1]
+        s = self._build_struct()
+        self.__dict__['_struct'] = ((self.depth.data_ptr(), self.rgb.data_ptr()), s)
+        return s
+
+    def _build_struct(self) -> _lib.SucreView:
         H, W = self.depth.shape
         assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
         assert self.rgb.dtype == torch.uint8 and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
@@ -192,11 +201,9 @@ class Restoration:
         tp = C.c_void_p(trace.data_ptr()) if trace is not None else None
         with torch.cuda.device(self.device):
             if self.light:
-                if use_closed_form:
-                    raise NotImplementedError('--light-model together with --use-closed-form is not built yet')
                 _lib.check(self.lib.sucre_fit_run_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self.steps_done,
                                                         int(num_iter), float(lr), float(betas[0]), float(betas[1]),
-                                                        float(eps), tp, _stream_ptr()))
+                                                        float(eps), flags, tp, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_fit_run(ws, H, W, n, self.steps_done, int(num_iter), float(lr),
                                                   float(betas[0]), float(betas[1]), float(eps), flags, tp,
@@ -208,7 +215,10 @@ class Restoration:
     def update_J(self) -> None:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.sucre_update_J(ws, H, W, n, _stream_ptr()))
+            if self.light:
+                _lib.check(self.lib.sucre_update_J_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, _stream_ptr()))
+            else:
+                _lib.check(self.lib.sucre_update_J(ws, H, W, n, _stream_ptr()))
 
     def params(self) -> torch.Tensor:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""

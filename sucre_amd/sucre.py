@@ -34,8 +34,6 @@ class SUCRe(torch.nn.Module):
 
     def __init__(self, image: sfm.Image, light_model: bool = False, use_closed_form: bool = False):
         super().__init__()
-        if light_model and use_closed_form:
-            raise NotImplementedError('--light-model together with --use-closed-form is not built yet')
         self.image = image
         self.light_model = light_model
         self.use_closed_form = use_closed_form

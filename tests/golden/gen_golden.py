@@ -82,6 +82,9 @@ def generate(name, spec):
     fitl = quiet(rh.reference_fit, scene, md, target, num_iter=200, light_model=True, batch_size=5)
     out['J_light_200'] = fitl['J']
     out['trace_light'] = fitl['trace']
+    fitlc = quiet(rh.reference_fit, scene, md, target, num_iter=100, light_model=True, use_closed_form=True, batch_size=5)
+    out['J_light_closed_100'] = fitlc['J']
+    out['trace_light_closed'] = fitlc['trace']
     # shared-water extension: this image and its left neighbour fitted in lock-step with tied B, beta, gamma
     import copy
     other = copy.copy(scene)

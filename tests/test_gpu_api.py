@@ -238,3 +238,23 @@ def test_cli_light_model(disk_scene, tmp_path, capsys):
     assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 2e-5
     got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma', 'cam2light', 'sigma')])
     assert np.abs(got[:9] - po[:9]).max() < 2e-5 and np.abs(got[9:] - po[9:]).max() < 1e-3
+
+
+def test_cli_light_model_closed_form(disk_scene, tmp_path):
+    """--light-model --use-closed-form end to end, with intermediate plots (the stand-alone light update_J)."""
+    from sucre_amd import sucre
+    root, scene, model, loaded = disk_scene
+    name = scene.names[scene.target]
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(tmp_path), '--image-name', name, '--num-iter', '12', '--light-model',
+                '--use-closed-form', '--save-interval', '5'])
+    stem = Path(name).stem
+    state = torch.load(tmp_path / f'{stem}.pt')
+    assert set(state) == {'B', 'beta', 'gamma', 'cam2light', 'sigma', 'J'}     # sucre.py:213-215 always stores J
+    _, samples = helpers.oracle_scene_samples(loaded)
+    Jo, po, to = oracle.fit_light(64, 96, samples, None, num_iter=12, use_closed_form=True)
+    J = state['J'].numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-4
+    got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma', 'cam2light', 'sigma')])
+    assert np.abs(got[:9] - po[:9]).max() < 5e-5 and np.abs(got[9:] - po[9:]).max() < 1e-3
+    assert len(list(tmp_path.glob('**/*.png'))) >= 3

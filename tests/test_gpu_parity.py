@@ -337,13 +337,13 @@ def test_min_cover_is_a_strict_inequality(golden):
     assert bool(r.view_keep().cpu().numpy()[k])
 
 
-def _fit_light_engine(scene, T):
+def _fit_light_engine(scene, T, closed=False):
     from sucre_amd import engine
     views = engine.device_views_from_scene(scene, 'cuda')
     r = engine.Restoration(scene.height, scene.width, len(views), light=True)
     r.match(views[scene.target], views)
     r.fit_init(views[scene.target])
-    trace = r.fit(T)
+    trace = r.fit(T, use_closed_form=closed)
     torch.cuda.synchronize()
     return r, r.J().cpu().numpy(), r.params().cpu().numpy(), trace.cpu().numpy()
 
@@ -373,3 +373,32 @@ def test_light_model_vs_reference_golden(golden):
     assert np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 5e-3
     assert np.array_equal(np.isnan(J), np.isnan(golden['J_light_200']))
     assert helpers.rms_per_channel(J, golden['J_light_200']).max() < RMS_BAR
+
+
+
+def test_light_model_closed_form_vs_oracle(golden):
+    """--light-model --use-closed-form: J re-solved each iteration with l in absorption and backscatter
+    (sucre.py:66-77, 141, 156). Tight against the oracle over the first iterations."""
+    sc = golden.scene
+    _, samples = helpers.oracle_scene_samples(sc)
+    r, J, params, trace = _fit_light_engine(sc, 10, closed=True)
+    Jo, po, to = oracle.fit_light(sc.height, sc.width, samples, None, num_iter=10, use_closed_form=True)
+    assert abs(trace[0, 0] / to[0, 0] - 1) < 1e-5
+    assert np.abs(trace[:, 1:10] - to[:, 1:10]).max() < 5e-5
+    assert np.abs(trace[:, 10:] - to[:, 10:]).max() < 1e-3
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < RMS_BAR
+
+
+def test_light_model_closed_form_vs_reference_golden(golden):
+    """100 iterations against the reference. This mode is chaotic in the reference itself on the relief fixture
+    (two batch orders differ by 2.8e-3 in the water parameters, 1.8e-2 RMS in red J; tests/test_oracle_golden.py),
+    so: tight over the first 50 iterations and in G/B, bounded by that self-noise elsewhere."""
+    r, J, params, trace = _fit_light_engine(golden.scene, 100, closed=True)
+    rt = golden['trace_light_closed']
+    assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-5
+    assert np.abs(trace[:50, 1:] - rt[:50, 1:]).max() < 5e-4
+    assert np.abs(trace[:50, 0] / rt[:50, 0] - 1).max() < 5e-4
+    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 1e-2
+    Jr = golden['J_light_closed_100']
+    rms = helpers.rms_per_channel(J, Jr)
+    assert np.array_equal(np.isnan(J), np.isnan(Jr)) and rms[1:].max() < 2e-4 and rms[0] < 5e-2

@@ -145,3 +145,20 @@ def test_se3_exp_matches_reference_values():
         R, t = oracle.se3_exp(xi)
         Rt, tt = se3.exp(torch.tensor(xi, dtype=torch.float32))
         assert np.abs(R - Rt.numpy()).max() < 5e-7 and np.abs(t - tt.numpy()).max() < 1e-6
+
+
+def test_light_model_with_closed_form_J(golden):
+    """--light-model --use-closed-form (sucre.py:66-77 with l != 1).  On the relief fixture this trajectory is chaotic
+    in the reference itself after ~70 iterations (red backscatter goes negative; its own batch-1 vs batch-5 runs
+    differ by 2.8e-3 in the water parameters and 1.8e-2 RMS in J's red channel), so: tight over the first 50
+    iterations, bounded by that self-noise afterwards."""
+    sc = golden.scene
+    _, samples = helpers.oracle_scene_samples(sc)
+    J, params, trace = oracle.fit_light(sc.height, sc.width, samples, None, num_iter=100, use_closed_form=True)
+    rt = golden['trace_light_closed']
+    assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-5
+    assert np.abs(trace[:50, 1:] - rt[:50, 1:]).max() < 2e-4 and np.abs(trace[:50, 0] / rt[:50, 0] - 1).max() < 1e-4
+    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 1e-2
+    assert np.array_equal(np.isnan(J), np.isnan(golden['J_light_closed_100']))
+    rms = helpers.rms_per_channel(J, golden['J_light_closed_100'])
+    assert rms[1:].max() < 1e-4 and rms[0] < 5e-2
