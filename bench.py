@@ -3,7 +3,9 @@
 
 A step = one full restoration of one synthetic 1920x1080 image against 65 views (64 neighbours + itself):
 match all views -> min_cover/finalize -> init -> 200 Adam iterations -> export J, with every input already
-resident in HBM.  N>1: one process per GPU (torchrun contract), every rank restores its own image of the scene
+resident in HBM.  Consecutive steps are kept in flight two at a time (own HIP stream + own workspace each,
+engine.in_flight_slot): the 200 launches of one fit depend on each other, so a second image fills their ramp-up
+and tails; the roofline block times the kernel of one image restored alone.  N>1: one process per GPU (torchrun contract), every rank restores its own image of the scene
 (per-image mode of the reference: no data-path collective, weak scaling); --shared-water adds the one
 all-reduce per iteration of the shared-water extension.
 
@@ -43,6 +45,9 @@ def parse():
     p.add_argument('--light-model', action='store_true', help='artificial-light model (19 parameters, 19 B/obs)')
     p.add_argument('--batch-images', type=int, default=1,
                    help='BASELINE config 3: restore this many different images of one survey per step (1 = config 2)')
+    p.add_argument('--images-in-flight', type=int, default=2,
+                   help='consecutive images (steps) kept in flight on their own HIP streams + workspaces '
+                        '(engine.in_flight_slot); 1 = strictly one image at a time')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=9, help='views in the CPU-baseline sample')
     p.add_argument('--cpu-iters', type=int, default=5, help='Adam iterations in the CPU-baseline sample')
@@ -116,8 +121,14 @@ def main():
         views = engine.device_views_from_scene(scene, device)
         jobs = [(views[scene.target], views)]
     n_views = len(jobs[0][1])
-    resto = engine.Restoration(H, W, n_views, device=device, light=args.light_model)
-    J_out = None
+    # images in flight: slot s = own workspace + own HIP stream; image i goes to slot i % S, so consecutive images
+    # overlap (the launches of one fit depend on each other; a second image fills their ramp-up and tails)
+    S = 1 if args.shared_water else max(1, args.images_in_flight)
+    restos = [engine.Restoration(H, W, n_views, device=device, light=args.light_model) for _ in range(S)]
+    streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(device)]
+    resto = restos[0]
+    J_out = [None] * S
+    submitted = 0
 
     fit_events = []
 
@@ -125,8 +136,15 @@ def main():
         for tgt, views in jobs:
             restore_one(tgt, views, record)
 
-    def restore_one(tgt, views, record):
-        nonlocal J_out
+    def restore_one(tgt, views, record, slot=None):
+        nonlocal submitted
+        if slot is None:
+            slot = submitted % S
+            submitted += 1
+        with torch.cuda.stream(streams[slot]):
+            restore_on(restos[slot], slot, tgt, views, record)
+
+    def restore_on(resto, slot, tgt, views, record):
         resto.match(tgt, views, min_cover=1e-6)
         resto.fit_init(tgt)
         if record:
@@ -142,7 +160,7 @@ def main():
         if record:
             e1.record()
             fit_events.append((e0, e1))
-        J_out = resto.J()
+        J_out[slot] = resto.J()
 
     def barrier():
         torch.cuda.synchronize()
@@ -150,9 +168,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()   # the scene was uploaded on the default stream; the slots have their own
+    for slot in range(args.warmup * len(jobs), S):   # setup: slots the W warmup steps will not reach run once too
+        restore_one(*jobs[0], False, slot=slot)
     for _ in range(args.warmup):
         step(False)
     barrier()
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -164,8 +187,27 @@ def main():
         elapsed = float(te.item())
 
     n_obs = resto.n_obs()
+    n_fits = len(fit_events)
+    if S > 1:
+        # the fits of different slots overlap: what the timed region sustained is the union of their intervals
+        spans = sorted((base.elapsed_time(a), base.elapsed_time(b)) for a, b in fit_events)
+        union, lo, hi = 0.0, spans[0][0], spans[0][1]
+        for a, b in spans[1:]:
+            if a > hi:
+                union, lo, hi = union + hi - lo, a, b
+            else:
+                hi = max(hi, b)
+        union += hi - lo
+        effective_iter_ms = union / (n_fits * T)
+        # the kernel by itself (what rocprofv3 shows for a lone launch): one more image, alone on the GPU, after
+        # the timed region
+        fit_events.clear()
+        restore_one(*jobs[0], True, slot=0)
+        torch.cuda.synchronize()
     fit_ms = sum(a.elapsed_time(b) for a, b in fit_events) / len(fit_events)
     iter_ms = fit_ms / T
+    if S == 1:
+        effective_iter_ms = iter_ms
     obs_passes = 2 if args.use_closed_form else 1  # closed form streams the observations twice (J, then gradient)
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
     algo_bytes = (OBS_BYTES + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
@@ -194,12 +236,18 @@ def main():
                                    + (', artificial-light model' if args.light_model else '')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
-                       'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_per_s_per_gpu':
-                           args.steps * len(jobs) / elapsed, 'fit_ms': fit_ms, 'match_init_export_ms': elapsed / args.steps / len(jobs) * 1e3 - fit_ms},
+                       'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S,
+                       'images_per_s_per_gpu': args.steps * len(jobs) / elapsed, 'fit_ms_alone': fit_ms,
+                       'ms_per_image': elapsed / args.steps / len(jobs) * 1e3},
             'roofline': {'bound': 'hbm', 'kernel': 'light_grad_kernel' if args.light_model else 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'ms_per_launch': iter_ms,
+                         'measured': ('HIP events around the 200 launches of one image restored alone after the timed '
+                                      'region (the timed region overlaps images)') if S > 1 else
+                                     'HIP events around the 200 launches of every image in the timed region',
+                         'timed_region_ms_per_launch': effective_iter_ms,
+                         'timed_region_frac': algo_bytes / (effective_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'obs_passes_per_launch': obs_passes},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -93,8 +93,11 @@ class Image:
         if self._device_view is None or self._device_view[0] != dev:
             rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
             depth = self.get_depth_map()
-            self._device_view = (dev, engine.DeviceView(depth=depth.to(dev).contiguous(), rgb=rgb.to(dev).contiguous(),
-                                                        K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name))
+            view = engine.DeviceView(depth=depth.to(dev).contiguous(), rgb=rgb.to(dev).contiguous(),
+                                     K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
+            if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
+                torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
+            self._device_view = (dev, view)
         return self._device_view[1]
 
     def release_device(self) -> None:

@@ -14,6 +14,7 @@ Under ``torchrun`` (WORLD_SIZE > 1) the images to restore are sharded over the r
 from __future__ import annotations
 
 import argparse
+import os
 from pathlib import Path
 
 import numpy as np
@@ -164,13 +165,7 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
     ``batch_size`` is accepted for compatibility: the engine always uses the full batch in one pass, which is
     what the reference's accumulated mini-batch gradients add up to."""
     print(f'Solve least squares with Adam optimizer ({num_iter} iterations).')
-    resto = _restoration_of(matches_data)
-    if sucre.light_model and not resto.light:
-        raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
-                           'needs were not kept (call Image.match_images(..., light_model=True))')
-    target = sucre.image.device_view(resto.device)
-    J0 = None if sucre.use_closed_form else sucre.J.detach()
-    resto.fit_init(target, params0=sucre.water_vector().cpu().numpy(), J0=J0)
+    resto = _adam_begin(sucre, matches_data)
     if save_dir is not None and save_interval is not None:
         stops = sorted({min(k + 1, num_iter) for k in range(0, num_iter, save_interval)} | {num_iter})
     else:
@@ -191,12 +186,28 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
     return sucre
 
 
-def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool = False,
-                  use_closed_form: bool = False, min_cover: float = 0.000001, image_list: list[sfm.Image] = None,
-                  lr: float = 0.05, num_iter: int = 200, batch_size: int = 1, save_interval: int = None,
-                  params_path: Path = None, force_compute_matches: bool = False, keep_matches: bool = False,
-                  num_workers: int = 0, device: str = 'cuda'):
-    """Per-image pipeline (sucre.py:160-219): match -> prepare -> check -> load -> fit -> save."""
+def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData):
+    resto = _restoration_of(matches_data)
+    if sucre.light_model and not resto.light:
+        raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
+                           'needs were not kept (call Image.match_images(..., light_model=True))')
+    target = sucre.image.device_view(resto.device)
+    J0 = None if sucre.use_closed_form else sucre.J.detach()
+    resto.fit_init(target, params0=sucre.water_vector().detach().cpu().numpy(), J0=J0)
+    return resto
+
+
+class _Job:
+    """One image between ``_restore_submit`` (everything enqueued, nothing waited for) and ``_restore_finish``."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _restore_submit(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool,
+                    use_closed_form: bool, min_cover: float, image_list: list[sfm.Image], lr: float, num_iter: int,
+                    params_path: Path, force_compute_matches: bool, num_workers: int, device: str) -> _Job:
+    """Stages of sucre.py:160-210 up to and including the enqueued fit; the trace and J stay on the device."""
     print(f'Restore {image.name}.')
     output_dir = Path(output_dir)
     matches_path = (output_dir / image.name).with_suffix('.h5')
@@ -223,19 +234,68 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
     sucre = SUCRe(image=image, light_model=light_model, use_closed_form=use_closed_form).to(device)
     if params_path is not None:
         sucre.load_state_dict(torch.load(params_path), strict=False)
+    return _Job(image=image, sucre=sucre, matches_file=matches_file, matches_data=matches_data,
+                matches_path=matches_path, output_dir=output_dir, lr=lr, num_iter=num_iter, trace=None)
 
-    adam(sucre=sucre, matches_data=matches_data, lr=lr, num_iter=num_iter, batch_size=batch_size,
-         save_dir=output_dir, save_interval=save_interval, device=device)
 
-    sucre.save_plots(save_dir=output_dir)
-    torch.save({**sucre.cpu().state_dict(), 'J': sucre.J.detach().cpu()}, (output_dir / image.name).with_suffix('.pt'))
+def _restore_enqueue_fit(job: _Job) -> None:
+    """The whole fit of sucre.py:138-156 enqueued in one go (no intermediate plots): no host synchronisation."""
+    print(f'Solve least squares with Adam optimizer ({job.num_iter} iterations).')
+    resto = _adam_begin(job.sucre, job.matches_data)
+    job.trace = resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
+
+
+def _restore_finish(job: _Job, keep_matches: bool) -> SUCRe:
+    sucre = job.sucre
+    if job.trace is not None:
+        _log_trace(job.trace.cpu().numpy(), 0)
+        _pull_results(sucre, _restoration_of(job.matches_data))
+    sucre.save_plots(save_dir=job.output_dir)
+    torch.save({**sucre.cpu().state_dict(), 'J': sucre.J.detach().cpu()},
+               (job.output_dir / job.image.name).with_suffix('.pt'))
     if keep_matches:
-        if matches_file.restoration._views_dev is not None:   # freshly matched (not loaded from this very file)
-            print(f'Keep {matches_file.save()}.')
-    elif matches_path.exists():
-        print(f'Erase {matches_path}.')
-        matches_path.unlink()
+        if job.matches_file.restoration._views_dev is not None:   # freshly matched (not loaded from this very file)
+            print(f'Keep {job.matches_file.save()}.')
+    elif job.matches_path.exists():
+        print(f'Erase {job.matches_path}.')
+        job.matches_path.unlink()
     return sucre
+
+
+def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool = False,
+                  use_closed_form: bool = False, min_cover: float = 0.000001, image_list: list[sfm.Image] = None,
+                  lr: float = 0.05, num_iter: int = 200, batch_size: int = 1, save_interval: int = None,
+                  params_path: Path = None, force_compute_matches: bool = False, keep_matches: bool = False,
+                  num_workers: int = 0, device: str = 'cuda'):
+    """Per-image pipeline (sucre.py:160-219): match -> prepare -> check -> load -> fit -> save."""
+    job = _restore_submit(image, colmap_model, output_dir, light_model, use_closed_form, min_cover, image_list, lr,
+                          num_iter, params_path, force_compute_matches, num_workers, device)
+    adam(sucre=job.sucre, matches_data=job.matches_data, lr=lr, num_iter=num_iter, batch_size=batch_size,
+         save_dir=job.output_dir, save_interval=save_interval, device=device)
+    return _restore_finish(job, keep_matches)
+
+
+def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, output_dir: Path, in_flight: int = 2,
+                   keep_matches: bool = False, device: str = 'cuda', **kw) -> None:
+    """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot).
+    While image i iterates, image i+1 is matched and submitted and image i-1's plots are written by the host, so
+    neither the tails of the fit launches nor the PNG encoding leave the GPU idle.  Per-image results are the
+    same bits as ``restore_image`` (each image has its own workspace and stream; nothing is shared)."""
+    from . import engine
+    pending: list[tuple[int, _Job]] = []
+    for i, image in enumerate(images):
+        slot = i % in_flight
+        while pending and (len(pending) >= in_flight or pending[0][0] == slot):
+            s, job = pending.pop(0)
+            with engine.in_flight_slot(s, device):
+                _restore_finish(job, keep_matches)
+        with engine.in_flight_slot(slot, device):
+            job = _restore_submit(image, colmap_model, output_dir, device=device, **kw)
+            _restore_enqueue_fit(job)
+        pending.append((slot, job))
+    for s, job in pending:
+        with engine.in_flight_slot(s, device):
+            _restore_finish(job, keep_matches)
 
 
 def parse_args(args: argparse.Namespace):
@@ -260,6 +320,14 @@ def parse_args(args: argparse.Namespace):
     skipped = set(args.filter_images_path.read_text().splitlines()) if args.filter_images_path else set()
     image_list = [im for im in colmap_model.images.values() if im.name not in skipped]
     args.output_dir.mkdir(parents=True, exist_ok=True)
+    in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
+    if len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda'):
+        restore_images(images, colmap_model, args.output_dir, in_flight=in_flight, keep_matches=args.keep_matches,
+                       device=device, light_model=args.light_model, use_closed_form=args.use_closed_form,
+                       min_cover=args.min_cover, image_list=image_list, lr=args.learning_rate, num_iter=args.num_iter,
+                       params_path=args.params_path, force_compute_matches=args.force_compute_matches,
+                       num_workers=args.num_workers)
+        return
     for image in images:
         restore_image(image=image, colmap_model=colmap_model, output_dir=args.output_dir,
                       light_model=args.light_model, use_closed_form=args.use_closed_form, min_cover=args.min_cover,

@@ -258,3 +258,32 @@ def test_cli_light_model_closed_form(disk_scene, tmp_path):
     got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma', 'cam2light', 'sigma')])
     assert np.abs(got[:9] - po[:9]).max() < 5e-5 and np.abs(got[9:] - po[9:]).max() < 1e-3
     assert len(list(tmp_path.glob('**/*.png'))) >= 3
+
+
+def test_cli_images_in_flight_equal_one_by_one(disk_scene, tmp_path, monkeypatch):
+    """A survey through the CLI with two images in flight (engine.in_flight_slot: own stream + own workspace per
+    slot) must write the same bits as strictly sequential restoration -- images are independent problems
+    (sucre.py:204, 243) and the engine's reductions have a fixed order."""
+    from sucre_amd import sucre
+    root, scene, model, loaded = disk_scene
+    base = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+            '--image-ids', '1', '6', '--num-iter', '25']
+    outs = {}
+    for mode in ('2', '1', '3'):
+        monkeypatch.setenv('SUCRE_IMAGES_IN_FLIGHT', mode)
+        out = tmp_path / f'inflight{mode}'
+        sucre.main(base + ['--output-dir', str(out)])
+        outs[mode] = {p.name: torch.load(p) for p in sorted(out.glob('*.pt'))}
+        assert len(outs[mode]) == 5 and len(list(out.glob('*_rgb.png'))) == 5
+    for mode in ('2', '3'):
+        for name, state in outs['1'].items():
+            for k, v in state.items():
+                assert torch.equal(torch.nan_to_num(v, nan=-7.0), torch.nan_to_num(outs[mode][name][k], nan=-7.0)), (mode, name, k)
+    # and against the oracle for one of them, so "equal" is not "equally wrong"
+    name = scene.names[3]
+    sc = copy.copy(loaded); sc.target = 3
+    _, samples = helpers.oracle_scene_samples(sc)
+    tgt = sc.views[3]
+    Jo, po, to = oracle.fit(64, 96, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=25)
+    J = outs['2'][Path(name).with_suffix('.pt').name]['J'].numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-5
