@@ -48,6 +48,8 @@ def parse():
     p.add_argument('--images-in-flight', type=int, default=2,
                    help='consecutive images (steps) kept in flight on their own HIP streams + workspaces '
                         '(engine.in_flight_slot); 1 = strictly one image at a time')
+    p.add_argument('--obs-format', choices=['f32', 'u16mm'], default='f32',
+                   help="observation store: f32 = 7 B/obs, lossless (configs 1-4); u16mm = 5 B/obs (config 5)")
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=9, help='views in the CPU-baseline sample')
     p.add_argument('--cpu-iters', type=int, default=5, help='Adam iterations in the CPU-baseline sample')
@@ -124,7 +126,8 @@ def main():
     # images in flight: slot s = own workspace + own HIP stream; image i goes to slot i % S, so consecutive images
     # overlap (the launches of one fit depend on each other; a second image fills their ramp-up and tails)
     S = 1 if args.shared_water else max(1, args.images_in_flight)
-    restos = [engine.Restoration(H, W, n_views, device=device, light=args.light_model) for _ in range(S)]
+    restos = [engine.Restoration(H, W, n_views, device=device, light=args.light_model, obs_format=args.obs_format)
+              for _ in range(S)]
     streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(device)]
     resto = restos[0]
     J_out = [None] * S
@@ -210,13 +213,15 @@ def main():
         effective_iter_ms = iter_ms
     obs_passes = 2 if args.use_closed_form else 1  # closed form streams the observations twice (J, then gradient)
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
-    algo_bytes = (OBS_BYTES + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
+    obs_bytes = 5 if args.obs_format == 'u16mm' else OBS_BYTES   # c = 5 B/obs for config 5
+    algo_bytes = (obs_bytes + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
     achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
     cover = resto.view_counts().cpu().numpy() / float(W * H)
 
     traffic = None
     tf = ROOT / 'profiles' / 'r01_traffic.json'
-    if tf.exists() and not args.use_closed_form and not args.light_model and (W, H, n_views, T) == (1920, 1080, 65, 200):
+    if (tf.exists() and not args.use_closed_form and not args.light_model and args.obs_format == 'f32'
+            and (W, H, n_views, T) == (1920, 1080, 65, 200)):
         rec = json.loads(tf.read_text())
         if rec.get('n_obs') == n_obs:   # same workload as the profiled one
             traffic = rec['hbm_bytes_per_launch']
@@ -230,10 +235,11 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{len(jobs)} image(s) {W}x{H} x {n_views} views (64 neighbours + self) per step per GPU, '
+            'config': {'workload': f'{len(jobs)} image(s) {W}x{H} x {n_views} views ({n_views - 1} neighbours + self) per step per GPU, '
                                    f'{T} Adam iterations, '
                                    + ('closed-form J' if args.use_closed_form else 'J as parameter')
                                    + (', artificial-light model' if args.light_model else '')
+                                   + (', compact observations (u16 mm ranges, 5 B/obs)' if args.obs_format == 'u16mm' else '')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S,

@@ -46,6 +46,16 @@ extern "C" {
 
 /* fit flags */
 #define SUCRE_FIT_CLOSED_FORM 1u /* --use-closed-form: J is a closed-form buffer, sucre.py:66-77,141 */
+#define SUCRE_FIT_OBS_U16MM 2u   /* the store was finalised with SUCRE_OBS_U16MM (must match, see below) */
+
+/*
+ * Observation formats of the store the fit streams.  SUCRE_OBS_F32: float32 range + 3 uint8
+ * colours = 7 B/observation, lossless for the reference's data (default).  SUCRE_OBS_U16MM: the range as uint16
+ * millimetres, rint(1000 z) clamped to [1, 65535] = 5 B/observation (BASELINE config 5) -- lossy by at most
+ * 0.5 mm of range; every sum is still accumulated in float32/float64 exactly as with SUCRE_OBS_F32.
+ */
+#define SUCRE_OBS_F32 0
+#define SUCRE_OBS_U16MM 1
 
 /*
  * One view of the scene = the arguments the reference reads from an sfm.Image (sfm.py:81-88): depth map,
@@ -117,6 +127,12 @@ int sucre_import_view(void *ws, int H, int W, int n_views, int k, const int16_t 
  * compaction of the kept observations that the fit iterates over.  Call once after all sucre_match_views calls.
  */
 int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover, void *stream);
+/*
+ * Same with an explicit observation format.  A store finalised with SUCRE_OBS_U16MM must be fitted with
+ * SUCRE_FIT_OBS_U16MM in the flags of sucre_fit_run / sucre_fit_grad (and sucre_update_J_fmt); a mismatch is
+ * detected on the device and poisons the logged cost with NaN instead of reading the store wrongly.
+ */
+int sucre_finalize_matches_fmt(void *ws, int H, int W, int n_views, double min_cover, int obs_format, void *stream);
 
 /*
  * SUCRe.__init__ (sucre.py:36-50): B, beta, gamma <- params0 (host, 9 floats; the reference uses 0.1),
@@ -149,6 +165,7 @@ int sucre_set_n_obs_total(void *ws, int H, int W, int n_views, uint64_t n_obs_to
 
 /* SUCRe.update_J(force_update=True) (sucre.py:66-77): closed-form J from the current parameters. */
 int sucre_update_J(void *ws, int H, int W, int n_views, void *stream);
+int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream);
 
 /* J as the reference lays it out: (H,W,3) float32 (sucre.py:213-215). */
 int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream);

@@ -156,6 +156,24 @@ def fit(H: int, W: int, samples, J0: np.ndarray | None, params0=None, num_iter: 
     return J, params, trace
 
 
+def quantize_ranges_u16mm(samples):
+    """The engine's compact observation format (include/sucre_hip.h SUCRE_OBS_U16MM, BASELINE config 5) restated:
+    the range z = ||cP|| (sucre.py:53) is kept as uint16 millimetres, rint(1000 z) clamped to [1, 65535], and read
+    back as float32(mm) * 0.001f.  Returns samples whose camera points are (0, 0, z') so that every fit function of
+    this module sees exactly that range (sqrt(fl(z'^2)) == z' in binary floating point; asserted)."""
+    out = []
+    for u, v, cP, I in samples:
+        cP = np.ascontiguousarray(cP, np.float32)
+        z = np.sqrt(cP[0] * cP[0] + cP[1] * cP[1] + cP[2] * cP[2])          # norm3 of sucre_oracle.c, float32
+        mm = np.clip(np.rint(z * np.float32(1000.0)), np.float32(1.0), np.float32(65535.0)).astype(np.uint16)
+        zq = mm.astype(np.float32) * np.float32(0.001)
+        assert np.array_equal(np.sqrt(zq * zq), zq)
+        cq = np.zeros_like(cP)
+        cq[2] = zq
+        out.append((u, v, cq, I))
+    return out
+
+
 def update_J(H: int, W: int, samples, params) -> np.ndarray:
     """SUCRe.update_J (sucre.py:66-77)."""
     s = _Samples(samples)

@@ -14,6 +14,9 @@ ABI_VERSION = 1
 LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent / 'libsucre_hip.so'))
 
 FIT_CLOSED_FORM = 1
+FIT_OBS_U16MM = 2
+OBS_F32, OBS_U16MM = 0, 1
+OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)
 
 
@@ -37,12 +40,14 @@ SIGNATURES = {
     'sucre_match_map': (_i, [_i, _i, _i, C.POINTER(SucreView), _vp, _i, _vp, _vp]),
     'sucre_import_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     'sucre_finalize_matches': (_i, [_vp, _i, _i, _i, _d, _vp]),
+    'sucre_finalize_matches_fmt': (_i, [_vp, _i, _i, _i, _d, _i, _vp]),
     'sucre_fit_init': (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
     'sucre_fit_run': (_i, [_vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp, _vp]),
     'sucre_fit_grad': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp]),
     'sucre_fit_step': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     'sucre_set_n_obs_total': (_i, [_vp, _i, _i, _i, _u64, _vp]),
     'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
+    'sucre_update_J_fmt': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'sucre_export_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sucre_light_workspace_bytes': (C.c_size_t, [_i, _i, _i]),

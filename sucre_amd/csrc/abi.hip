@@ -132,6 +132,16 @@ int sucre_finalize_matches(void *ws, int H, int W, int n_views, double min_cover
                      "sucre_finalize_matches");
 }
 
+int sucre_finalize_matches_fmt(void *ws, int H, int W, int n_views, double min_cover, int obs_format, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM)
+        return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
+    return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream),
+                                     nullptr, nullptr, obs_format), "sucre_finalize_matches_fmt");
+}
+
 int sucre_fit_init(void *ws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
                    const float *params0, const float *J0_dev, void *stream) {
     Layout L;
@@ -147,7 +157,7 @@ int sucre_fit_grad(void *ws, int H, int W, int n_views, int step, double lr, dou
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
-    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     return check_hip(launch_fit_grad(L, static_cast<uint8_t *>(ws), adam_coef(step, lr, beta1, beta2, eps), flags,
                                      static_cast<hipStream_t>(stream)), "sucre_fit_grad");
 }
@@ -168,7 +178,7 @@ int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr,
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
-    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
     auto *w = static_cast<uint8_t *>(ws);
     auto s = static_cast<hipStream_t>(stream);
@@ -177,7 +187,9 @@ int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr,
         if (int rc = check_hip(launch_fit_iter_fused(L, w, co, flags, trace_dev ? trace_dev + (size_t)it * 10 : nullptr, s),
                                "sucre_fit_run")) return rc;
     }
-    if (flags & SUCRE_FIT_CLOSED_FORM) return check_hip(launch_update_J(L, w, s), "sucre_fit_run/update_J");
+    if (flags & SUCRE_FIT_CLOSED_FORM)
+        return check_hip(launch_update_J(L, w, (flags & SUCRE_FIT_OBS_U16MM) ? SUCRE_OBS_U16MM : SUCRE_OBS_F32, s),
+                         "sucre_fit_run/update_J");
     return SUCRE_OK;
 }
 
@@ -190,9 +202,16 @@ int sucre_set_n_obs_total(void *ws, int H, int W, int n_views, uint64_t n_obs_to
 }
 
 int sucre_update_J(void *ws, int H, int W, int n_views, void *stream) {
+    return sucre_update_J_fmt(ws, H, W, n_views, SUCRE_OBS_F32, stream);
+}
+
+int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
-    return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), static_cast<hipStream_t>(stream)), "sucre_update_J");
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM)
+        return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
+    return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), obs_format, static_cast<hipStream_t>(stream)),
+                     "sucre_update_J");
 }
 
 int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream) {

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void tile_levels_kernel(const uint16_t *__rest
 // 3b. byte offset of every sorted tile's first chunk (exclusive scan of levels; one workgroup).
 __global__ __launch_bounds__(256) void tile_offset_kernel(const uint32_t *__restrict__ levels, int n_tiles,
                                                           uint64_t *__restrict__ tile_off,
-                                                          uint64_t *__restrict__ total_chunks) {
+                                                          uint64_t *__restrict__ total_chunks, int fmt) {
     __shared__ unsigned long long part[256];
     const int t = threadIdx.x;
     const int per = (n_tiles + 255) / 256;
@@ -175,16 +175,20 @@ __global__ __launch_bounds__(256) void tile_offset_kernel(const uint32_t *__rest
         unsigned long long run = 0;
         for (int i = 0; i < 256; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
         *total_chunks = run;
+        *reinterpret_cast<uint32_t *>(total_chunks + 1) = (uint32_t)fmt;  // what the fit kernels must be told
     }
     __syncthreads();
     unsigned long long run = part[t];
-    for (int i = lo; i < hi; ++i) { tile_off[i] = run * kChunk; run += levels[i]; }
+    for (int i = lo; i < hi; ++i) { tile_off[i] = run * (unsigned long long)chunk_bytes(fmt); run += levels[i]; }
 }
 
 // 3c. gather: one thread per slot of the sorted order walks its pixel's view bitmask (next set bit = next level)
 //     and pulls that observation out of the dense store; every compact chunk is written whole and coalesced
 //     (a scatter from the dense side puts neighbouring pixels at different levels -> partial-line writes, 4x slower).
 //     kBatch levels are resolved first, then loaded, then stored.
+//     kFmt = SUCRE_OBS_U16MM: the range is stored as uint16 millimetres, rint(1000 z) clamped to [1, 65535]
+//     (0 stays the empty-slot marker), colours unchanged -> 1280-byte chunks.
+template <int kFmt>
 __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                      size_t view_stride, const uint32_t *__restrict__ perm,
                                                      const uint64_t *__restrict__ pmask, int mask_words,
@@ -229,12 +233,18 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
 #pragma unroll
         for (int b = 0; b < kBatch; ++b) {
             if (l0 + b < nl) {  // workgroup-uniform
-                uint8_t *o = out + (size_t)(l0 + b) * kChunk;
-                reinterpret_cast<float *>(o)[t] = z[b];
-                o[kChunkZ + t] = r[b];
-                o[kChunkZ + kTilePx + t] = g[b];
-                o[kChunkZ + 2 * kTilePx + t] = bl[b];
-                if (ext_dense) {  // light model: carry the camera point along (same chunk numbering, kExtChunk stride)
+                uint8_t *o = out + (size_t)(l0 + b) * chunk_bytes(kFmt);
+                constexpr int zb = kFmt ? kChunkZ16 : kChunkZ;
+                if (kFmt) {
+                    const float mm = fminf(fmaxf(rintf(z[b] * kMmPerM), 1.0f), 65535.0f);
+                    reinterpret_cast<uint16_t *>(o)[t] = z[b] > 0.0f ? (uint16_t)mm : (uint16_t)0;
+                } else {
+                    reinterpret_cast<float *>(o)[t] = z[b];
+                }
+                o[zb + t] = r[b];
+                o[zb + kTilePx + t] = g[b];
+                o[zb + 2 * kTilePx + t] = bl[b];
+                if (kFmt == 0 && ext_dense) {  // light model: carry the camera point along (same chunk numbering, kExtChunk stride)
                     const float *se = reinterpret_cast<const float *>(
                         ext_dense + ((size_t)stile * n_views + (kk[b] >= 0 ? kk[b] : 0)) * kExtChunk);
                     float *de = reinterpret_cast<float *>(ext_comp + (tile_off[dtile] / kChunk + l0 + b) * kExtChunk);
@@ -246,7 +256,8 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
     }
 }
 
-hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp) {
+hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
+                          int fmt) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *keep = reinterpret_cast<const uint32_t *>(ws + L.off_view_keep);
     auto *pcount = reinterpret_cast<uint16_t *>(ws + L.off_pcount);
@@ -268,10 +279,15 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     hipLaunchKernelGGL(tile_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, levels,
                        reinterpret_cast<uint32_t *>(ws + L.off_full));
     hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
-                       reinterpret_cast<uint64_t *>(ws + L.off_total_chunks));
-    hipLaunchKernelGGL(gather_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                       L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
-                       ext_dense, ext_comp);
+                       reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+    if (fmt)
+        hipLaunchKernelGGL(gather_kernel<1>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
+                           L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
+                           ext_dense, ext_comp);
+    else
+        hipLaunchKernelGGL(gather_kernel<0>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
+                           L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
+                           ext_dense, ext_comp);
     return hipGetLastError();
 }
 

@@ -140,24 +140,43 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // measured, tools/probes/lds_dma_probe.hip), so the 768 colour bytes are moved by the first 48 lanes of a second
 // dwordx4: the LDS image is a byte-exact copy of the 1792-byte chunk.  EXEC is all ones here (whole workgroup
 // runs this code) and is restored inside the statement; M0 is written in the statement that reads it.
+template <int kFmt>
 __device__ __forceinline__ void dma_chunk(const uint8_t *chunk, uint32_t slot, uint32_t voff) {
 #ifndef SUCRE_EXP_NOLOAD
     unsigned keep;
     const uint32_t slot_c = slot + kChunkZ;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_mov_b32 exec_hi, 0xffff\n\t"
-        "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
-        "s_mov_b32 exec_hi, -1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
-        : "memory");
+    if (kFmt == 0) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_mov_b32 exec_hi, 0xffff\n\t"
+            "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
+            "s_mov_b32 exec_hi, -1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
+            : "memory");
+    } else {
+        // 1280-byte chunk (512 B of uint16 ranges + 768 B of colours): 64 lanes move the first KiB, 16 lanes the rest
+        asm volatile(
+            "s_nop 4\n\t"
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_mov_b64 exec, 0xffff\n\t"
+            "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
+            : "memory");
+    }
 #endif
 }
 
@@ -173,7 +192,7 @@ __device__ __forceinline__ uint32_t views_of_wave(uint32_t n, int wave) {
 }
 
 // Ring prologue: put the first kAhead chunks in flight.
-template <class FitLds>
+template <int kFmt, class FitLds>
 __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, int wave,
                                              int lane) {
     const uint32_t voff = lane * 16;
@@ -187,11 +206,11 @@ __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restr
 #endif
 #pragma unroll
     for (uint32_t d = 0; d < (uint32_t)kAhead; ++d)
-        if (d < r) dma_chunk(tile_obs + (size_t)(wave + 4u * d) * kChunk, ring0 + d * kSlot, voff);
+        if (d < r) dma_chunk<kFmt>(tile_obs + (size_t)(wave + 4u * d) * chunk_bytes(kFmt), ring0 + d * kSlot, voff);
 }
 
 // Ring steady state for this wave's levels v0 <= v < v1 (of r); slot / slot_in carry the ring position across calls.
-template <int kPass, bool kMasked, class FitLds>
+template <int kPass, bool kMasked, int kFmt, class FitLds>
 __device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, uint32_t v0,
                                              uint32_t v1, int wave, int lane, const Water &w, const float (&J)[3][4],
                                              Acc &acc, uint32_t &slot, uint32_t &slot_in) {
@@ -199,15 +218,22 @@ __device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restr
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
     for (uint32_t v = v0; v < v1; ++v) {
         if (v + kAhead < r)
-            dma_chunk(tile_obs + (size_t)(wave + 4u * (v + kAhead)) * kChunk, ring0 + slot_in * kSlot, voff);
+            dma_chunk<kFmt>(tile_obs + (size_t)(wave + 4u * (v + kAhead)) * chunk_bytes(kFmt), ring0 + slot_in * kSlot, voff);
         const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
         if (ahead >= (uint32_t)kAhead) wait_chunks<kAhead>();
         else if (kAhead > 2 && ahead == 2u) wait_chunks<2>();
         else if (ahead == 1u) wait_chunks<1>();
         else wait_chunks<0>();
         const uint8_t *sp = &lds.u.ring[wave][slot][0];
-        const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + kChunkZ) + lane;  // planar R | G | B
+        float4 z4;
+        if (kFmt == 0) {
+            z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
+        } else {  // uint16 millimetres -> metres, the same float32 product the CPU restatement forms
+            const uint2 q = *reinterpret_cast<const uint2 *>(sp + lane * 8);
+            z4 = make_float4((float)(q.x & 0xffffu) * kMPerMm, (float)(q.x >> 16) * kMPerMm,
+                             (float)(q.y & 0xffffu) * kMPerMm, (float)(q.y >> 16) * kMPerMm);
+        }
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + (kFmt ? kChunkZ16 : kChunkZ)) + lane;  // planar R | G | B
         const uint3 c3 = make_uint3(cp[0], cp[64], cp[128]);
         accumulate_view<kPass, kMasked>(z4, c3, w, J, acc);
         slot = slot + 1 == kRing ? 0 : slot + 1;
@@ -219,14 +245,14 @@ __device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restr
 // nfull (the tile's smallest pixel count) hold 256 real observations each: they run the select-free loop; the
 // few levels above it run the masked one.  Two separate loops on purpose: as one loop with a uniform branch hipcc
 // if-converted both bodies into one (41 selects, 127 VGPRs).
-template <int kPass, class FitLds>
+template <int kPass, int kFmt, class FitLds>
 __device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r,
                                              uint32_t nfull, int wave, int lane, const Water &w,
                                              const float (&J)[3][4], Acc &acc) {
     uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
     const uint32_t rf = min(r, views_of_wave(nfull, wave));
-    stream_range<kPass, false>(lds, tile_obs, r, 0u, rf, wave, lane, w, J, acc, slot, slot_in);
-    stream_range<kPass, true>(lds, tile_obs, r, rf, r, wave, lane, w, J, acc, slot, slot_in);
+    stream_range<kPass, false, kFmt>(lds, tile_obs, r, 0u, rf, wave, lane, w, J, acc, slot, slot_in);
+    stream_range<kPass, true, kFmt>(lds, tile_obs, r, rf, r, wave, lane, w, J, acc, slot, slot_in);
     wait_chunks<0>();  // nothing of ours is in flight past this point
 }
 static_assert(kAhead == 2 || kAhead == 3, "wait ladder in stream_views covers kAhead 2 and 3");
@@ -352,7 +378,7 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
     }
 }
 
-template <bool kClosed, bool kFused>
+template <bool kClosed, bool kFused, int kFmt>
 __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
                                                        const uint64_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ levels,
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
                                                        float *__restrict__ Jt, float *__restrict__ mt,
                                                        float *__restrict__ vt, float *partials, const AdamCoef co,
                                                        unsigned *ticket, double *gpart, int n_groups, double *sums,
-                                                       double *trace_row) {
+                                                       double *trace_row, const uint32_t *__restrict__ obs_format) {
     __shared__ FitLdsT<kClosed> lds;  // 25.2 KB (6 workgroups/CU) without jbuf, 28.2 KB (5) with it
     const int n_blocks = gridDim.x;
     const int t = threadIdx.x;
@@ -377,15 +403,18 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     Acc acc;
     zero_acc(acc);
     float sBetaAcc[3] = {0.f, 0.f, 0.f};
+    // a store compacted in the other format is not read at all; the logged cost turns NaN instead
+    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    if (!fmt_ok) acc.cost = __builtin_nanf("");
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
-        const uint32_t n = levels[tile], nfull = full[tile];
+        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
         const uint8_t *tile_obs = comp + tile_off[tile];
         float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
         const uint32_t r = views_of_wave(n, wave);
         float J[3][4];
         float tot[6];
-        stream_begin(lds, tile_obs, r, wave, lane);
+        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
         if (kClosed) {
             // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
             Acc cj;
@@ -394,7 +423,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-            stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, cj);
+            stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, cj);
             reduce_pixels(lds, cj, wave, lane, t, tot);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
                 lds.jbuf[c][t] = Jc;
             }
             __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
-            stream_begin(lds, tile_obs, r, wave, lane);
+            stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
@@ -429,8 +458,8 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
-        if (kClosed) stream_views<kPassGradClosed>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-        else stream_views<kPassGradJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+        if (kClosed) stream_views<kPassGradClosed, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+        else stream_views<kPassGradJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
         reduce_pixels(lds, acc, wave, lane, t, tot);
 
         // pixel-parallel tail: this thread owns pixel slot t
@@ -497,13 +526,19 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
 }
 
 // SUCRe.update_J alone (sucre.py:66-77, 156)
+template <int kFmt>
 __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ comp,
                                                        const uint64_t *__restrict__ tile_off,
                                                        const uint32_t *__restrict__ levels,
                                                        const uint32_t *__restrict__ full,
-                                                       const float *__restrict__ params, float *__restrict__ Jt) {
+                                                       const float *__restrict__ params, float *__restrict__ Jt,
+                                                       const uint32_t *__restrict__ obs_format) {
     __shared__ FitLdsT<false> lds;
     const int tile = blockIdx.x;
+    if (*obs_format != (uint32_t)kFmt) {  // wrong format announced by the caller: poison instead of misreading
+        for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + threadIdx.x] = __builtin_nanf("");
+        return;
+    }
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -517,8 +552,8 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
         for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
     Acc acc;
     zero_acc(acc);
-    stream_begin(lds, tile_obs, r, wave, lane);
-    stream_views<kPassClosedJ>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+    stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
+    stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
     float tot[6];
     reduce_pixels(lds, acc, wave, lane, t, tot);
 #pragma unroll
@@ -596,9 +631,9 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
     return hipGetLastError();
 }
 
-template <bool kClosed, bool kFused>
-static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+template <bool kClosed, bool kFused, int kFmt>
+static void launch_grad_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
+    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
                        reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
@@ -608,22 +643,30 @@ static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co
                        reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_partials), co,
                        reinterpret_cast<unsigned *>(ws + L.off_ticket),
                        reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups,
-                       reinterpret_cast<double *>(ws + L.off_sums), trace_row);
+                       reinterpret_cast<double *>(ws + L.off_sums), trace_row,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
+}
+
+template <bool kClosed, bool kFused>
+static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, double *trace_row,
+                                hipStream_t s) {
+    if (flags & SUCRE_FIT_OBS_U16MM) launch_grad_fmt<kClosed, kFused, 1>(L, ws, co, trace_row, s);
+    else launch_grad_fmt<kClosed, kFused, 0>(L, ws, co, trace_row, s);
 }
 
 // One whole iteration in a single launch (gradient pass + last-arriver reduction + water-parameter step).
 hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags,
                                  double *trace_row, hipStream_t s) {
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, true>(L, ws, co, trace_row, s);
-    else launch_grad_variant<false, true>(L, ws, co, trace_row, s);
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, true>(L, ws, co, flags, trace_row, s);
+    else launch_grad_variant<false, true>(L, ws, co, flags, trace_row, s);
     return hipGetLastError();
 }
 
 // Split form for multi-GPU shared-water runs: gradient pass + reduction, sums left at off_sums for the host's
 // all-reduce; launch_fit_step applies them.
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, nullptr, s);
-    else launch_grad_variant<false, false>(L, ws, co, nullptr, s);
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, flags, nullptr, s);
+    else launch_grad_variant<false, false>(L, ws, co, flags, nullptr, s);
     hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.n_groups), dim3(256), 0, s,
                        reinterpret_cast<const float *>(ws + L.off_partials), L.n_blocks,
                        reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups);
@@ -640,12 +683,19 @@ hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, dou
     return hipGetLastError();
 }
 
-hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s) {
-    hipLaunchKernelGGL(update_J_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
+template <int kFmt>
+static void launch_update_J_fmt(const Layout &L, uint8_t *ws, hipStream_t s) {
+    hipLaunchKernelGGL(update_J_kernel<kFmt>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
                        reinterpret_cast<const uint32_t *>(ws + L.off_full),
-                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J));
+                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
+}
+
+hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
+    if (fmt) launch_update_J_fmt<1>(L, ws, s);
+    else launch_update_J_fmt<0>(L, ws, s);
     return hipGetLastError();
 }
 

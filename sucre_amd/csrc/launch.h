@@ -33,9 +33,9 @@ hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const s
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
                               const uint8_t *rgb, long long n, hipStream_t s);
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s,
-                           const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr);
+                           const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense = nullptr,
-                          uint8_t *ext_comp = nullptr);
+                          uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);
 
 hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,
@@ -44,7 +44,7 @@ hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &c
                                  hipStream_t s);
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s);
 hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s);
-hipError_t launch_update_J(const Layout &L, uint8_t *ws, hipStream_t s);
+hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s);
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
 hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
 

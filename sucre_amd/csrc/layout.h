@@ -10,6 +10,12 @@ constexpr int kTilePx = 256;         // pixels per tile = one 64-lane wave x 4 p
 constexpr int kChunkZ = 1024;        // bytes: 256 float32 ranges
 constexpr int kChunkRGB = 768;       // bytes: planar R[256] G[256] B[256] uint8
 constexpr int kChunk = kChunkZ + kChunkRGB;  // 1792 bytes per (tile, view)
+// Compact observation format (SUCRE_OBS_U16MM, BASELINE config 5): ranges as uint16 millimetres (0 = empty slot),
+// 5 bytes per observation.  Only the compact store (what the fit streams) uses it; the dense store stays float32.
+constexpr int kChunkZ16 = 512;       // bytes: 256 uint16 ranges
+constexpr int kChunk16 = kChunkZ16 + kChunkRGB;  // 1280 bytes per (sorted tile, level)
+constexpr float kMmPerM = 1000.0f, kMPerMm = 0.001f;
+__host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt ? kChunk16 : kChunk; }
 constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
 constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
@@ -35,7 +41,7 @@ struct Layout {
     size_t off_levels;      // uint32 [n_tiles]            chunks (levels) of every sorted tile (= largest pixel count in it)
     size_t off_full;        // uint32 [n_tiles]            levels with all 256 slots occupied (= smallest pixel count)
     size_t off_tile_off;    // uint64 [n_tiles]            byte offset of a sorted tile's first chunk in the compact store
-    size_t off_total_chunks;// uint64 [1]
+    size_t off_total_chunks;// uint64 [1], then uint32 [1]: observation format of the compact store (SUCRE_OBS_*)
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]
     size_t off_n_obs;       // uint64 [1]

@@ -308,7 +308,7 @@ hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const s
 }
 
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s, const uint8_t *ext_dense,
-                           uint8_t *ext_comp) {
+                           uint8_t *ext_comp, int fmt) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *vc = reinterpret_cast<uint64_t *>(ws + L.off_view_count);
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
@@ -318,7 +318,7 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_compact(L, ws, s, ext_dense, ext_comp);
+    return launch_compact(L, ws, s, ext_dense, ext_comp, fmt);
 }
 
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {

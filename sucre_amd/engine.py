@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -62,9 +63,19 @@ class Restoration:
     """Workspace + launch sequence for one target image (replaces the HDF5 spill and the host-resident
     MatchesData of the reference, loader.py:56-130)."""
 
-    def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda', light: bool = False):
+    def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda', light: bool = False,
+                 obs_format: str = 'f32'):
+        """``obs_format``: 'f32' = 7 B/observation, lossless (default); 'u16mm' = 5 B/observation, ranges rounded to
+        the millimetre (BASELINE config 5; include/sucre_hip.h SUCRE_OBS_U16MM)."""
         self.lib = _lib.load()
         self.light = bool(light)
+        if obs_format not in _lib.OBS_FORMATS:
+            raise ValueError(f'obs_format must be one of {sorted(_lib.OBS_FORMATS)}, not {obs_format!r}')
+        if self.light and obs_format != 'f32':
+            raise NotImplementedError('the artificial-light model keeps float32 camera points: obs_format must be f32')
+        self.obs_format = obs_format
+        self._fmt = _lib.OBS_FORMATS[obs_format]
+        self._fmt_flag = _lib.FIT_OBS_U16MM if self._fmt == _lib.OBS_U16MM else 0
         self.H, self.W, self.n_views = int(height), int(width), int(n_views)
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -114,7 +125,7 @@ class Restoration:
             else:
                 _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
                                                       0, n, _stream_ptr()))
-                _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
 
     def import_matches(self, target: DeviceView, lists: list, min_cover: float = -1.0) -> None:
         """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
@@ -133,7 +144,7 @@ class Restoration:
                 _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
                                                       C.c_void_p(z.data_ptr()), C.c_void_p(rgb.data_ptr()),
                                                       u1.numel(), _stream_ptr()))
-            _lib.check(self.lib.sucre_finalize_matches(ws, H, W, n, float(min_cover), _stream_ptr()))
+            _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
 
     def match_map(self, k: int) -> torch.Tensor:
         """(H,W) int32: linear pixel index v2*W2+u2 in view k matched to every target pixel, -1 = none
@@ -197,7 +208,7 @@ class Restoration:
         into several calls (``finalize`` is kept for readability) ends in the same state."""
         width = 20 if self.light else 10
         trace = torch.zeros((num_iter, width), dtype=torch.float64, device=self.device) if record_trace else None
-        flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
+        flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag
         ws, H, W, n = self._geom
         tp = C.c_void_p(trace.data_ptr()) if trace is not None else None
         with torch.cuda.device(self.device):
@@ -219,7 +230,7 @@ class Restoration:
             if self.light:
                 _lib.check(self.lib.sucre_update_J_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, _stream_ptr()))
             else:
-                _lib.check(self.lib.sucre_update_J(ws, H, W, n, _stream_ptr()))
+                _lib.check(self.lib.sucre_update_J_fmt(ws, H, W, n, self._fmt, _stream_ptr()))
 
     def params(self) -> torch.Tensor:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
@@ -252,7 +263,7 @@ class HipWaterBackend:
                  use_closed_form: bool = False, trace: torch.Tensor | None = None):
         self.r = restoration
         self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))
-        self.flags = _lib.FIT_CLOSED_FORM if use_closed_form else 0
+        self.flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | restoration._fmt_flag
         self.trace = trace
         self._sums = restoration._region(_lib.WS_SUMS, torch.float64, 12)
 
@@ -286,15 +297,18 @@ _STREAMS: dict = {}
 _SLOT = 0          # the in-flight slot the calling code is working for (see in_flight_slot)
 
 
-def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False) -> Restoration:
+def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
+                        obs_format: str | None = None) -> Restoration:
     """Workspace pool: one Restoration per (geometry, device, in-flight slot), reused image after image (the
     1080p x 65-view workspace is ~2 GB; re-allocating it per image would serialise on the allocator)."""
     dev = torch.device(device)
     if dev.type == 'cuda' and dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
-    key = (int(height), int(width), int(n_views), str(dev), bool(light), _SLOT)
+    if obs_format is None:   # engine knob for the reference-compatible CLI, which has no flag for it
+        obs_format = 'f32' if light else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
+    key = (int(height), int(width), int(n_views), str(dev), bool(light), _SLOT, obs_format)
     if key not in _POOL:
-        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light)
+        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light, obs_format=obs_format)
     return _POOL[key]
 
 

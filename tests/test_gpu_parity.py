@@ -126,6 +126,53 @@ def test_fit_J_parameter_mode(golden, T, key):
     assert np.allclose(params, trace[-1, 1:], rtol=0, atol=0)
 
 
+def _fit_engine_u16mm(scene, T, closed=False):
+    from sucre_amd import engine
+    views = engine.device_views_from_scene(scene, 'cuda')
+    r = engine.Restoration(scene.height, scene.width, len(views), obs_format='u16mm')
+    r.match(views[scene.target], views)
+    r.fit_init(views[scene.target])
+    trace = r.fit(T, use_closed_form=closed)
+    torch.cuda.synchronize()
+    return r, r.J().cpu().numpy(), r.params().cpu().numpy(), trace.cpu().numpy()
+
+
+@pytest.mark.parametrize('closed', [False, True])
+def test_compact_u16mm_store_vs_oracle_and_golden(golden, closed):
+    """SUCRE_OBS_U16MM (5 B/observation, BASELINE config 5): same bits of range as the oracle's restatement of the
+    format, so the same tight bar as the float32 store; and against the *unquantised* reference the J-parameter
+    mode stays inside the 1e-4 parity bar (measured 7e-6).  Closed-form mode is ill-conditioned (see
+    test_fit_closed_form_mode): half a millimetre of range moves it by up to 3.4e-4 in red J, so it is only held to
+    the oracle there."""
+    sc = golden.scene
+    r, J, params, trace = _fit_engine_u16mm(sc, 200, closed)
+    _, samples = helpers.oracle_scene_samples(sc)
+    tgt = sc.views[sc.target]
+    J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    Jo, po, to = oracle.fit(sc.height, sc.width, oracle.quantize_ranges_u16mm(samples), J0, num_iter=200, use_closed_form=closed)
+    assert r.n_obs() == sum(len(s[0]) for s in samples)
+    assert np.array_equal(np.isnan(J), np.isnan(Jo))
+    assert helpers.rms_per_channel(J, Jo).max() < (2e-5 if closed else RMS_ORACLE)
+    assert np.abs(trace[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
+    assert np.abs(trace[:, 0] / to[:, 0] - 1).max() < 1e-4
+    if not closed:
+        assert helpers.rms_per_channel(J, golden['J_param_200']).max() < RMS_BAR
+        assert np.abs(trace[:, 1:] - golden['trace_param'][:, 1:]).max() < 1e-4
+
+
+def test_announcing_the_wrong_observation_format_poisons_the_cost(golden):
+    from sucre_amd import _lib
+    sc = golden.scene
+    r, J, params, trace = _fit_engine_u16mm(sc, 1)
+    assert np.isfinite(trace[0, 0])
+    r._fmt_flag = 0                              # store is u16mm, caller now claims float32
+    t = r.fit(1).cpu().numpy()
+    assert np.isnan(t[0, 0])
+    r._fmt = _lib.OBS_F32
+    r.update_J()
+    assert bool(torch.isnan(r.J()).all())
+
+
 def test_fit_closed_form_mode(golden):
     J, params, trace = _fit_engine(golden.scene, 200, closed=True)
     ref = golden['J_closed_200']
@@ -239,15 +286,17 @@ def test_split_grad_step_path_equals_fused(golden):
 
 
 @pytest.mark.timeout(600)
-def test_config5_shape_properties():
-    """BASELINE config 5 shape (3840x2160, 256 neighbours + self = 257 views; 7 B/obs store): more than 255 views
-    (quantised counting-sort bins, 5 mask words per pixel), ~30 GB workspace, 64-bit offsets."""
+@pytest.mark.parametrize('obs_format', ['f32', 'u16mm'])
+def test_config5_shape_properties(obs_format):
+    """BASELINE config 5 shape (3840x2160, 256 neighbours + self = 257 views), on the 7 B/obs store and on the
+    compact 5 B/obs one the config names: more than 255 views (quantised counting-sort bins, 5 mask words per
+    pixel), ~30 GB workspace, 64-bit offsets."""
     from sucre_amd import engine, synth
     W, H, NN = 3840, 2160, 256
     scene = synth.make_scene(W, H, NN, seed=2, device='cuda', spacing=0.05)
     views = engine.device_views_from_scene(scene, 'cuda')
     tgt = views[scene.target]
-    r = engine.Restoration(H, W, len(views))
+    r = engine.Restoration(H, W, len(views), obs_format=obs_format)
     r.match(tgt, views)
     counts = r.view_counts().cpu().numpy()
     keep = r.view_keep().cpu().numpy().astype(bool)
@@ -277,6 +326,8 @@ def test_config5_shape_properties():
         z, rgb = r.export_view(k)
         m = z > 0
         zz = z[m].double()[:, None]
+        if obs_format == 'u16mm':   # what the compact store keeps of the range
+            zz = torch.clamp(torch.round(z[m] * 1000.0), 1, 65535).double()[:, None] * float(np.float32(0.001))
         a = torch.exp(-0.1 * zz)
         res = rgb[m].double() / 255 - (J0[m] * a + 0.1 * (1 - a))
         total += float((res * res).sum())

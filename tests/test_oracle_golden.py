@@ -162,3 +162,19 @@ def test_light_model_with_closed_form_J(golden):
     assert np.array_equal(np.isnan(J), np.isnan(golden['J_light_closed_100']))
     rms = helpers.rms_per_channel(J, golden['J_light_closed_100'])
     assert rms[1:].max() < 1e-4 and rms[0] < 5e-2
+
+
+def test_u16mm_ranges_stay_inside_the_parity_bar(golden):
+    """The compact observation format (ranges rounded to the millimetre, include/sucre_hip.h SUCRE_OBS_U16MM) against
+    the unquantised reference: J-parameter mode well inside the 1e-4 bar."""
+    sc = golden.scene
+    _, samples = helpers.oracle_scene_samples(sc)
+    tgt = sc.views[sc.target]
+    q = oracle.quantize_ranges_u16mm(samples)
+    for (u, v, cP, I), (_, _, cq, _) in zip(samples, q):
+        z = np.sqrt((cP.astype(np.float64) ** 2).sum(axis=0))
+        assert np.abs(cq[2] - z).max() <= 0.5e-3 + 1e-6 and (cq[:2] == 0).all()
+    J, p, tr = oracle.fit(sc.height, sc.width, q, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=200)
+    assert np.array_equal(np.isnan(J), np.isnan(golden['J_param_200']))
+    assert helpers.rms_per_channel(J, golden['J_param_200']).max() < 2e-5
+    assert np.abs(tr[:, 1:] - golden['trace_param'][:, 1:]).max() < 1e-4
