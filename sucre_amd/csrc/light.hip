@@ -132,7 +132,7 @@ struct LightAcc {
 };
 
 // l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
-struct LightObs { float l, z, nl, lp0, lp1, lP[3]; };
+struct LightObs { float l, z, nl, inl, iz, lp0, lp1, lP[3]; };
 
 __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const float (&R)[9], const float (&tl)[3],
                                               const float (&M)[4]) {
@@ -140,11 +140,16 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
 #pragma unroll
     for (int a = 0; a < 3; ++a)
         o.lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], R[a * 3] * cP[0])) + tl[a];
-    o.lp0 = o.lP[0] / o.lP[2];
-    o.lp1 = o.lP[1] / o.lP[2];
+    // hardware reciprocal / reciprocal square root (1 ulp): this path is held to a tolerance, not to bit parity,
+    // and the IEEE sequences were a quarter of the kernel's instructions
+    o.iz = __builtin_amdgcn_rcpf(o.lP[2]);
+    o.lp0 = o.lP[0] * o.iz;
+    o.lp1 = o.lP[1] * o.iz;
     const float q = o.lp0 * (M[0] * o.lp0 + M[1] * o.lp1) + o.lp1 * (M[2] * o.lp0 + M[3] * o.lp1);
     o.l = fast_exp2(q * (-0.5f * kLog2e));
-    o.nl = sqrtf(o.lP[0] * o.lP[0] + o.lP[1] * o.lP[1] + o.lP[2] * o.lP[2]);
+    const float n2 = o.lP[0] * o.lP[0] + o.lP[1] * o.lP[1] + o.lP[2] * o.lP[2];
+    o.inl = __builtin_amdgcn_rsqf(n2);
+    o.nl = n2 * o.inl;
     o.z = zc + o.nl;
     return o;
 }
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 const float kk = dl * (-0.5f * l);
                 const float dlp0 = kk * ((M[0] * o.lp0 + M[1] * o.lp1) + (M[0] * o.lp0 + M[2] * o.lp1));
                 const float dlp1 = kk * ((M[2] * o.lp0 + M[3] * o.lp1) + (M[1] * o.lp0 + M[3] * o.lp1));
-                const float iz = 1.0f / o.lP[2], inl = 1.0f / o.nl;
+                const float iz = o.iz, inl = o.inl;
                 float dlP[3];
                 dlP[0] = dz * o.lP[0] * inl + dlp0 * iz;
                 dlP[1] = dz * o.lP[1] * inl + dlp1 * iz;
