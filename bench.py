@@ -211,7 +211,7 @@ def main():
     iter_ms = fit_ms / T
     if S == 1:
         effective_iter_ms = iter_ms
-    obs_passes = 2 if args.use_closed_form else 1  # closed form streams the observations twice (J, then gradient)
+    obs_passes = 2 if (args.use_closed_form and args.light_model) else 1  # light + closed form: J pass, then gradient pass
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
     obs_bytes = 5 if args.obs_format == 'u16mm' else OBS_BYTES   # c = 5 B/obs for config 5
     algo_bytes = (obs_bytes + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
@@ -245,7 +245,7 @@ def main():
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S,
                        'images_per_s_per_gpu': args.steps * len(jobs) / elapsed, 'fit_ms_alone': fit_ms,
                        'ms_per_image': elapsed / args.steps / len(jobs) * 1e3},
-            'roofline': {'bound': 'hbm', 'kernel': 'light_grad_kernel' if args.light_model else 'fit_grad_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'light_grad_kernel' if args.light_model else ('fit_closed_kernel' if args.use_closed_form else 'fit_grad_kernel'), 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)' if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes, 'ms_per_launch': iter_ms,

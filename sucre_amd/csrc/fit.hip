@@ -34,7 +34,7 @@ __device__ __forceinline__ Water load_water(const float *__restrict__ params) {
 }
 
 // What one pass over a view accumulates.
-enum Pass { kPassGradJ = 0, kPassClosedJ = 1, kPassGradClosed = 2 };
+enum Pass { kPassGradJ = 0, kPassClosedJ = 1 };
 
 // Measured on gfx950 (tools/microbench.py, no-load build): a scalar fp32 VALU op issues in 2 cycles per wave64, a
 // packed v_pk_*_f32 in 4 and v_exp_f32 in 4, so writing this loop two-wide saved instructions but not time (and
@@ -80,23 +80,59 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
                 acc.pb[c][j] += a2;
             } else {
                 const float Ihat = __builtin_fmaf(J[c][j], a, bt);
-                float r;
-                if (kPass == kPassGradClosed) {
-                    // the closed-form trajectory is ill-conditioned (J is re-solved every iteration, gradients are
-                    // tiny): keep the reference's exactly rounded I = float32(k/255) so it is followed closely
-                    r = unit_from_u8(k) - Ihat;
-                } else {
-                    // I = k/255 folded into the residual: one rounding instead of two, two VALU ops fewer
-                    r = __builtin_fmaf((float)k, kInv255, -Ihat);
-                }
+                // I = k/255 folded into the residual: one rounding instead of two, two VALU ops fewer
+                float r = __builtin_fmaf((float)k, kInv255, -Ihat);
                 r = valid ? r : 0.0f;  // select, not multiply: J may be NaN where unobserved
                 const float rz = r * z;
                 acc.cost = __builtin_fmaf(r, r, acc.cost);
-                if (kPass == kPassGradJ) acc.pa[c][j] = __builtin_fmaf(r, a, acc.pa[c][j]);
+                acc.pa[c][j] = __builtin_fmaf(r, a, acc.pa[c][j]);
                 acc.pb[c][j] = __builtin_fmaf(rz, a, acc.pb[c][j]);
                 acc.sB[c] = __builtin_fmaf(r, omg, acc.sB[c]);
                 acc.sGZ[c] = __builtin_fmaf(rz, g, acc.sGZ[c]);
             }
+        }
+    }
+}
+
+// Closed-form mode in ONE pass over the observations (sucre.py:141 + 142-147 with J a constant of the backward pass).
+// With y = I - B(1-g) (free of J) and J = N/D per pixel-channel, N = sum y a, D = sum a^2, the residual is
+// r = y - J a and every sum the gradient needs factors through per-pixel sums that do not contain J:
+//   sum r (1-g) = S1 - J S2      S1 = sum y (1-g)   S2 = sum a (1-g)
+//   sum r z a   = S3 - J S4      S3 = sum y z a     S4 = sum z a^2
+//   sum r z g   = S5 - J S6      S5 = sum y z g     S6 = sum a z g
+//   sum r^2     = S7 - J N       S7 = sum y^2                      (J^2 D = J N)
+// so the observations are streamed once (the two-pass form: J first, then the gradient, 2x the traffic and 1.4x
+// the VALU work).  The cancellation in S - J S' is of the same size as the one the reference has in r = I - Ihat.
+struct AccOne {
+    float q[9][3][4];  // N, D, S1..S7 per pixel-channel
+};
+
+template <int kPass, bool kMasked>
+__device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
+                                                const float (&)[3][4], AccOne &acc) {
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+    const uint32_t cc[3] = {c3.x, c3.y, c3.z};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float z = zz[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t k = (cc[c] >> (8 * j)) & 255u;
+            const float a = fast_exp2(z * w.nb[c]);
+            const float g = fast_exp2(z * w.ng[c]);
+            const float omg = 1.0f - g;
+            const float y = unit_from_u8(k) - w.B[c] * omg;  // padding slot: z = 0, colour 0 -> g = 1, y = 0
+            const float za = z * a, zg = z * g;
+            acc.q[0][c][j] = __builtin_fmaf(y, a, acc.q[0][c][j]);
+            if (kMasked) acc.q[1][c][j] += (z > 0.0f) ? a * a : 0.0f;  // the only sum a padding slot would touch
+            else acc.q[1][c][j] = __builtin_fmaf(a, a, acc.q[1][c][j]);
+            acc.q[2][c][j] = __builtin_fmaf(y, omg, acc.q[2][c][j]);
+            acc.q[3][c][j] = __builtin_fmaf(a, omg, acc.q[3][c][j]);
+            acc.q[4][c][j] = __builtin_fmaf(y, za, acc.q[4][c][j]);
+            acc.q[5][c][j] = __builtin_fmaf(a, za, acc.q[5][c][j]);
+            acc.q[6][c][j] = __builtin_fmaf(y, zg, acc.q[6][c][j]);
+            acc.q[7][c][j] = __builtin_fmaf(a, zg, acc.q[7][c][j]);
+            acc.q[8][c][j] = __builtin_fmaf(y, y, acc.q[8][c][j]);
         }
     }
 }
@@ -115,13 +151,21 @@ constexpr int kRing = 3;
 constexpr int kAhead = kRing - 1;
 constexpr int kSlot = kChunk;  // LDS image of one chunk = byte-exact copy
 
-template <bool kWithJ>
-struct __attribute__((aligned(16))) FitLdsT {
+struct __attribute__((aligned(16))) FitLds {
     union {
         uint8_t ring[4][kRing][kSlot];  // phase 1: per-wave chunk ring
         float red[4][6][kTilePx];        // phase 2: per-pixel sums of the four waves (ring is dead by then)
     } u;
-    float jbuf[kWithJ ? 3 : 1][kWithJ ? kTilePx : 4];  // closed-form J of the tile (closed-form kernels only)
+    double stot[kSumsPad];
+    float wsum[4][kNumSums];
+    int is_last;
+};
+
+struct __attribute__((aligned(16))) FitLdsOne {
+    union {
+        uint8_t ring[4][kRing][kSlot];
+        float red[4][9][kTilePx];        // one round = one triple of quantities x 3 channels of the four waves
+    } u;
     double stot[kSumsPad];
     float wsum[4][kNumSums];
     int is_last;
@@ -210,10 +254,10 @@ __device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restr
 }
 
 // Ring steady state for this wave's levels v0 <= v < v1 (of r); slot / slot_in carry the ring position across calls.
-template <int kPass, bool kMasked, int kFmt, class FitLds>
+template <int kPass, bool kMasked, int kFmt, class FitLds, class AccT>
 __device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, uint32_t v0,
                                              uint32_t v1, int wave, int lane, const Water &w, const float (&J)[3][4],
-                                             Acc &acc, uint32_t &slot, uint32_t &slot_in) {
+                                             AccT &acc, uint32_t &slot, uint32_t &slot_in) {
     const uint32_t voff = lane * 16;
     const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
     for (uint32_t v = v0; v < v1; ++v) {
@@ -245,10 +289,10 @@ __device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restr
 // nfull (the tile's smallest pixel count) hold 256 real observations each: they run the select-free loop; the
 // few levels above it run the masked one.  Two separate loops on purpose: as one loop with a uniform branch hipcc
 // if-converted both bodies into one (41 selects, 127 VGPRs).
-template <int kPass, int kFmt, class FitLds>
+template <int kPass, int kFmt, class FitLds, class AccT>
 __device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r,
                                              uint32_t nfull, int wave, int lane, const Water &w,
-                                             const float (&J)[3][4], Acc &acc) {
+                                             const float (&J)[3][4], AccT &acc) {
     uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
     const uint32_t rf = min(r, views_of_wave(nfull, wave));
     stream_range<kPass, false, kFmt>(lds, tile_obs, r, 0u, rf, wave, lane, w, J, acc, slot, slot_in);
@@ -378,117 +422,18 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
     }
 }
 
-template <bool kClosed, bool kFused, int kFmt>
-__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
-                                                       const uint64_t *__restrict__ tile_off,
-                                                       const uint32_t *__restrict__ levels,
-                                                       const uint32_t *__restrict__ full, int n_tiles,
-                                                       float *pstate, const uint64_t *__restrict__ n_obs_total,
-                                                       float *__restrict__ Jt, float *__restrict__ mt,
-                                                       float *__restrict__ vt, float *partials, const AdamCoef co,
-                                                       unsigned *ticket, double *gpart, int n_groups, double *sums,
-                                                       double *trace_row, const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLdsT<kClosed> lds;  // 25.2 KB (6 workgroups/CU) without jbuf, 28.2 KB (5) with it
+// End of a fit launch: the workgroup's ten sums -> one float32 partial each -> (fused form) two-level last-arriver
+// reduction in float64 and the Adam step on B, beta, gamma by the workgroup that arrives last.
+template <bool kFused, class FitLds>
+__device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums], float *partials, const AdamCoef &co,
+                                              unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                              float *pstate, const uint64_t *__restrict__ n_obs_total,
+                                              double *trace_row) {
     const int n_blocks = gridDim.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(pstate);
-    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
-
-    // The workgroup is persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the compact store's tiles are
-    // sorted heaviest first, so this deal is balanced).  The per-thread global sums simply keep accumulating across
-    // its tiles; the shuffle reduction, the sc1 publish and the ticket hand-off -- measured at ~40 us per launch when
-    // done once per tile (bisected with early-return builds) -- happen once per workgroup.
-    Acc acc;
-    zero_acc(acc);
-    float sBetaAcc[3] = {0.f, 0.f, 0.f};
-    // a store compacted in the other format is not read at all; the logged cost turns NaN instead
-    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
-    if (!fmt_ok) acc.cost = __builtin_nanf("");
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
-        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
-        const uint8_t *tile_obs = comp + tile_off[tile];
-        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
-        const uint32_t r = views_of_wave(n, wave);
-        float J[3][4];
-        float tot[6];
-        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-        if (kClosed) {
-            // SUCRe.update_J at the top of the iteration (sucre.py:141, 66-77)
-            Acc cj;
-            zero_acc(cj);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-            stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, cj);
-            reduce_pixels(lds, cj, wave, lane, t, tot);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float Jc = tot[c] / tot[3 + c];  // 0/0 = NaN where nothing was observed
-                Jtile[c * kTilePx + t] = Jc;
-                lds.jbuf[c][t] = Jc;
-            }
-            __syncthreads();  // jbuf complete; `red` retired before the second pass reuses the ring
-            stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 v = *reinterpret_cast<const float4 *>(&lds.jbuf[c][lane * 4]);
-                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
-            }
-        } else {
-            // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count
-            // the asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's
-            // first use; the empty asm makes that first use happen here, where only the prologue (issued at the same
-            // time, hence landing at the same time) is outstanding: one shared start-up latency per tile.
-            float4 jv[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
-                J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
-            }
-        }
-
-        // per-pixel sums restart with every tile; the global sums (sB, sGZ, cost) carry on
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
-        if (kClosed) stream_views<kPassGradClosed, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-        else stream_views<kPassGradJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-        reduce_pixels(lds, acc, wave, lane, t, tot);
-
-        // pixel-parallel tail: this thread owns pixel slot t
-        if (kClosed) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float Jc = lds.jbuf[c][t];
-                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
-            }
-        } else {
-            float *mtile = mt + (size_t)tile * 3 * kTilePx;
-            float *vtile = vt + (size_t)tile * 3 * kTilePx;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
-                // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
-                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
-                adam_update(Jc, m, v, gscale * tot[c], co);
-                Jtile[c * kTilePx + t] = Jc;
-                mtile[c * kTilePx + t] = m;
-                vtile[c * kTilePx + t] = v;
-            }
-        }
-        __syncthreads();  // `red` (and jbuf) retired before the next tile's ring prologue overwrites the LDS
-    }
-
     // ten workgroup sums: wave shuffle tree, then the four waves in fixed order
-    float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
-                         sBetaAcc[0], sBetaAcc[1], sBetaAcc[2], acc.cost};
 #pragma unroll
     for (int q = 0; q < kNumSums; ++q) {
 #pragma unroll
@@ -525,6 +470,166 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     }
 }
 
+template <bool kFused, int kFmt>
+__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
+                                                       const uint64_t *__restrict__ tile_off,
+                                                       const uint32_t *__restrict__ levels,
+                                                       const uint32_t *__restrict__ full, int n_tiles,
+                                                       float *pstate, const uint64_t *__restrict__ n_obs_total,
+                                                       float *__restrict__ Jt, float *__restrict__ mt,
+                                                       float *__restrict__ vt, float *partials, const AdamCoef co,
+                                                       unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                                       double *trace_row, const uint32_t *__restrict__ obs_format) {
+    __shared__ FitLds lds;  // 24.9 KB: 6 workgroups per CU
+    const int n_blocks = gridDim.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(pstate);
+    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
+
+    // The workgroup is persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the compact store's tiles are
+    // sorted heaviest first, so this deal is balanced).  The per-thread global sums simply keep accumulating across
+    // its tiles; the shuffle reduction, the sc1 publish and the ticket hand-off -- measured at ~40 us per launch when
+    // done once per tile (bisected with early-return builds) -- happen once per workgroup.
+    Acc acc;
+    zero_acc(acc);
+    float sBetaAcc[3] = {0.f, 0.f, 0.f};
+    // a store compacted in the other format is not read at all; the logged cost turns NaN instead
+    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    if (!fmt_ok) acc.cost = __builtin_nanf("");
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
+        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
+        const uint8_t *tile_obs = comp + tile_off[tile];
+        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+        const uint32_t r = views_of_wave(n, wave);
+        float J[3][4];
+        float tot[6];
+        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
+        {
+            // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count
+            // the asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's
+            // first use; the empty asm makes that first use happen here, where only the prologue (issued at the same
+            // time, hence landing at the same time) is outstanding: one shared start-up latency per tile.
+            float4 jv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
+                J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
+            }
+        }
+
+        // per-pixel sums restart with every tile; the global sums (sB, sGZ, cost) carry on
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
+        stream_views<kPassGradJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
+        reduce_pixels(lds, acc, wave, lane, t, tot);
+
+        // pixel-parallel tail: this thread owns pixel slot t
+        {
+            float *mtile = mt + (size_t)tile * 3 * kTilePx;
+            float *vtile = vt + (size_t)tile * 3 * kTilePx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
+                // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
+                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
+                adam_update(Jc, m, v, gscale * tot[c], co);
+                Jtile[c * kTilePx + t] = Jc;
+                mtile[c * kTilePx + t] = m;
+                vtile[c * kTilePx + t] = v;
+            }
+        }
+        __syncthreads();  // `red` retired before the next tile's ring prologue overwrites the LDS
+    }
+
+    float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
+                         sBetaAcc[0], sBetaAcc[1], sBetaAcc[2], acc.cost};
+    finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
+}
+
+// Closed-form mode, one observation pass per iteration (see AccOne).
+template <bool kFused, int kFmt>
+__global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restrict__ comp,
+                                                         const uint64_t *__restrict__ tile_off,
+                                                         const uint32_t *__restrict__ levels,
+                                                         const uint32_t *__restrict__ full, int n_tiles,
+                                                         float *pstate, const uint64_t *__restrict__ n_obs_total,
+                                                         float *__restrict__ Jt, float *partials, const AdamCoef co,
+                                                         unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                                         double *trace_row, const uint32_t *__restrict__ obs_format) {
+    __shared__ FitLdsOne lds;  // 37 KB; the kernel is register-bound (3 workgroups per CU) before it is LDS-bound
+    const int n_blocks = gridDim.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(pstate);
+    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    float sB[3] = {0.f, 0.f, 0.f}, sGZ[3] = {0.f, 0.f, 0.f}, sBeta[3] = {0.f, 0.f, 0.f};
+    float cost = fmt_ok ? 0.f : __builtin_nanf("");
+    const float Jdummy[3][4] = {};
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
+        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
+        const uint8_t *tile_obs = comp + tile_off[tile];
+        const uint32_t r = views_of_wave(n, wave);
+        AccOne acc;
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc.q[q][c][j] = 0.f;
+        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
+        stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, Jdummy, acc);
+
+        // the four waves' per-pixel sums, three quantities (x 3 channels) per round through `red`
+        float tot[9][3];
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            __syncthreads();  // ring (round 0) / previous round retired
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<float4 *>(&lds.u.red[wave][qq * 3 + c][lane * 4]) =
+                        make_float4(acc.q[round * 3 + qq][c][0], acc.q[round * 3 + qq][c][1],
+                                    acc.q[round * 3 + qq][c][2], acc.q[round * 3 + qq][c][3]);
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int pl = qq * 3 + c;
+                    tot[round * 3 + qq][c] =
+                        ((lds.u.red[0][pl][t] + lds.u.red[1][pl][t]) + lds.u.red[2][pl][t]) + lds.u.red[3][pl][t];
+                }
+        }
+        // pixel-parallel tail: this thread owns pixel slot t
+        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float N = tot[0][c], D = tot[1][c];
+            const float Jc = N / D;  // 0/0 = NaN where nothing was observed (sucre.py:77)
+            Jtile[c * kTilePx + t] = Jc;
+            if (D != 0.0f) {
+                sB[c] += __builtin_fmaf(-Jc, tot[3][c], tot[2][c]);
+                sBeta[c] += Jc * __builtin_fmaf(-Jc, tot[5][c], tot[4][c]);
+                sGZ[c] += __builtin_fmaf(-Jc, tot[7][c], tot[6][c]);
+                cost += __builtin_fmaf(-Jc, N, tot[8][c]);
+            }
+        }
+        __syncthreads();  // `red` retired before the next tile's ring prologue overwrites the LDS
+    }
+    float s[kNumSums] = {sB[0], sB[1], sB[2], sGZ[0], sGZ[1], sGZ[2], sBeta[0], sBeta[1], sBeta[2], cost};
+    finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
+}
+
 // SUCRe.update_J alone (sucre.py:66-77, 156)
 template <int kFmt>
 __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ comp,
@@ -533,7 +638,7 @@ __global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ full,
                                                        const float *__restrict__ params, float *__restrict__ Jt,
                                                        const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLdsT<false> lds;
+    __shared__ FitLds lds;
     const int tile = blockIdx.x;
     if (*obs_format != (uint32_t)kFmt) {  // wrong format announced by the caller: poison instead of misreading
         for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + threadIdx.x] = __builtin_nanf("");
@@ -631,9 +736,9 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
     return hipGetLastError();
 }
 
-template <bool kClosed, bool kFused, int kFmt>
+template <bool kFused, int kFmt>
 static void launch_grad_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_grad_kernel<kClosed, kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+    hipLaunchKernelGGL((fit_grad_kernel<kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
                        reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels),
                        reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
@@ -647,26 +752,46 @@ static void launch_grad_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, do
                        reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
 }
 
-template <bool kClosed, bool kFused>
+template <bool kFused, int kFmt>
+static void launch_closed_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
+    hipLaunchKernelGGL((fit_closed_kernel<kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
+                       reinterpret_cast<float *>(ws + L.off_params),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
+                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_partials), co,
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket),
+                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups,
+                       reinterpret_cast<double *>(ws + L.off_sums), trace_row,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
+}
+
+// J-parameter mode: gradient pass + Adam on J; closed-form mode: the one-pass kernel (J re-solved, then constant).
+template <bool kFused>
 static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, double *trace_row,
                                 hipStream_t s) {
-    if (flags & SUCRE_FIT_OBS_U16MM) launch_grad_fmt<kClosed, kFused, 1>(L, ws, co, trace_row, s);
-    else launch_grad_fmt<kClosed, kFused, 0>(L, ws, co, trace_row, s);
+    const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
+    if (flags & SUCRE_FIT_CLOSED_FORM) {
+        if (u16) launch_closed_fmt<kFused, 1>(L, ws, co, trace_row, s);
+        else launch_closed_fmt<kFused, 0>(L, ws, co, trace_row, s);
+    } else {
+        if (u16) launch_grad_fmt<kFused, 1>(L, ws, co, trace_row, s);
+        else launch_grad_fmt<kFused, 0>(L, ws, co, trace_row, s);
+    }
 }
 
 // One whole iteration in a single launch (gradient pass + last-arriver reduction + water-parameter step).
 hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags,
                                  double *trace_row, hipStream_t s) {
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, true>(L, ws, co, flags, trace_row, s);
-    else launch_grad_variant<false, true>(L, ws, co, flags, trace_row, s);
+    launch_grad_variant<true>(L, ws, co, flags, trace_row, s);
     return hipGetLastError();
 }
 
 // Split form for multi-GPU shared-water runs: gradient pass + reduction, sums left at off_sums for the host's
 // all-reduce; launch_fit_step applies them.
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_grad_variant<true, false>(L, ws, co, flags, nullptr, s);
-    else launch_grad_variant<false, false>(L, ws, co, flags, nullptr, s);
+    launch_grad_variant<false>(L, ws, co, flags, nullptr, s);
     hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.n_groups), dim3(256), 0, s,
                        reinterpret_cast<const float *>(ws + L.off_partials), L.n_blocks,
                        reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups);

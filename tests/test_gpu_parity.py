@@ -152,7 +152,7 @@ def test_compact_u16mm_store_vs_oracle_and_golden(golden, closed):
     Jo, po, to = oracle.fit(sc.height, sc.width, oracle.quantize_ranges_u16mm(samples), J0, num_iter=200, use_closed_form=closed)
     assert r.n_obs() == sum(len(s[0]) for s in samples)
     assert np.array_equal(np.isnan(J), np.isnan(Jo))
-    assert helpers.rms_per_channel(J, Jo).max() < (2e-5 if closed else RMS_ORACLE)
+    assert helpers.rms_per_channel(J, Jo).max() < (5e-5 if closed else RMS_ORACLE)
     assert np.abs(trace[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
     assert np.abs(trace[:, 0] / to[:, 0] - 1).max() < 1e-4
     if not closed:
