@@ -1,14 +1,17 @@
 // Exponential-model fit for gfx950.
 //
-// One iteration of sucre.adam (sucre.py:138-148) = fit_grad_kernel (streams the observation store once,
-// updates J in place) + reduce_sums_kernel + param_step_kernel (Adam on B, beta, gamma).
+// One iteration of sucre.adam (sucre.py:138-148) = ONE launch of fit_grad_kernel (J as a parameter) or
+// fit_closed_kernel (--use-closed-form): it streams the compact observation store once, updates J in place, reduces
+// the ten global sums and -- in the workgroup that arrives last -- applies Adam to B, beta, gamma and logs the row.
+// The split form (launch_fit_grad + launch_fit_step) leaves the sums in the workspace for a host all-reduce.
 //
-// Work decomposition: one 256-thread workgroup per 16x16 tile.  Phase 1 is view-parallel: the tile's kept
-// views are dealt round-robin to the four waves, each lane owning 4 pixels x 3 channels, so every load is a
-// fully coalesced 1 KiB (ranges, dwordx4) or 768 B (colours, dwordx3) wave access and the per-pixel sums need
-// no atomics.  Phase 2 adds the four waves' per-pixel sums through LDS in a fixed order; phase 3 is
-// pixel-parallel (one pixel per thread): torch.optim.Adam on J.  The ten global sums go wave shuffle -> LDS ->
-// one float32 partial per tile -> float64 fixed-order reduction, so results are bitwise reproducible.
+// Work decomposition: 1536 persistent 256-thread workgroups, each looping over 16x16-pixel tiles of the sorted
+// compact store (csrc/compact.hip).  Phase 1 is level-parallel: the tile's levels are dealt round-robin to the four
+// waves, each lane owning 4 pixels x 3 channels; a chunk is copied HBM -> LDS by two LDS-DMA instructions into a
+// per-wave ring, so the per-pixel sums need no atomics and prefetch depth costs no registers.  Phase 2 adds the four
+// waves' per-pixel sums through LDS in a fixed order; phase 3 is pixel-parallel (one pixel per thread):
+// torch.optim.Adam on J.  The ten global sums go wave shuffle -> LDS -> one float32 partial per workgroup ->
+// float64 fixed-order two-level reduction, so results are bitwise reproducible.
 //
 // Model (sucre.py:79-82, l = 1):  Ihat = J a + B (1 - g),  a = exp(-beta z),  g = exp(-gamma z),  r = I - Ihat.
 // With L = sum r^2 / (3 n_obs) and s = (1/3)/n_obs (sucre.py:145):
@@ -36,9 +39,10 @@ __device__ __forceinline__ Water load_water(const float *__restrict__ params) {
 // What one pass over a view accumulates.
 enum Pass { kPassGradJ = 0, kPassClosedJ = 1 };
 
-// Measured on gfx950 (tools/microbench.py, no-load build): a scalar fp32 VALU op issues in 2 cycles per wave64, a
-// packed v_pk_*_f32 in 4 and v_exp_f32 in 4, so writing this loop two-wide saved instructions but not time (and
-// cost 20 VGPRs); it stays scalar.  ~57 issue slots per observation: 6 exp, 3 byte->float, 48 mul/fma/select.
+// The kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 89 % of the launch): 15 instructions per
+// observation-channel in the select-free loop, 4 cycles each, 8 for v_exp_f32.  Packed v_pk_*_f32 issues at half
+// rate on gfx950 (tools/probes/valu_probe.hip), so writing the loop two-wide saved instructions but no time (and
+// cost 20 VGPRs); it stays scalar.
 struct Acc {
     float pa[3][4];  // per pixel-channel: sum r a           | closed-form numerator   sum (I - b) a
     float pb[3][4];  // per pixel-channel: sum r a z         | closed-form denominator sum a^2
