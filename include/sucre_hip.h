@@ -171,6 +171,14 @@ int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void
 int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream);
 
 /*
+ * MatchesFile.check_integrity (loader.py:89-101) over the whole store in one launch: verdict_dev[k] (uint32, one per
+ * view) gets bit 0 if a stored range of view k is not finite, bit 1 if one is negative, bit 2 if the number of
+ * stored ranges > 0 differs from the view's match count; 0 = sound.  scratch_dev: n_views uint64 of scratch.
+ */
+int sucre_check_store(const void *ws, int H, int W, int n_views, uint32_t *verdict_dev, uint64_t *scratch_dev,
+                      void *stream);
+
+/*
  * One view of the observation store as dense planes (inverse of the tiling): z (H,W) float32, 0 = no match,
  * and rgb (H,W,3) uint8.  Either output may be NULL.  Used by tests and by the MatchesData compatibility shim.
  */

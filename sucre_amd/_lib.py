@@ -49,6 +49,7 @@ SIGNATURES = {
     'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
     'sucre_update_J_fmt': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'sucre_check_store': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'sucre_export_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sucre_light_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'sucre_light_params_offset': (C.c_int64, [_i, _i, _i]),

@@ -232,6 +232,16 @@ int sucre_export_view(const void *ws, int H, int W, int n_views, int k, float *z
                                         static_cast<hipStream_t>(stream)), "sucre_export_view");
 }
 
+int sucre_check_store(const void *ws, int H, int W, int n_views, uint32_t *verdict_dev, uint64_t *scratch_dev,
+                      void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (!verdict_dev || !scratch_dev) return fail(SUCRE_ERR_ARG, "verdict_dev / scratch_dev is NULL");
+    if (!aligned(verdict_dev, 4) || !aligned(scratch_dev, 8)) return fail(SUCRE_ERR_ARG, "outputs must be 4 / 8-byte aligned");
+    return check_hip(launch_check_store(L, static_cast<const uint8_t *>(ws), verdict_dev, scratch_dev,
+                                        static_cast<hipStream_t>(stream)), "sucre_check_store");
+}
+
 /* ---- artificial-light model (--light-model) ------------------------------------------------------------------ */
 
 size_t sucre_light_workspace_bytes(int H, int W, int n_views) {

@@ -36,6 +36,7 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
                            const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense = nullptr,
                           uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
+hipError_t launch_check_store(const Layout &L, const uint8_t *ws, uint32_t *verdict, uint64_t *scratch, hipStream_t s);
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);
 
 hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, const float *depth1,

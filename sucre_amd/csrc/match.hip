@@ -231,6 +231,33 @@ __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restr
     }
 }
 
+// MatchesFile.check_integrity (loader.py:89-101) for every view in one launch: per view, bit 0 = a stored range is not
+// finite, bit 1 = a stored range is negative, and the number of ranges > 0 (compared with the view's match count by
+// the second kernel -> bit 2).  One workgroup per tile walks the views whose chunk was written.
+__global__ __launch_bounds__(256) void integrity_scan_kernel(const uint8_t *__restrict__ obs,
+                                                             const uint16_t *__restrict__ cnt, int n_views,
+                                                             size_t tile_stride, size_t view_stride,
+                                                             uint32_t *__restrict__ verdict,
+                                                             unsigned long long *__restrict__ positives) {
+    const int tile = blockIdx.x, slot = threadIdx.x;
+    for (int k = 0; k < n_views; ++k) {
+        if (cnt[(size_t)tile * n_views + k] == 0) continue;   // workgroup-uniform: the chunk was never written
+        const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[slot];
+        const uint32_t bad = (__builtin_isfinite(z) ? 0u : 1u) | (z < 0.0f ? 2u : 0u);
+        const unsigned long long pos = __ballot(z > 0.0f);
+        const unsigned long long any_bad = __ballot(bad != 0u);
+        if (any_bad != 0ull && bad != 0u) atomicOr(verdict + k, bad);
+        if ((slot & 63) == 0 && pos != 0ull) atomicAdd(positives + k, (unsigned long long)__popcll(pos));
+    }
+}
+
+__global__ void integrity_verdict_kernel(const unsigned long long *__restrict__ positives,
+                                         const uint64_t *__restrict__ view_count, int n_views,
+                                         uint32_t *__restrict__ verdict) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_views && positives[k] != view_count[k]) verdict[k] |= 4u;
+}
+
 // ---- import of an explicit match list (e.g. one group of a matches file written by the reference, loader.py:68-76)
 // into the dense store: clear view k, scatter the observations, recount the tiles.
 __global__ __launch_bounds__(256) void clear_view_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
@@ -319,6 +346,18 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_compact(L, ws, s, ext_dense, ext_comp, fmt);
+}
+
+hipError_t launch_check_store(const Layout &L, const uint8_t *ws, uint32_t *verdict, uint64_t *scratch, hipStream_t s) {
+    if (hipError_t e = hipMemsetAsync(verdict, 0, sizeof(uint32_t) * L.n_views, s); e != hipSuccess) return e;
+    if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint64_t) * L.n_views, s); e != hipSuccess) return e;
+    hipLaunchKernelGGL(integrity_scan_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, L.obs_tile_stride,
+                       L.obs_view_stride, verdict, reinterpret_cast<unsigned long long *>(scratch));
+    hipLaunchKernelGGL(integrity_verdict_kernel, dim3((L.n_views + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned long long *>(scratch),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_view_count), L.n_views, verdict);
+    return hipGetLastError();
 }
 
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s) {

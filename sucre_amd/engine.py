@@ -177,6 +177,17 @@ class Restoration:
                                                   C.c_void_p(rgb.data_ptr()), _stream_ptr()))
         return z, rgb
 
+    def check_store(self) -> torch.Tensor:
+        """uint32 per view: 0 = sound, bit 0 = non-finite range, bit 1 = negative range, bit 2 = the number of stored
+        ranges differs from the view's match count (the checks of loader.py:89-101, one launch for all views)."""
+        verdict = torch.empty(self.n_views, dtype=torch.int32, device=self.device)
+        scratch = torch.empty(self.n_views, dtype=torch.int64, device=self.device)
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_check_store(ws, H, W, n, C.c_void_p(verdict.data_ptr()),
+                                                  C.c_void_p(scratch.data_ptr()), _stream_ptr()))
+        return verdict
+
     # -- fit (sucre.py:36-82, 124-157) --------------------------------------------------------------------------
     def fit_init(self, target: DeviceView, params0=None, J0: torch.Tensor | None = None) -> None:
         npar = 19 if self.light else 9

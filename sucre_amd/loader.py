@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from collections import namedtuple
 from concurrent.futures import ThreadPoolExecutor
+import os
 from pathlib import Path
 
 import numpy as np
@@ -84,13 +85,47 @@ def load_depth_map(depth_map_path: Path, width: int, height: int) -> Tensor:
     return torch.tensor(depth, dtype=torch.float32)
 
 
-def prefetch_device_views(images, device, num_workers: int = 0) -> None:
-    """Decodes and uploads the pixels of every image not yet resident on ``device`` (threads overlap the PNG /
-    JPEG decode; replaces the reference's DataLoader prefetch, loader.py:173-180)."""
-    todo = [im for im in {id(i): i for i in images}.values()
-            if im._device_view is None or im._device_view[0] != torch.device(device)]
-    if num_workers and len(todo) > 1:
-        with ThreadPoolExecutor(max_workers=num_workers) as pool:
+def load_depth_raw(depth_map_path: Path, width: int, height: int) -> Tensor | None:
+    """(H,W) int32 millimetres exactly as stored in a 16-bit depth PNG (nearest-neighbour resized like
+    ``load_depth_map``), for conversion on the GPU; None when the file is not an unsigned 16-bit image."""
+    depth = _imread_depth_u16(Path(depth_map_path))
+    if depth.dtype != np.uint16 or depth.ndim != 2:
+        return None
+    if depth.shape[0] != height or depth.shape[1] != width:
+        rows = (np.arange(height) * (depth.shape[0] / height)).astype(np.int64).clip(0, depth.shape[0] - 1)
+        cols = (np.arange(width) * (depth.shape[1] / width)).astype(np.int64).clip(0, depth.shape[1] - 1)
+        depth = depth[rows][:, cols]
+    return torch.from_numpy(depth.astype(np.int32))
+
+
+def decode_threads(num_workers: int = 0) -> int:
+    """Threads used to decode image files: ``--num-workers`` when given, else SUCRE_DECODE_THREADS (default 8).
+    PNG/JPEG decoding releases the GIL, and the result does not depend on who decoded it."""
+    return int(num_workers) if num_workers else max(1, int(os.environ.get('SUCRE_DECODE_THREADS', '8')))
+
+
+_PREFETCH_POOL: ThreadPoolExecutor | None = None
+
+
+def prefetch_device_views(images, device, num_workers: int = 0, background: bool = False) -> None:
+    """Decodes and uploads the pixels of every image not yet resident on ``device`` (replaces the reference's
+    DataLoader prefetch, loader.py:173-180).  ``background=True`` returns at once: the decode threads keep filling
+    the per-image caches while the caller matches and fits, and ``Image.device_view`` blocks only on an image
+    that is still being decoded (per-image lock)."""
+    global _PREFETCH_POOL
+    from .sfm import _canonical_device
+    dev = _canonical_device(device)
+    todo = [im for im in {id(i): i for i in images}.values() if im._device_view is None or im._device_view[0] != dev]
+    if not todo:
+        return
+    n = decode_threads(num_workers)
+    if background:
+        if _PREFETCH_POOL is None:
+            _PREFETCH_POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix='sucre-decode')
+        for im in todo:
+            _PREFETCH_POOL.submit(im.device_view, device)
+    elif n > 1 and len(todo) > 1:
+        with ThreadPoolExecutor(max_workers=n) as pool:
             list(pool.map(lambda im: im.device_view(device), todo))
     else:
         for im in todo:
@@ -232,16 +267,17 @@ class MatchesFile:
 
     def check_integrity(self):
         """Device-side counterpart of loader.py:89-101: every stored range must be finite and >= 0 and the
-        per-view totals must add up to n_obs."""
+        per-view totals must add up to n_obs.  One launch checks all views; the verdicts come back in one read."""
         r = self._need()
-        keep = r.view_keep().cpu().numpy().astype(bool)
-        counts = r.view_counts().cpu().numpy()
+        state = torch.cat([r.view_keep().to(torch.int64), r.view_counts().to(torch.int64),
+                           r.check_store().to(torch.int64)]).cpu().numpy()
+        n = r.n_views
+        keep, counts, verdict = state[:n].astype(bool), state[n:2 * n], state[2 * n:]
         assert int(counts[keep].sum()) == r.n_obs(), f'In {self.path}, observation count mismatch.'
         for k in np.nonzero(keep)[0]:
-            z, _ = r.export_view(int(k))
-            assert bool(torch.isfinite(z).all()), f'In {self.path}, view {k} contains NaN(s).'
-            assert bool((z >= 0).all()), f'In {self.path}, view {k} contains null of negative depth(s).'
-            assert int((z > 0).sum()) == int(counts[k]), f'In {self.path}, view {k} lost observations.'
+            assert not verdict[k] & 1, f'In {self.path}, view {k} contains NaN(s).'
+            assert not verdict[k] & 2, f'In {self.path}, view {k} contains null of negative depth(s).'
+            assert not verdict[k] & 4, f'In {self.path}, view {k} lost observations.'
 
     def load_matches(self, pin_memory: bool = False) -> MatchesData:
         return MatchesData(restoration=self._need(), image_list=self.image_list)

@@ -15,6 +15,8 @@ import struct
 from pathlib import Path
 
 import numpy as np
+import threading
+
 import torch
 from torch import Tensor
 
@@ -51,6 +53,14 @@ class Camera:
         return f'Camera(id={self.id}, width={self.width}, height={self.height}, K={self.K!r})'
 
 
+def _canonical_device(device) -> torch.device:
+    """'cuda' and 'cuda:<current>' name the same GPU: the pixel cache must not treat them as different."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 class Image:
     def __init__(self, image_id: int, rgb_path: Path, depth_map_path: Path, pose: Pose, camera: Camera):
         self.id = image_id
@@ -60,6 +70,7 @@ class Image:
         self.pose = pose          # world-from-camera
         self.camera = camera
         self._device_view = None  # (device, engine.DeviceView) cache: pixels stay resident in HBM
+        self._device_lock = threading.Lock()   # decode threads and in-flight slots may ask for the same image
 
     # -- geometry helpers (plain tensor math; used by the output stage and the compatibility shims) -------------
     def unproject_depth(self, u: Tensor, v: Tensor, d: Tensor) -> Tensor:
@@ -87,18 +98,25 @@ class Image:
 
     def device_view(self, device):
         """This image as the engine sees it: uint8 colour + float32 depth resident on ``device`` (cached), and
-        the float32 camera/pose matrices."""
+        the float32 camera/pose matrices.  The files are decoded to their stored integers, uploaded as such
+        (7 instead of 20 bytes per pixel over PCIe) and the depth is converted on the GPU with the reference's
+        arithmetic, ``float32(float64(mm) / 1000)`` (loader.py:167-170)."""
         from . import engine
-        dev = torch.device(device)
-        if self._device_view is None or self._device_view[0] != dev:
-            rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
-            depth = self.get_depth_map()
-            view = engine.DeviceView(depth=depth.to(dev).contiguous(), rgb=rgb.to(dev).contiguous(),
-                                     K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
-            if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
-                torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
-            self._device_view = (dev, view)
-        return self._device_view[1]
+        dev = _canonical_device(device)
+        with self._device_lock:
+            if self._device_view is None or self._device_view[0] != dev:
+                rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
+                mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
+                if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
+                    depth = self.get_depth_map().to(dev).contiguous()
+                else:
+                    depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
+                view = engine.DeviceView(depth=depth, rgb=rgb.to(dev).contiguous(),
+                                         K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
+                if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
+                    torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
+                self._device_view = (dev, view)
+            return self._device_view[1]
 
     def release_device(self) -> None:
         self._device_view = None

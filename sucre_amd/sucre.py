@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import argparse
 import os
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -45,8 +46,16 @@ class SUCRe(torch.nn.Module):
             self.cam2light = torch.nn.Parameter(torch.zeros(6))
             self.sigma = torch.nn.Parameter(torch.eye(2))
         if not use_closed_form:
-            J = image.get_rgb()
-            J[image.get_depth_map() <= 0] = torch.nan
+            cached = getattr(image, '_device_view', None)
+            if cached is not None and cached[0].type == 'cuda':
+                # the pixels are already resident for the engine: same values as get_rgb() / get_depth_map()
+                # (float32(float64(k)/255), loader.py:157-163) without decoding the files a second time
+                view = cached[1]
+                J = (view.rgb.to(torch.float64) / 255).to(torch.float32)
+                J[view.depth <= 0] = torch.nan
+            else:
+                J = image.get_rgb()
+                J[image.get_depth_map() <= 0] = torch.nan
             self.J = torch.nn.Parameter(J)
 
     # -- model evaluation (output stage / compatibility; the fit itself runs in the HIP engine) -------------------
@@ -87,6 +96,8 @@ class SUCRe(torch.nn.Module):
     @torch.no_grad()
     def plot_J(self) -> PILImage.Image:
         """Restored image: per-channel 1-99 percentile stretch of the valid pixels, invalid pixels black."""
+        if self.J.is_cuda:
+            return PILImage.fromarray(self._plot_J_device().cpu().numpy())
         J = self.J.detach().cpu().numpy().copy()
         ok = ~np.isnan(J).any(axis=2)
         vals = J[ok]
@@ -98,11 +109,29 @@ class SUCRe(torch.nn.Module):
         J[ok] = vals
         return PILImage.fromarray(np.uint8(J * 255))
 
+    def _plot_J_device(self) -> Tensor:
+        """The same stretch with J left on the GPU (uint8 (H,W,3) out).  Only the two percentiles are taken on the
+        host, by numpy itself on the valid pixels of one channel at a time, so they are the very numbers the
+        reference computes; clip, min, max, the two float32 divisions' worth of arithmetic and the uint8 cast are
+        IEEE-exact elementwise operations and give the same bits on either side (tested against the host path)."""
+        J = self.J.detach()
+        ok = ~torch.isnan(J).any(dim=2)
+        vals = J[ok]                                              # (n, 3)
+        host = vals.T.contiguous().cpu().numpy()                  # (3, n): one contiguous row per channel
+        lo = np.stack([np.percentile(host[c], 1) for c in range(3)]).astype(np.float32)
+        hi = np.stack([np.percentile(host[c], 99) for c in range(3)]).astype(np.float32)
+        vals = torch.clamp(vals, torch.from_numpy(lo).to(J.device), torch.from_numpy(hi).to(J.device))
+        vals = vals - vals.amin(dim=0)
+        vals = vals / vals.amax(dim=0)
+        out = torch.zeros_like(J)
+        out[ok] = vals
+        return (out * 255).to(torch.uint8)
+
     @torch.no_grad()
     def plot_reconstruction(self) -> PILImage.Image:
         """The image as the fitted model re-synthesises it from J and the depth map."""
         dev = self.B.device
-        u, v, cP = self.image.unproject_depth_map(self.image.get_depth_map().to(dev), to_world=False)
+        u, v, cP = self.image.unproject_depth_map(self._depth_on(dev), to_world=False)
         out = torch.zeros((self.image.camera.height, self.image.camera.width, 3), device=dev)
         out[v, u] = self(u=u, v=v, cP=cP).clip(0, 1).T
         return PILImage.fromarray(np.uint8(out.cpu().numpy() * 255))
@@ -112,19 +141,27 @@ class SUCRe(torch.nn.Module):
         """Illumination factor over the image, jet colour map (sucre.py:96-104)."""
         import matplotlib.pyplot as plt
         dev = self.cam2light.device
-        u, v, cP = self.image.unproject_depth_map(self.image.get_depth_map().to(dev), to_world=False)
+        u, v, cP = self.image.unproject_depth_map(self._depth_on(dev), to_world=False)
         l, _ = self.compute_l_z(cP)
         lmap = torch.zeros((self.image.camera.height, self.image.camera.width), device=dev)
         lmap[v, u] = l
         return PILImage.fromarray(np.uint8(plt.colormaps['jet'](lmap.cpu().numpy())[:, :, :3] * 255))
 
+    def _depth_on(self, dev) -> Tensor:
+        """The target's depth map on ``dev``: the copy already resident for the engine when there is one (same
+        values as ``get_depth_map``), else decoded from the file like the reference does."""
+        if dev.type == 'cuda' and hasattr(self.image, 'device_view'):
+            return self.image.device_view(dev).depth
+        return self.image.get_depth_map().to(dev)
+
     def save_plots(self, save_dir: Path, iteration: int | None = None):
         stem = Path(self.image.name).stem
         tag = '' if iteration is None else f'_{iteration:04d}'
-        self.plot_J().save(Path(save_dir) / f'{stem}_rgb{tag}.png')
-        self.plot_reconstruction().save(Path(save_dir) / f'{stem}_reconstruction{tag}.png')
+        level = int(os.environ.get('SUCRE_PNG_COMPRESS_LEVEL', '1'))   # same pixels; 6 = PIL's default, 4x slower
+        self.plot_J().save(Path(save_dir) / f'{stem}_rgb{tag}.png', compress_level=level)
+        self.plot_reconstruction().save(Path(save_dir) / f'{stem}_reconstruction{tag}.png', compress_level=level)
         if self.light_model:
-            self.plot_l().save(Path(save_dir) / f'{stem}_vignetting{tag}.png')
+            self.plot_l().save(Path(save_dir) / f'{stem}_vignetting{tag}.png', compress_level=level)
 
 
 def _restoration_of(matches_data: loader.MatchesData):
@@ -151,11 +188,16 @@ def _pull_results(sucre: SUCRe, resto) -> None:
             sucre.J.copy_(J)
 
 
-def _log_trace(trace: np.ndarray, first_iteration: int) -> None:
+def _format_trace(trace: np.ndarray, first_iteration: int) -> str:
+    """The per-iteration lines of sucre.py:149-152."""
     with np.printoptions(precision=4):
-        for i, row in enumerate(trace):
-            print(f'iter: {first_iteration + i:04d}, cost: {row[0]:.4e}, B: {row[1:4].astype(np.float32)}, '
-                  f'beta: {row[4:7].astype(np.float32)}, gamma: {row[7:10].astype(np.float32)}')
+        return '\n'.join(f'iter: {first_iteration + i:04d}, cost: {row[0]:.4e}, B: {row[1:4].astype(np.float32)}, '
+                         f'beta: {row[4:7].astype(np.float32)}, gamma: {row[7:10].astype(np.float32)}'
+                         for i, row in enumerate(trace))
+
+
+def _log_trace(trace: np.ndarray, first_iteration: int) -> None:
+    print(_format_trace(trace, first_iteration))
 
 
 def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_iter: int = 200, batch_size: int = 1,
@@ -245,21 +287,36 @@ def _restore_enqueue_fit(job: _Job) -> None:
     job.trace = resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
 
 
-def _restore_finish(job: _Job, keep_matches: bool) -> SUCRe:
+def _restore_finish(job: _Job, keep_matches: bool, writers: ThreadPoolExecutor | None = None):
+    """Results back from the device (the only wait of the image), then the output files (sucre.py:211-219).  With a
+    ``writers`` pool the files are written in the background -- percentile stretch, PNG encoding and the .pt take
+    ~1 s of host time per 1080p image, 30x the GPU time -- and the future is returned instead of the model."""
     sucre = job.sucre
     if job.trace is not None:
-        _log_trace(job.trace.cpu().numpy(), 0)
+        job.trace = job.trace.cpu().numpy()
+        if writers is None:
+            _log_trace(job.trace, 0)
         _pull_results(sucre, _restoration_of(job.matches_data))
+    if keep_matches and job.matches_file.restoration._views_dev is not None:   # freshly matched (not loaded from this
+        print(f'Keep {job.matches_file.save()}.')                              # very file); needs the live workspace
+    if writers is None:
+        _write_outputs(job, keep_matches)
+        return sucre
+    if sucre.B.is_cuda:
+        torch.cuda.current_stream(sucre.B.device).synchronize()   # the writer thread works on another stream
+    return writers.submit(_write_outputs, job, keep_matches, True)
+
+
+def _write_outputs(job: _Job, keep_matches: bool, log: bool = False) -> None:
+    sucre = job.sucre
+    if log and job.trace is not None:   # formatted off the main thread, printed as one block
+        print(f'{job.image.name}:\n' + _format_trace(job.trace, 0))
     sucre.save_plots(save_dir=job.output_dir)
     torch.save({**sucre.cpu().state_dict(), 'J': sucre.J.detach().cpu()},
                (job.output_dir / job.image.name).with_suffix('.pt'))
-    if keep_matches:
-        if job.matches_file.restoration._views_dev is not None:   # freshly matched (not loaded from this very file)
-            print(f'Keep {job.matches_file.save()}.')
-    elif job.matches_path.exists():
+    if not keep_matches and job.matches_path.exists():
         print(f'Erase {job.matches_path}.')
         job.matches_path.unlink()
-    return sucre
 
 
 def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool = False,
@@ -277,25 +334,34 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
 
 def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, output_dir: Path, in_flight: int = 2,
                    keep_matches: bool = False, device: str = 'cuda', **kw) -> None:
-    """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot).
-    While image i iterates, image i+1 is matched and submitted and image i-1's plots are written by the host, so
-    neither the tails of the fit launches nor the PNG encoding leave the GPU idle.  Per-image results are the
-    same bits as ``restore_image`` (each image has its own workspace and stream; nothing is shared)."""
+    """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot)
+    and the output files written by background threads (SUCRE_WRITER_THREADS, default min(16, cores)).  While image i iterates,
+    image i+1 is matched and submitted and the plots of images < i are encoded, so neither the tails of the fit
+    launches nor the PNG encoding leave the GPU idle.  Per-image results are the same bits as ``restore_image``
+    (each image has its own workspace and stream; nothing is shared)."""
     from . import engine
     pending: list[tuple[int, _Job]] = []
-    for i, image in enumerate(images):
-        slot = i % in_flight
-        while pending and (len(pending) >= in_flight or pending[0][0] == slot):
-            s, job = pending.pop(0)
-            with engine.in_flight_slot(s, device):
-                _restore_finish(job, keep_matches)
-        with engine.in_flight_slot(slot, device):
-            job = _restore_submit(image, colmap_model, output_dir, device=device, **kw)
-            _restore_enqueue_fit(job)
-        pending.append((slot, job))
-    for s, job in pending:
-        with engine.in_flight_slot(s, device):
-            _restore_finish(job, keep_matches)
+    written = []
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(16, os.cpu_count() or 1)))),
+                            thread_name_prefix='sucre-write') as writers:
+        def finish(slot, job):
+            with engine.in_flight_slot(slot, device):
+                written.append(_restore_finish(job, keep_matches, writers))
+            while len(written) > 4 * in_flight:       # bound the host memory held by queued outputs
+                written.pop(0).result()
+
+        for i, image in enumerate(images):
+            slot = i % in_flight
+            while pending and (len(pending) >= in_flight or pending[0][0] == slot):
+                finish(*pending.pop(0))
+            with engine.in_flight_slot(slot, device):
+                job = _restore_submit(image, colmap_model, output_dir, device=device, **kw)
+                _restore_enqueue_fit(job)
+            pending.append((slot, job))
+        for slot, job in pending:
+            finish(slot, job)
+        for f in written:
+            f.result()   # re-raises anything a writer thread hit
 
 
 def parse_args(args: argparse.Namespace):
@@ -320,6 +386,8 @@ def parse_args(args: argparse.Namespace):
     skipped = set(args.filter_images_path.read_text().splitlines()) if args.filter_images_path else set()
     image_list = [im for im in colmap_model.images.values() if im.name not in skipped]
     args.output_dir.mkdir(parents=True, exist_ok=True)
+    if str(device).startswith('cuda') and images:   # start decoding + uploading the scene now, in the background
+        loader.prefetch_device_views(image_list + images, device, num_workers=args.num_workers, background=True)
     in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
     if len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda'):
         restore_images(images, colmap_model, args.output_dir, in_flight=in_flight, keep_matches=args.keep_matches,

@@ -287,3 +287,47 @@ def test_cli_images_in_flight_equal_one_by_one(disk_scene, tmp_path, monkeypatch
     Jo, po, to = oracle.fit(64, 96, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=25)
     J = outs['2'][Path(name).with_suffix('.pt').name]['J'].numpy()
     assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-5
+
+
+def test_plot_J_on_the_device_equals_the_host_path():
+    """SUCRe.plot_J with J on the GPU (percentiles by numpy on the host, everything else on the device) must give
+    the same image as the host path, which tests/test_host_logic.py pins to reference-made images."""
+    from sucre_amd import sucre
+    g = torch.Generator().manual_seed(5)
+    for H, W in ((97, 131), (480, 640)):
+        J = torch.rand((H, W, 3), generator=g) ** 2 * 1.3 - 0.1
+        J[torch.rand((H, W), generator=g) < 0.03] = float('nan')
+        J[0, :7] = float('nan')
+        m = sucre.SUCRe.__new__(sucre.SUCRe)
+        torch.nn.Module.__init__(m)
+        m.J = J.clone()
+        host = np.asarray(m.plot_J())
+        m.J = J.cuda()
+        dev = np.asarray(m.plot_J())
+        assert host.shape == (H, W, 3) and np.array_equal(host, dev)
+
+
+def test_check_store_flags_every_kind_of_damage(golden):
+    """sucre_check_store = MatchesFile.check_integrity (loader.py:89-101) in one launch: sound store -> all zero; a
+    NaN, a negative range or a lost observation planted in the store -> the right bit of the right view."""
+    from sucre_amd import engine
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views)
+    assert r.check_store().cpu().tolist() == [0] * len(views)
+    lists = []
+    for k in range(len(views)):
+        z, rgb = r.export_view(k)
+        v1, u1 = torch.nonzero(z > 0, as_tuple=True)
+        lists.append([u1.to(torch.int16), v1.to(torch.int16), z[v1, u1].clone(), rgb[v1, u1].clone()])
+    lists[0][2][3] = float('nan')
+    lists[1][2][5] = -1.0
+    r.import_matches(views[sc.target], [tuple(l) for l in lists])
+    got = r.check_store().cpu().tolist()
+    assert got[0] == 1 and got[1] == 2 and all(g == 0 for g in got[2:])
+    with pytest.raises(AssertionError, match='NaN'):
+        from sucre_amd import loader
+        mf = loader.MatchesFile.__new__(loader.MatchesFile)
+        mf.path, mf.restoration = 'planted', r
+        mf.check_integrity()

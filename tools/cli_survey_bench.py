@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the reference-compatible CLI on a synthetic survey written to disk (PNG images, uint16
+depth maps, COLMAP text model): where does a user's wall time go once the GPU part takes ~30 ms per image?
+usage (GPU box): python3 tools/cli_survey_bench.py [width height grid_x grid_y n_restore]"""
+import cProfile
+import io
+import pstats
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from PIL import Image as PILImage  # noqa: E402
+
+from sucre_amd import sfm, sucre, synth  # noqa: E402
+
+
+def main():
+    W, H, gx, gy, n = (int(a) for a in (sys.argv[1:6] + [1920, 1080, 6, 5, 8][len(sys.argv) - 1:]))
+    survey = synth.make_survey(W, H, gx, gy, seed=3, device='cuda')
+    with tempfile.TemporaryDirectory() as tmp:
+        root = Path(tmp)
+        (root / 'images').mkdir(); (root / 'depth').mkdir()
+        t0 = time.perf_counter()
+        for v in survey.views:
+            PILImage.fromarray(v.rgb_u8.cpu().numpy()).save(root / 'images' / v.name, compress_level=1)
+            PILImage.fromarray(v.depth_u16.cpu().numpy().astype(np.uint16)).save(
+                root / 'depth' / ('depth_' + Path(v.name).stem + '.png'), compress_level=1)
+        sfm.write_colmap_text(root / 'model', survey.K, W, H, [v.name for v in survey.views], [sfm.Pose(v.R.cpu(), v.t.cpu()) for v in survey.views])
+        print(f'wrote {len(survey.views)} views in {time.perf_counter() - t0:.1f}s', flush=True)
+        first = 1 if n >= gx * gy else gx * (gy // 2) + 1
+        argv = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(root / 'out'), '--image-ids', str(first), str(first + n)]
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        pr.enable()
+        sucre.main(argv)
+        pr.disable()
+        dt = time.perf_counter() - t0
+        print(f'CLI: {n} images in {dt:.2f}s = {dt / n * 1e3:.0f} ms/image', flush=True)
+        s = io.StringIO()
+        pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(35)
+        print(s.getvalue()[:6000])
+
+
+if __name__ == '__main__':
+    main()
