@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 # one image at a time, so that a kernel's duration is its own (bench.py overlaps two images by default)
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --images-in-flight 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
+# and the default command (two images in flight: kernel durations overlap)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_inflight2 -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $* > $OUT/bench_trace_inflight2.log 2>&1
 PMCARGS="--steps 1 --warmup 0 --no-cpu-baseline --images-in-flight 1 --num-iter 10 $*"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMCARGS > $OUT/bench_pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMCARGS > $OUT/bench_pmc_fetch.log 2>&1
