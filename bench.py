@@ -51,8 +51,8 @@ def parse():
     p.add_argument('--obs-format', choices=['f32', 'u16mm'], default='f32',
                    help="observation store: f32 = 7 B/obs, lossless (configs 1-4); u16mm = 5 B/obs (config 5)")
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-views', type=int, default=9, help='views in the CPU-baseline sample')
-    p.add_argument('--cpu-iters', type=int, default=5, help='Adam iterations in the CPU-baseline sample')
+    p.add_argument('--cpu-views', type=int, default=25, help='views in the CPU-baseline sample')
+    p.add_argument('--cpu-iters', type=int, default=30, help='Adam iterations in the CPU-baseline sample')
     return p.parse_args()
 
 
