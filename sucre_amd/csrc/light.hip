@@ -132,7 +132,7 @@ struct LightAcc {
 };
 
 // l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
-struct LightObs { float l, z, nl, inl, iz, lp0, lp1, lP[3]; };
+struct LightObs { float l, z, nl, inl, iz, lp0, lp1, w0, w1, lP[3]; };
 
 __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const float (&R)[9], const float (&tl)[3],
                                               const float (&M)[4]) {
@@ -145,7 +145,9 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
     o.iz = __builtin_amdgcn_rcpf(o.lP[2]);
     o.lp0 = o.lP[0] * o.iz;
     o.lp1 = o.lP[1] * o.iz;
-    const float q = o.lp0 * (M[0] * o.lp0 + M[1] * o.lp1) + o.lp1 * (M[2] * o.lp0 + M[3] * o.lp1);
+    o.w0 = __builtin_fmaf(M[0], o.lp0, M[1] * o.lp1);   // M = (sigma^T sigma)^-1 is symmetric: M[1] == M[2]
+    o.w1 = __builtin_fmaf(M[2], o.lp0, M[3] * o.lp1);
+    const float q = __builtin_fmaf(o.lp0, o.w0, o.lp1 * o.w1);
     o.l = fast_exp2(q * (-0.5f * kLog2e));
     const float n2 = o.lP[0] * o.lP[0] + o.lP[1] * o.lP[1] + o.lP[2] * o.lP[2];
     o.inl = __builtin_amdgcn_rsqf(n2);
@@ -199,6 +201,8 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) M[i] = geom[12 + i];
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));
+    const float gB[3] = {gamma[0] * B[0], gamma[1] * B[1], gamma[2] * B[2]};
+    constexpr float kInv255L = (float)(1.0 / 255.0);
 
     LightAcc acc;
 #pragma unroll
@@ -262,10 +266,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
             }
         }
+        float bJ[3][4];   // beta J of this lane's pixels: constant over the tile's observations
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
+            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; bJ[c][j] = beta[c] * J[c][j]; }
         for (uint32_t lv = wave; lv < n; lv += 4) {
             const LightChunk k = load_light_chunk(tobs, text, lv, lane);
 #pragma unroll
@@ -280,21 +285,26 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     const float a = fast_exp2(z * nb[c]), g = fast_exp2(z * ng[c]);
                     const float omg = 1.0f - g;
                     const float E = __builtin_fmaf(J[c][j], a, B[c] * omg);
-                    const float I = unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
-                    const float r = I - l * E;
+                    // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
+                    // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
+                    const uint32_t kb = (k.cc[c] >> (8 * j)) & 255u;
+                    const float r = kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
                     const float rl = r * l;
+                    const float rlz = rl * z;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
                     acc.pa[c][j] = __builtin_fmaf(rl, a, acc.pa[c][j]);
-                    acc.pb[c][j] = __builtin_fmaf(rl * z, a, acc.pb[c][j]);
+                    acc.pb[c][j] = __builtin_fmaf(rlz, a, acc.pb[c][j]);
                     acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
-                    acc.s[3 + c] = __builtin_fmaf(rl * z, g, acc.s[3 + c]);
+                    acc.s[3 + c] = __builtin_fmaf(rlz, g, acc.s[3 + c]);
                     dl = __builtin_fmaf(r, E, dl);
-                    dz = __builtin_fmaf(rl, gamma[c] * B[c] * g - beta[c] * J[c][j] * a, dz);
+                    dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g, -(bJ[c][j] * a)), dz);
                 }
-                // chain rule into lP (common factor -2 s applied in the step kernel)
+                // chain rule into lP (common factor -2 s applied in the step kernel); M symmetric:
+                // d(lp^T M lp)/dlp = 2 M lp = 2 (w0, w1)
                 const float kk = dl * (-0.5f * l);
-                const float dlp0 = kk * ((M[0] * o.lp0 + M[1] * o.lp1) + (M[0] * o.lp0 + M[2] * o.lp1));
-                const float dlp1 = kk * ((M[2] * o.lp0 + M[3] * o.lp1) + (M[1] * o.lp0 + M[3] * o.lp1));
+                const float kk2 = kk + kk;
+                const float dlp0 = kk2 * o.w0;
+                const float dlp1 = kk2 * o.w1;
                 const float iz = o.iz, inl = o.inl;
                 float dlP[3];
                 dlP[0] = dz * o.lP[0] * inl + dlp0 * iz;
@@ -307,8 +317,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
                 }
                 acc.s[22] = __builtin_fmaf(kk * o.lp0, o.lp0, acc.s[22]);
-                acc.s[23] = __builtin_fmaf(kk * o.lp0, o.lp1, acc.s[23]);
-                acc.s[24] = __builtin_fmaf(kk * o.lp1, o.lp0, acc.s[24]);
+                acc.s[23] = __builtin_fmaf(kk * o.lp0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
                 acc.s[25] = __builtin_fmaf(kk * o.lp1, o.lp1, acc.s[25]);
             }
         }
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(512) void light_step_kernel(const double *__restric
     }
     if (tid == 7) {  // sigma: M = Sigma^-1, Sigma = sigma^T sigma;  dSigma = -M^T dM M^T;  dsigma = sigma (dSigma + dSigma^T)
         const double M[4] = {geom[12], geom[13], geom[14], geom[15]};
-        const double dM[4] = {f * sums[22], f * sums[23], f * sums[24], f * sums[25]};
+        const double dM[4] = {f * sums[22], f * sums[23], f * sums[23], f * sums[25]};  // lane 24 is not accumulated (symmetry)
         const double Mt[4] = {M[0], M[2], M[1], M[3]};
         double T1[4], dS[4];
         T1[0] = Mt[0] * dM[0] + Mt[1] * dM[2]; T1[1] = Mt[0] * dM[1] + Mt[1] * dM[3];
