@@ -120,10 +120,15 @@ def prefetch_device_views(images, device, num_workers: int = 0, background: bool
         return
     n = decode_threads(num_workers)
     if background:
+        from .sfm import PIXEL_CACHE
         if _PREFETCH_POOL is None:
             _PREFETCH_POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix='sucre-decode')
+
+        def fetch(im):
+            if not PIXEL_CACHE.full(dev):   # a scene larger than the cache budget is decoded on demand instead
+                im.device_view(device)
         for im in todo:
-            _PREFETCH_POOL.submit(im.device_view, device)
+            _PREFETCH_POOL.submit(fetch, im)
     elif n > 1 and len(todo) > 1:
         with ThreadPoolExecutor(max_workers=n) as pool:
             list(pool.map(lambda im: im.device_view(device), todo))

@@ -15,6 +15,8 @@ import struct
 from pathlib import Path
 
 import numpy as np
+import collections
+import os
 import threading
 
 import torch
@@ -61,6 +63,58 @@ def _canonical_device(device) -> torch.device:
     return dev
 
 
+class _PixelCache:
+    """Budget for the pixels kept resident in HBM (uint8 colour + float32 depth = 7 B/pixel per image): least
+    recently used images are dropped from the cache once the budget (SUCRE_DEVICE_CACHE_GB, default half of the
+    device memory) is exceeded.  Dropping only removes the cache's reference -- a restoration in flight keeps its
+    views alive through its own references -- so a survey larger than the GPU degrades to re-decoding, not to an
+    out-of-memory error."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.entries: 'collections.OrderedDict[int, tuple[Image, int]]' = collections.OrderedDict()
+        self.total = 0
+        self._budget = None
+
+    def budget(self, dev: torch.device) -> int:
+        if self._budget is None:
+            gb = os.environ.get('SUCRE_DEVICE_CACHE_GB')
+            if gb is not None:
+                self._budget = int(float(gb) * 2 ** 30)
+            elif dev.type == 'cuda':
+                self._budget = torch.cuda.mem_get_info(dev)[1] // 2
+            else:
+                self._budget = 1 << 62
+        return self._budget
+
+    def full(self, dev: torch.device) -> bool:
+        return self.total >= self.budget(dev)
+
+    def touch(self, image: 'Image') -> None:
+        with self.lock:
+            if id(image) in self.entries:
+                self.entries.move_to_end(id(image))
+
+    def insert(self, image: 'Image', nbytes: int, dev: torch.device) -> None:
+        with self.lock:
+            self.entries[id(image)] = (image, nbytes)
+            self.entries.move_to_end(id(image))
+            self.total += nbytes
+            while self.total > self.budget(dev) and len(self.entries) > 1:
+                _, (old, n) = self.entries.popitem(last=False)
+                old._device_view = None     # benign race with a reader: it holds its own reference or re-decodes
+                self.total -= n
+
+    def forget(self, image: 'Image') -> None:
+        with self.lock:
+            ent = self.entries.pop(id(image), None)
+            if ent is not None:
+                self.total -= ent[1]
+
+
+PIXEL_CACHE = _PixelCache()
+
+
 class Image:
     def __init__(self, image_id: int, rgb_path: Path, depth_map_path: Path, pose: Pose, camera: Camera):
         self.id = image_id
@@ -104,21 +158,27 @@ class Image:
         from . import engine
         dev = _canonical_device(device)
         with self._device_lock:
-            if self._device_view is None or self._device_view[0] != dev:
-                rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
-                mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
-                if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
-                    depth = self.get_depth_map().to(dev).contiguous()
-                else:
-                    depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
-                view = engine.DeviceView(depth=depth, rgb=rgb.to(dev).contiguous(),
-                                         K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
-                if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
-                    torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
-                self._device_view = (dev, view)
-            return self._device_view[1]
+            cached = self._device_view
+            if cached is not None and cached[0] == dev:
+                PIXEL_CACHE.touch(self)
+                return cached[1]
+            PIXEL_CACHE.forget(self)
+            rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
+            mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
+            if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
+                depth = self.get_depth_map().to(dev).contiguous()
+            else:
+                depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
+            view = engine.DeviceView(depth=depth, rgb=rgb.to(dev).contiguous(),
+                                     K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
+            if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
+                torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
+            self._device_view = (dev, view)
+            PIXEL_CACHE.insert(self, view.depth.numel() * 4 + view.rgb.numel(), dev)
+            return view
 
     def release_device(self) -> None:
+        PIXEL_CACHE.forget(self)
         self._device_view = None
 
     # -- matching ---------------------------------------------------------------------------------------------------

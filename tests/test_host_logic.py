@@ -275,3 +275,26 @@ def test_h5_bridge_writes_the_reference_layout(tmp_path):
         assert set(back[name]) == set(h5bridge.DATASETS)
         for k, v in ds.items():
             assert back[name][k].dtype == v.dtype and back[name][k].shape == v.shape and np.array_equal(back[name][k], v)
+
+
+def test_pixel_cache_evicts_least_recently_used(monkeypatch):
+    """sfm.PIXEL_CACHE: the resident-pixel budget drops the least recently used image's cache entry (only the
+    cache's reference), so a scene larger than the GPU degrades to re-decoding instead of running out of memory."""
+    cache = sfm._PixelCache()
+    cache._budget = 250
+
+    class Fake:
+        def __init__(self):
+            self._device_view = ('dev', object())
+    a, b, c = Fake(), Fake(), Fake()
+    dev = torch.device('cpu')
+    cache.insert(a, 100, dev); cache.insert(b, 100, dev)
+    assert cache.total == 200 and not cache.full(dev)
+    cache.touch(a)                      # b is now the least recently used
+    cache.insert(c, 100, dev)
+    assert b._device_view is None and a._device_view is not None and c._device_view is not None
+    assert cache.total == 200 and list(cache.entries) == [id(a), id(c)]
+    cache.forget(a)
+    assert cache.total == 100
+    cache.insert(a, 1000, dev)          # a single image larger than the budget still stays (it is in use)
+    assert a._device_view is not None and c._device_view is None and cache.total == 1000
