@@ -254,7 +254,8 @@ def main():
                                      'HIP events around the 200 launches of every image in the timed region',
                          'timed_region_ms_per_launch': effective_iter_ms,
                          'timed_region_frac': algo_bytes / (effective_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'obs_passes_per_launch': obs_passes},
+                         'obs_passes_per_launch': obs_passes,
+                         'limiter': 'VALU issue (80-89 % busy, profiles/README.md); HBM is the algorithmic bound'},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scene, n_obs, n_views, T, args.cpu_views, args.cpu_iters)
