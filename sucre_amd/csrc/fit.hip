@@ -99,44 +99,50 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 }
 
 // Closed-form mode in ONE pass over the observations (sucre.py:141 + 142-147 with J a constant of the backward pass).
-// With y = I - B(1-g) (free of J) and J = N/D per pixel-channel, N = sum y a, D = sum a^2, the residual is
-// r = y - J a and every sum the gradient needs factors through per-pixel sums that do not contain J:
-//   sum r (1-g) = S1 - J S2      S1 = sum y (1-g)   S2 = sum a (1-g)
-//   sum r z a   = S3 - J S4      S3 = sum y z a     S4 = sum z a^2
-//   sum r z g   = S5 - J S6      S5 = sum y z g     S6 = sum a z g
-//   sum r^2     = S7 - J N       S7 = sum y^2                      (J^2 D = J N)
-// so the observations are streamed once (the two-pass form: J first, then the gradient, 2x the traffic and 1.4x
-// the VALU work).  The cancellation in S - J S' is of the same size as the one the reference has in r = I - Ihat.
+// Write y = I - B(1-g) (free of J) and let Jp be the pixel's J of the previous iteration.  With the provisional
+// residual p = y - Jp a, the re-solved J = sum y a / sum a^2 is Jp + dJ, dJ = N/D, N = sum p a, D = sum a^2, the true
+// residual is r = p - dJ a, and every sum the gradient needs factors through per-pixel sums that do not contain dJ:
+//   sum r (1-g) = S1 - dJ S2      S1 = sum p (1-g)   S2 = sum a (1-g)
+//   sum r z a   = S3 - dJ S4      S3 = sum p z a     S4 = sum z a^2
+//   sum r z g   = S5 - dJ S6      S5 = sum p z g     S6 = sum a z g
+//   sum r^2     = S7 - dJ N       S7 = sum p^2                      (dJ^2 D = dJ N)
+// so the observations are streamed once (the two-pass form: J first, then the gradient, is 2x the traffic and 1.4x
+// the VALU work).  Measuring from Jp matters: J moves by ~1e-3 per iteration, so p is already at the scale of r and
+// the corrections dJ S' are small -- with p = y the differences S - J S' cancel three to four digits when a pixel
+// has few observations (seen as 1e-4 relative noise on the cost and the gradients of 2-view scenes).
 struct AccOne {
     float q[9][3][4];  // N, D, S1..S7 per pixel-channel
 };
 
 template <int kPass, bool kMasked>
 __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
-                                                const float (&)[3][4], AccOne &acc) {
+                                                const float (&Jp)[3][4], AccOne &acc) {
     const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
     const uint32_t cc[3] = {c3.x, c3.y, c3.z};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float z = zz[j];
+        const bool valid = !kMasked || z > 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t k = (cc[c] >> (8 * j)) & 255u;
             const float a = fast_exp2(z * w.nb[c]);
             const float g = fast_exp2(z * w.ng[c]);
             const float omg = 1.0f - g;
-            const float y = unit_from_u8(k) - w.B[c] * omg;  // padding slot: z = 0, colour 0 -> g = 1, y = 0
-            const float za = z * a, zg = z * g;
-            acc.q[0][c][j] = __builtin_fmaf(y, a, acc.q[0][c][j]);
-            if (kMasked) acc.q[1][c][j] += (z > 0.0f) ? a * a : 0.0f;  // the only sum a padding slot would touch
+            const float y = unit_from_u8(k) - w.B[c] * omg;
+            float p = __builtin_fmaf(-Jp[c][j], a, y);
+            p = valid ? p : 0.0f;  // select, not multiply: Jp is NaN where the pixel has never been observed
+            const float za = z * a, zg = z * g;  // a padding slot has z = 0, g = 1: it only touches D (masked below)
+            acc.q[0][c][j] = __builtin_fmaf(p, a, acc.q[0][c][j]);
+            if (kMasked) acc.q[1][c][j] += valid ? a * a : 0.0f;
             else acc.q[1][c][j] = __builtin_fmaf(a, a, acc.q[1][c][j]);
-            acc.q[2][c][j] = __builtin_fmaf(y, omg, acc.q[2][c][j]);
+            acc.q[2][c][j] = __builtin_fmaf(p, omg, acc.q[2][c][j]);
             acc.q[3][c][j] = __builtin_fmaf(a, omg, acc.q[3][c][j]);
-            acc.q[4][c][j] = __builtin_fmaf(y, za, acc.q[4][c][j]);
+            acc.q[4][c][j] = __builtin_fmaf(p, za, acc.q[4][c][j]);
             acc.q[5][c][j] = __builtin_fmaf(a, za, acc.q[5][c][j]);
-            acc.q[6][c][j] = __builtin_fmaf(y, zg, acc.q[6][c][j]);
+            acc.q[6][c][j] = __builtin_fmaf(p, zg, acc.q[6][c][j]);
             acc.q[7][c][j] = __builtin_fmaf(a, zg, acc.q[7][c][j]);
-            acc.q[8][c][j] = __builtin_fmaf(y, y, acc.q[8][c][j]);
+            acc.q[8][c][j] = __builtin_fmaf(p, p, acc.q[8][c][j]);
         }
     }
 }
@@ -576,7 +582,6 @@ __global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restri
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
     float sB[3] = {0.f, 0.f, 0.f}, sGZ[3] = {0.f, 0.f, 0.f}, sBeta[3] = {0.f, 0.f, 0.f};
     float cost = fmt_ok ? 0.f : __builtin_nanf("");
-    const float Jdummy[3][4] = {};
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
         const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
@@ -589,8 +594,21 @@ __global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restri
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc.q[q][c][j] = 0.f;
+        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
         stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-        stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, Jdummy, acc);
+        // previous J of this lane's four pixels: ordinary loads issued behind the ring prologue (see fit_grad_kernel)
+        float Jp[3][4];
+        {
+            float4 jv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
+                Jp[c][0] = jv[c].x; Jp[c][1] = jv[c].y; Jp[c][2] = jv[c].z; Jp[c][3] = jv[c].w;
+            }
+        }
+        stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, Jp, acc);
 
         // the four waves' per-pixel sums, three quantities (x 3 channels) per round through `red`
         float tot[9][3];
@@ -615,17 +633,17 @@ __global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restri
                 }
         }
         // pixel-parallel tail: this thread owns pixel slot t
-        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float N = tot[0][c], D = tot[1][c];
-            const float Jc = N / D;  // 0/0 = NaN where nothing was observed (sucre.py:77)
+            const float dJ = N / D;                          // 0/0 = NaN where nothing was observed (sucre.py:77)
+            const float Jc = Jtile[c * kTilePx + t] + dJ;    // = sum y a / sum a^2
             Jtile[c * kTilePx + t] = Jc;
             if (D != 0.0f) {
-                sB[c] += __builtin_fmaf(-Jc, tot[3][c], tot[2][c]);
-                sBeta[c] += Jc * __builtin_fmaf(-Jc, tot[5][c], tot[4][c]);
-                sGZ[c] += __builtin_fmaf(-Jc, tot[7][c], tot[6][c]);
-                cost += __builtin_fmaf(-Jc, N, tot[8][c]);
+                sB[c] += __builtin_fmaf(-dJ, tot[3][c], tot[2][c]);
+                sBeta[c] += Jc * __builtin_fmaf(-dJ, tot[5][c], tot[4][c]);
+                sGZ[c] += __builtin_fmaf(-dJ, tot[7][c], tot[6][c]);
+                cost += __builtin_fmaf(-dJ, N, tot[8][c]);
             }
         }
         __syncthreads();  // `red` retired before the next tile's ring prologue overwrites the LDS

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: many small scenes (odd sizes, few/many views, steep relief, large twist
+noise, many invalid pixels, far views) -- matching must be bit-identical to the CPU oracle and the fit must stay
+within the test tolerances, in every mode.  Not a test (too long for the suite); run by hand:
+    python3 tools/parity_sweep.py [n_scenes] [seed0]"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
+import helpers  # noqa: E402
+from oracle import oracle  # noqa: E402
+from sucre_amd import engine, synth  # noqa: E402
+
+
+def main():
+    n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    rng = np.random.default_rng(seed0)
+    worst = {'J': 0.0, 'Jc': 0.0, 'Ju': 0.0, 'p': 0.0, 'pc': 0.0}
+    t0 = time.time()
+    for s in range(n_scenes):
+        W, H = int(rng.integers(33, 260)), int(rng.integers(33, 200))
+        nn = int(rng.integers(1, 14))
+        kw = dict(relief=float(rng.choice([0.0, 0.15, 0.6])), spacing=float(rng.choice([0.05, 0.1, 0.25, 0.5])),
+                  invalid_frac=float(rng.choice([0.0, 0.01, 0.3])), rot_sigma=float(rng.choice([0.0, 0.03, 0.15])),
+                  pos_sigma=float(rng.choice([0.0, 0.1, 0.4])), far_views=int(rng.integers(0, 3)))
+        sc = synth.make_scene(W, H, nn, seed=seed0 + s, **kw)
+        per_view, samples = helpers.oracle_scene_samples(sc)
+        views = engine.device_views_from_scene(sc, 'cuda')
+        tgt = sc.views[sc.target]
+        T = int(rng.choice([3, 20, 60]))
+        for fmt in ('f32', 'u16mm'):
+            r = engine.Restoration(H, W, len(views), obs_format=fmt)
+            r.match(views[sc.target], views)
+            assert r.view_counts().cpu().numpy().tolist() == [len(m) for _, _, m in per_view], (s, 'counts')
+            kept = [k for _, k, _ in per_view]
+            assert r.view_keep().cpu().numpy().astype(bool).tolist() == kept, (s, 'kept')
+            if fmt == 'f32':
+                for k, (_, _, m) in enumerate(per_view):
+                    ref = np.full((H, W), -1, np.int32)
+                    ref[m.v1.astype(np.int64), m.u1.astype(np.int64)] = m.v2.astype(np.int32) * W + m.u2.astype(np.int32)
+                    assert np.array_equal(r.match_map(k).cpu().numpy(), ref), (s, 'map', k)
+            if r.n_obs() == 0:
+                continue
+            smp = samples if fmt == 'f32' else oracle.quantize_ranges_u16mm(samples)
+            for closed in (False, True):
+                r.fit_init(views[sc.target])
+                tr = r.fit(T, use_closed_form=closed).cpu().numpy()
+                J = r.J().cpu().numpy()
+                J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+                Jo, po, to = oracle.fit(H, W, smp, J0, num_iter=T, use_closed_form=closed)
+                assert np.array_equal(np.isnan(J), np.isnan(Jo)), (s, fmt, closed, 'nan mask')
+                rms = float(np.nan_to_num(helpers.rms_per_channel(J, Jo)).max())
+                dp = float(np.abs(tr[:, 1:] - to[:, 1:]).max())
+                key = ('Jc' if closed else 'J') if fmt == 'f32' else 'Ju'
+                worst[key] = max(worst[key], rms)
+                worst['pc' if closed else 'p'] = max(worst['pc' if closed else 'p'], dp)
+                bar_J, bar_p = (1e-4, 1e-3) if closed else (1e-5, 1e-4)
+                assert rms < bar_J and dp < bar_p, (s, fmt, closed, rms, dp, W, H, nn, kw, T)
+        if (s + 1) % 10 == 0:
+            print(f'{s + 1} scenes ok, worst so far {worst}, {time.time() - t0:.0f}s', flush=True)
+    print('sweep ok', worst)
+
+
+if __name__ == '__main__':
+    main()
