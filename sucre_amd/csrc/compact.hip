@@ -256,6 +256,86 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__
     }
 }
 
+// 3c'. the same compaction driven from the DENSE side (the default; the gather above remains for the light model,
+//      whose camera-point planes ride along).  The gather reads 4 + 3 x 1 bytes per observation from a different
+//      (tile, view) chunk for every thread, and a dense chunk is re-read by every sorted tile that holds some of its
+//      pixels (~7 count bins per tile): 3.9 GB fetched for 0.55 GB of observations (rocprofv3 FETCH_SIZE), which makes
+//      it HBM-bound at 1.13 ms.  Here one workgroup owns one dense tile: it stages the tile's chunks through LDS
+//      32 views at a time -- every chunk is read from HBM exactly once, fully coalesced -- and each thread (pixel)
+//      then emits its observations level by level to its slot of the sorted order.  Pixels of one dense tile that fall
+//      into the same count bin are neighbours in the sorted order (the sort is stable), so these writes form runs.
+#ifndef SUCRE_STAGE_VIEWS
+#define SUCRE_STAGE_VIEWS 32
+#endif
+constexpr int kStageViews = SUCRE_STAGE_VIEWS;  // 32 x 1792 B = 56 KB of LDS: two workgroups per CU
+
+template <int kFmt>
+__global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
+                                                      size_t view_stride, const uint32_t *__restrict__ invperm,
+                                                      const uint64_t *__restrict__ pmask, int mask_words,
+                                                      const uint32_t *__restrict__ levels,
+                                                      const uint64_t *__restrict__ tile_off,
+                                                      uint8_t *__restrict__ comp, int n_views) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kChunk];
+    __shared__ uint32_t present;
+    __shared__ uint8_t vl[kStageViews];
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
+    const uint32_t dtile = dst / kTilePx, dslot = dst % kTilePx;
+    const uint32_t nl = levels[dtile];
+    uint8_t *out = comp + tile_off[dtile];
+    const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
+    const uint8_t *tbase = obs + (size_t)tile * tile_stride;
+    constexpr int cb = kFmt ? kChunk16 : kChunk, zb = kFmt ? kChunkZ16 : kChunkZ;
+    constexpr int kUnits = kChunk / 16;  // 16-byte pieces of a chunk
+    uint32_t lv = 0;
+    for (int g0 = 0; g0 < n_views; g0 += kStageViews) {
+        const uint32_t bits = (uint32_t)(mask[g0 >> 6] >> (g0 & 63)) &
+                              (kStageViews == 32 ? 0xffffffffu : ((1u << (kStageViews & 31)) - 1u));  // views g0 .. g0+kStageViews-1
+        if (t == 0) present = 0u;
+        __syncthreads();
+        if (bits) atomicOr(&present, bits);
+        __syncthreads();
+        const uint32_t p = present;  // views of the group that some pixel of the tile uses (workgroup-uniform)
+        if (p == 0u) continue;
+        if (t < kStageViews && ((p >> t) & 1u)) vl[__builtin_popcount(p & ((1u << t) - 1u))] = (uint8_t)t;
+        __syncthreads();
+        const int total = __builtin_popcount(p) * kUnits;
+        for (int u = t; u < total; u += 256) {
+            const int i = vl[u / kUnits], w = u % kUnits;
+            *reinterpret_cast<uint4 *>(&stage[i][w * 16]) =
+                *reinterpret_cast<const uint4 *>(tbase + (size_t)(g0 + i) * view_stride + (size_t)w * 16);
+        }
+        __syncthreads();
+        uint32_t m = bits;
+        while (m) {
+            const int i = __builtin_ctz(m);
+            m &= m - 1u;
+            const float z = reinterpret_cast<const float *>(&stage[i][0])[t];
+            uint8_t *o = out + (size_t)lv * cb;
+            if (kFmt) {
+                const float mm = fminf(fmaxf(rintf(z * kMmPerM), 1.0f), 65535.0f);
+                reinterpret_cast<uint16_t *>(o)[dslot] = z > 0.0f ? (uint16_t)mm : (uint16_t)0;
+            } else {
+                reinterpret_cast<float *>(o)[dslot] = z;
+            }
+            o[zb + dslot] = stage[i][kChunkZ + t];
+            o[zb + kTilePx + dslot] = stage[i][kChunkZ + kTilePx + t];
+            o[zb + 2 * kTilePx + dslot] = stage[i][kChunkZ + 2 * kTilePx + t];
+            ++lv;
+        }
+        __syncthreads();  // everyone is done with the stage before the next group overwrites it
+    }
+    for (; lv < nl; ++lv) {  // padding slots of this pixel: the sorted tile has more levels than it has observations
+        uint8_t *o = out + (size_t)lv * cb;
+        if (kFmt) reinterpret_cast<uint16_t *>(o)[dslot] = 0;
+        else reinterpret_cast<float *>(o)[dslot] = 0.0f;
+        o[zb + dslot] = 0;
+        o[zb + kTilePx + dslot] = 0;
+        o[zb + 2 * kTilePx + dslot] = 0;
+    }
+}
+
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
                           int fmt) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
@@ -280,14 +360,17 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
                        reinterpret_cast<uint32_t *>(ws + L.off_full));
     hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
-    if (fmt)
-        hipLaunchKernelGGL(gather_kernel<1>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                           L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
-                           ext_dense, ext_comp);
-    else
+    if (ext_dense) {  // light model: float32 store only, camera points carried by the gather
         hipLaunchKernelGGL(gather_kernel<0>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
                            L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
                            ext_dense, ext_comp);
+    } else if (fmt) {
+        hipLaunchKernelGGL(scatter_kernel<1>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
+                           L.obs_view_stride, invperm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views);
+    } else {
+        hipLaunchKernelGGL(scatter_kernel<0>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
+                           L.obs_view_stride, invperm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views);
+    }
     return hipGetLastError();
 }
 
