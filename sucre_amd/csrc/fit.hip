@@ -110,6 +110,8 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 // the VALU work).  Measuring from Jp matters: J moves by ~1e-3 per iteration, so p is already at the scale of r and
 // the corrections dJ S' are small -- with p = y the differences S - J S' cancel three to four digits when a pixel
 // has few observations (seen as 1e-4 relative noise on the cost and the gradients of 2-view scenes).
+__device__ __forceinline__ float finite_or_zero(float x) { return __builtin_isfinite(x) ? x : 0.0f; }
+
 struct AccOne {
     float q[9][3][4];  // N, D, S1..S7 per pixel-channel
 };
@@ -131,7 +133,7 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
             const float omg = 1.0f - g;
             const float y = unit_from_u8(k) - w.B[c] * omg;
             float p = __builtin_fmaf(-Jp[c][j], a, y);
-            p = valid ? p : 0.0f;  // select, not multiply: Jp is NaN where the pixel has never been observed
+            p = valid ? p : 0.0f;  // a padding slot contributes nothing (its Jp a is not zero)
             const float za = z * a, zg = z * g;  // a padding slot has z = 0, g = 1: it only touches D (masked below)
             acc.q[0][c][j] = __builtin_fmaf(p, a, acc.q[0][c][j]);
             if (kMasked) acc.q[1][c][j] += valid ? a * a : 0.0f;
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restri
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
-                Jp[c][0] = jv[c].x; Jp[c][1] = jv[c].y; Jp[c][2] = jv[c].z; Jp[c][3] = jv[c].w;
+                // a pixel that had no J so far (NaN: never observed, or a warm start without it) is measured from 0
+                Jp[c][0] = finite_or_zero(jv[c].x); Jp[c][1] = finite_or_zero(jv[c].y);
+                Jp[c][2] = finite_or_zero(jv[c].z); Jp[c][3] = finite_or_zero(jv[c].w);
             }
         }
         stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, Jp, acc);
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restri
         for (int c = 0; c < 3; ++c) {
             const float N = tot[0][c], D = tot[1][c];
             const float dJ = N / D;                          // 0/0 = NaN where nothing was observed (sucre.py:77)
-            const float Jc = Jtile[c * kTilePx + t] + dJ;    // = sum y a / sum a^2
+            const float Jc = finite_or_zero(Jtile[c * kTilePx + t]) + dJ;    // = sum y a / sum a^2
             Jtile[c * kTilePx + t] = Jc;
             if (D != 0.0f) {
                 sB[c] += __builtin_fmaf(-dJ, tot[3][c], tot[2][c]);

@@ -453,3 +453,25 @@ def test_light_model_closed_form_vs_reference_golden(golden):
     Jr = golden['J_light_closed_100']
     rms = helpers.rms_per_channel(J, Jr)
     assert np.array_equal(np.isnan(J), np.isnan(Jr)) and rms[1:].max() < 2e-4 and rms[0] < 5e-2
+
+
+def test_closed_form_does_not_depend_on_the_starting_J(golden):
+    """The one-pass closed-form kernel measures residuals from the previous J for accuracy only: J is re-solved from
+    the observations every iteration (sucre.py:141), so a warm start with garbage or NaN in J must end where the
+    default start ends (to rounding)."""
+    from sucre_amd import engine
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views)
+    outs = []
+    g = torch.Generator().manual_seed(3)
+    starts = [None, torch.full((sc.height, sc.width, 3), float('nan')), torch.rand((sc.height, sc.width, 3), generator=g) * 5 - 2]
+    for J0 in starts:
+        r.fit_init(views[sc.target], J0=J0)
+        tr = r.fit(40, use_closed_form=True).cpu().numpy()
+        outs.append((r.J().cpu().numpy(), tr))
+    for J, tr in outs[1:]:
+        assert np.array_equal(np.isnan(J), np.isnan(outs[0][0]))
+        assert helpers.rms_per_channel(J, outs[0][0]).max() < 2e-5
+        assert np.abs(tr[:, 1:] - outs[0][1][:, 1:]).max() < 1e-4
