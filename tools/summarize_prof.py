@@ -35,7 +35,7 @@ for d in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
             cnt[k][r['Counter_Name']] += 1
         print(f'== {d}: per-dispatch averages')
         for k in acc:
-            if not any(s in k for s in ('fit_grad', 'fit_closed', 'light_grad', 'match_kernel', 'update_J', 'gather_kernel')):
+            if not any(s in k for s in ('fit_grad', 'fit_closed', 'light_grad', 'match_kernel', 'update_J', 'gather_kernel', 'scatter_kernel')):
                 continue
             print(' ', k)
             for c in sorted(acc[k]):
