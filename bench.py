@@ -135,9 +135,36 @@ def main():
 
     fit_events = []
 
+    group_restos = None
+    if args.shared_water and len(jobs) > 1:
+        # BASELINE config 4 shape: every image of this rank (and of every other rank) shares B, beta, gamma, so all
+        # of them are matched first and then step in lock-step -- one workspace per image
+        group_restos = [resto] + [engine.Restoration(H, W, n_views, device=device, obs_format=args.obs_format)
+                                  for _ in range(len(jobs) - 1)]
+
     def step(record):
+        if group_restos is not None:
+            return shared_water_step(record)
         for tgt, views in jobs:
             restore_one(tgt, views, record)
+
+    def shared_water_step(record):
+        for r, (tgt, views) in zip(group_restos, jobs):
+            r.match(tgt, views, min_cover=1e-6)
+            r.fit_init(tgt)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        group = engine.HipWaterGroup([engine.HipWaterBackend(r, use_closed_form=args.use_closed_form) for r in group_restos])
+        sdist.fit_shared_water(group, T)
+        if args.use_closed_form:
+            for r in group_restos:
+                r.update_J()
+        if record:
+            e1.record()
+            fit_events.append((e0, e1))
+        for r in group_restos:
+            J_out[0] = r.J()
 
     def restore_one(tgt, views, record, slot=None):
         nonlocal submitted
@@ -207,7 +234,7 @@ def main():
         fit_events.clear()
         restore_one(*jobs[0], True, slot=0)
         torch.cuda.synchronize()
-    fit_ms = sum(a.elapsed_time(b) for a, b in fit_events) / len(fit_events)
+    fit_ms = sum(a.elapsed_time(b) for a, b in fit_events) / len(fit_events) / (len(jobs) if group_restos is not None else 1)
     iter_ms = fit_ms / T
     if S == 1:
         effective_iter_ms = iter_ms

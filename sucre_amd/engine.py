@@ -303,6 +303,37 @@ class HipWaterBackend:
         self.r.steps_done = int(step)
 
 
+class HipWaterGroup:
+    """dist.WaterBackend over SEVERAL restorations of this rank (BASELINE config 4: a 512-image scene, 64 images per
+    GPU, all sharing B, beta, gamma): the images' gradient sums are added on the device before the one all-reduce of
+    the iteration, and every image then applies the same reduced sums."""
+
+    def __init__(self, backends: list[HipWaterBackend]):
+        assert backends, 'need at least one image'
+        self.backends = list(backends)
+        self._total = torch.zeros(12, dtype=torch.float64, device=backends[0].r.device)
+
+    def grad_device(self):
+        return self.backends[0].r.device
+
+    def n_obs(self) -> int:
+        return sum(b.n_obs() for b in self.backends)
+
+    def set_n_obs_total(self, n: int) -> None:
+        for b in self.backends:
+            b.set_n_obs_total(n)
+
+    def grad(self, step: int) -> torch.Tensor:
+        sums = [b.grad(step) for b in self.backends]
+        torch.sum(torch.stack(sums), dim=0, out=self._total)   # fixed order: image 0, 1, ... (float64)
+        return self._total
+
+    def step(self, step: int) -> None:
+        for b in self.backends:
+            b._sums.copy_(self._total)
+            b.step(step)
+
+
 _POOL: dict = {}
 _STREAMS: dict = {}
 _SLOT = 0          # the in-flight slot the calling code is working for (see in_flight_slot)

@@ -138,16 +138,11 @@ def test_shared_water_split_path_vs_oracle():
         oimgs.append(oracle.SharedWaterImage(32, 48, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
     total = sum(b.n_obs() for b in backends)
     assert total == sum(o.n_obs for o in oimgs)
-    for b in backends:
-        b.set_n_obs_total(total)
+    # several images of one rank: engine.HipWaterGroup adds their sums before the (here absent) all-reduce
+    from sucre_amd import dist as sdist
+    sdist.fit_shared_water(engine.HipWaterGroup(backends), T)
     pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
     for it in range(1, T + 1):
-        sums = [b.grad(it) for b in backends]
-        red = sums[0] + sums[1]                     # what dist.all_reduce(SUM) leaves on every rank
-        for s in sums:
-            s.copy_(red)
-        for b in backends:
-            b.step(it)
         acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
         oracle.shared_step(pstate, acc, it, total)
     p0, p1 = backends[0].r.params().cpu().numpy(), backends[1].r.params().cpu().numpy()
