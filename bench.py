@@ -106,12 +106,12 @@ def main():
 
     # every rank restores its own image(s) (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
     if args.batch_images > 1:
-        side = int((args.neighbours + 1) ** 0.5) + 1
-        gx = side + 8
-        gy = side + (args.batch_images + 7) // 8 - 1
+        half = (int((args.neighbours + 1) ** 0.5) + 1) // 2      # cameras needed around a target on each side
+        rows = (args.batch_images + 7) // 8
+        gx, gy = 2 * half + 8, 2 * half + rows                   # targets: a block of rows x 8 interior cameras
         survey = synth.make_survey(W, H, gx, gy, seed=rank, device=device)
         all_views = engine.device_views_from_scene(survey, device)
-        centre = [j * gx + i for j in range(side // 2, gy - side // 2) for i in range(side // 2, gx - side // 2)]
+        centre = [j * gx + i for j in range(half, half + rows) for i in range(half, half + 8)]
         jobs = []
         for idx in centre[:args.batch_images]:
             sel = survey.neighbours(idx, args.neighbours)
