@@ -58,6 +58,16 @@ extern "C" {
 #define SUCRE_OBS_U16MM 1
 
 /*
+ * What the three float32 extension planes of the second workspace (`lws`, see the *_light entry points) carry per
+ * observation.  SUCRE_EXT_POINTS: the camera-frame point cP (artificial-light model).  SUCRE_EXT_COLOUR: the colour I
+ * as float32 -- for inputs that are not k/255 (the reference's --image-scale resizes colours in float64,
+ * loader.py:156-163), with the plain water model; the uint8 colours of the main store are then unused.
+ */
+#define SUCRE_EXT_POINTS 1
+#define SUCRE_EXT_COLOUR 2
+#define SUCRE_FIT_EXT_COLOUR 4u  /* flag of sucre_fit_run_light / sucre_update_J_ext: lws was matched with SUCRE_EXT_COLOUR */
+
+/*
  * One view of the scene = the arguments the reference reads from an sfm.Image (sfm.py:81-88): depth map,
  * colour image, camera, pose.  The 3x3 matrices are row-major float32 and must be computed by the caller the
  * way the reference computes them (Kinv = K.inverse(), sfm.py:92; Rinv/tinv = Pose.inverse() = (R.T, -R.T@t),
@@ -199,13 +209,17 @@ size_t sucre_light_workspace_bytes(int H, int W, int n_views);
 int64_t sucre_light_params_offset(int H, int W, int n_views);
 int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
                             const sucre_view_t *views_dev, int k0, int k1, void *stream);
+/* Same with float32 colour images: every view's `rgb` points to (H,W,3) float32 instead of uint8 (SUCRE_EXT_COLOUR). */
+int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                              const sucre_view_t *views_dev, int k0, int k1, void *stream);
 int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream);
 int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
                          const float *params0, const float *J0_dev, void *stream);
 /* closed-form J with the illumination factor in absorption and backscatter (sucre.py:66-77 with light_model) */
 int sucre_update_J_light(void *ws, void *lws, int H, int W, int n_views, void *stream);
+int sucre_update_J_ext(void *ws, void *lws, int H, int W, int n_views, unsigned flags, void *stream);
 int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
-                        double beta2, double eps, unsigned flags /* SUCRE_FIT_CLOSED_FORM or 0 */, double *trace_dev,
+                        double beta2, double eps, unsigned flags /* SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR */, double *trace_dev,
                         void *stream);
 
 #ifdef __cplusplus

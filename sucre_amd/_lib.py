@@ -15,6 +15,7 @@ LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent 
 
 FIT_CLOSED_FORM = 1
 FIT_OBS_U16MM = 2
+FIT_EXT_COLOUR = 4
 OBS_F32, OBS_U16MM = 0, 1
 OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)
@@ -54,9 +55,11 @@ SIGNATURES = {
     'sucre_light_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'sucre_light_params_offset': (C.c_int64, [_i, _i, _i]),
     'sucre_match_views_light': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_match_views_fcolour': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
     'sucre_finalize_matches_light': (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     'sucre_fit_init_light': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
     'sucre_update_J_light': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'sucre_update_J_ext': (_i, [_vp, _vp, _i, _i, _i, C.c_uint, _vp]),
     'sucre_fit_run_light': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp, _vp]),
 }
 

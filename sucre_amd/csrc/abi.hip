@@ -274,6 +274,18 @@ int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, cons
                                   light_ext_dense(L, static_cast<uint8_t *>(lws))), "sucre_match_views_light");
 }
 
+int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                              const sucre_view_t *views_dev, int k0, int k1, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (!target || !views_dev || !target->depth) return fail(SUCRE_ERR_ARG, "target / views_dev / target depth is NULL");
+    if (target->H != H || target->W != W) return fail(SUCRE_ERR_ARG, "target is %dx%d, expected %dx%d", target->W, target->H, W, H);
+    if (k0 < 0 || k1 > n_views || k0 >= k1) return fail(SUCRE_ERR_RANGE, "view range [%d,%d) outside [0,%d)", k0, k1, n_views);
+    return check_hip(launch_match(L, static_cast<uint8_t *>(ws), *target, views_dev, k0, k1, static_cast<hipStream_t>(stream),
+                                  light_ext_dense(L, static_cast<uint8_t *>(lws)), SUCRE_EXT_COLOUR), "sucre_match_views_fcolour");
+}
+
 int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
@@ -298,11 +310,16 @@ int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const u
 }
 
 int sucre_update_J_light(void *ws, void *lws, int H, int W, int n_views, void *stream) {
+    return sucre_update_J_ext(ws, lws, H, W, n_views, 0u, stream);
+}
+
+int sucre_update_J_ext(void *ws, void *lws, int H, int W, int n_views, unsigned flags, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (int rc = check_lws(lws)) return rc;
-    return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
-                                           static_cast<hipStream_t>(stream)), "sucre_update_J_light");
+    if (flags & ~SUCRE_FIT_EXT_COLOUR) return fail(SUCRE_ERR_ARG, "unknown flags 0x%x", flags);
+    return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), flags,
+                                           static_cast<hipStream_t>(stream)), "sucre_update_J_ext");
 }
 
 int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
@@ -313,7 +330,7 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
-    if (flags & ~SUCRE_FIT_CLOSED_FORM) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
         if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co, flags,
@@ -322,7 +339,8 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     }
     if (flags & SUCRE_FIT_CLOSED_FORM)  // the final update_J of sucre.py:156
         return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
-                                               static_cast<hipStream_t>(stream)), "sucre_fit_run_light/update_J");
+                                               flags & SUCRE_FIT_EXT_COLOUR, static_cast<hipStream_t>(stream)),
+                         "sucre_fit_run_light/update_J");
     return SUCRE_OK;
 }
 

@@ -27,7 +27,7 @@ struct AdamCoef {
 AdamCoef adam_coef(int step, double lr, double beta1, double beta2, double eps);
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s, uint8_t *ext = nullptr);
+                        int k0, int k1, hipStream_t s, uint8_t *ext = nullptr, int ext_mode = SUCRE_EXT_POINTS);
 hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
                             int32_t *map, hipStream_t s);
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
@@ -57,6 +57,6 @@ uint8_t *light_ext_comp(const Layout &L, uint8_t *lws);
 hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params19, hipStream_t s);
 hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, unsigned flags,
                              double *trace_row, hipStream_t s);
-hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, hipStream_t s);
+hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s);
 
 }  // namespace sucre

@@ -173,7 +173,9 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *tobs, cons
 
 // kClosed: J is re-solved in closed form at the top of the iteration (sucre.py:141, 66-77 with absorption = l a,
 // backscatter = l B (1 - g)) and is a constant of the gradient; kJOnly: only that closed-form J (final update_J).
-template <bool kClosed, bool kJOnly>
+// kColour (SUCRE_EXT_COLOUR): the extension planes carry the observation's float32 colour instead of its camera
+// point; there is no light then (l = 1, z = the stored range) and the light sums stay zero.
+template <bool kClosed, bool kJOnly, bool kColour>
 __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restrict__ comp, const uint8_t *__restrict__ ext,
                                                          const uint64_t *__restrict__ tile_off,
                                                          const uint32_t *__restrict__ levels, int n_tiles,
@@ -226,12 +228,14 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 for (int j = 0; j < 4; ++j) {
                     if (!(k.zz[j] > 0.0f)) continue;
                     const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
-                    const LightObs o = light_obs(cP, k.zz[j], R, tl, M);
+                    LightObs o;
+                    if (kColour) { o.l = 1.0f; o.z = k.zz[j]; }
+                    else o = light_obs(cP, k.zz[j], R, tl, M);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float a = o.l * fast_exp2(o.z * nb[c]);
                         const float b = o.l * B[c] * (1.0f - fast_exp2(o.z * ng[c]));
-                        const float I = unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
+                        const float I = kColour ? cP[c] : unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
                         acc.pa[c][j] = __builtin_fmaf(I - b, a, acc.pa[c][j]);
                         acc.pb[c][j] = __builtin_fmaf(a, a, acc.pb[c][j]);
                     }
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             for (int j = 0; j < 4; ++j) {
                 if (!(k.zz[j] > 0.0f)) continue;  // padding slot
                 const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
-                const LightObs o = light_obs(cP, k.zz[j], R, tl, M);
+                LightObs o;
+                if (kColour) { o.l = 1.0f; o.z = k.zz[j]; }
+                else o = light_obs(cP, k.zz[j], R, tl, M);
                 const float l = o.l, z = o.z;
                 float dl = 0.f, dz = 0.f;
 #pragma unroll
@@ -288,7 +294,8 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
                     // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
                     const uint32_t kb = (k.cc[c] >> (8 * j)) & 255u;
-                    const float r = kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
+                    const float r = kColour ? cP[c] - l * E
+                                  : kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
                     const float rl = r * l;
                     const float rlz = rl * z;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     dl = __builtin_fmaf(r, E, dl);
                     dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g, -(bJ[c][j] * a)), dz);
                 }
+                if (kColour) continue;  // no light: nothing flows into cam2light / sigma
                 // chain rule into lP (common factor -2 s applied in the step kernel); M symmetric:
                 // d(lp^T M lp)/dlp = 2 M lp = 2 (w0, w1)
                 const float kk = dl * (-0.5f * l);
@@ -480,10 +488,10 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     return hipGetLastError();
 }
 
-template <bool kClosed, bool kJOnly>
-static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
-                              hipStream_t s) {
-    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+template <bool kClosed, bool kJOnly, bool kColour>
+static void launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
+                                hipStream_t s) {
+    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
                        lws + X.off_ext_comp, reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
                        reinterpret_cast<const uint32_t *>(ws + L.off_levels), L.n_tiles,
                        reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
@@ -492,12 +500,19 @@ static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws
                        reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(lws + X.off_partials), co);
 }
 
-hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, hipStream_t s) {
+template <bool kClosed, bool kJOnly>
+static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
+                              unsigned flags, hipStream_t s) {
+    if (flags & SUCRE_FIT_EXT_COLOUR) launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
+    else launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s);
+}
+
+hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
     hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(512), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
                        reinterpret_cast<float *>(lws + X.off_geom));
-    launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, s);
+    launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, flags, s);
     return hipGetLastError();
 }
 
@@ -510,8 +525,8 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
     float *partials = reinterpret_cast<float *>(lws + X.off_partials);
     double *sums = reinterpret_cast<double *>(lws + X.off_sums);
     auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, co, s);
-    else launch_light_grad<false, false>(L, X, ws, lws, co, s);
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, co, flags, s);
+    else launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
     hipLaunchKernelGGL(light_reduce_kernel, dim3(1), dim3(256), 0, s, partials, L.n_blocks, sums);
     hipLaunchKernelGGL(light_step_kernel, dim3(1), dim3(512), 0, s, sums, pstate, geom, nobs, co, trace_row);
     return hipGetLastError();

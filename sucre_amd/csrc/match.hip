@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                                                     const float *__restrict__ depth1, const CamDev c1,
                                                     const sucre_view_t *__restrict__ views, int n_views, int k0,
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
-                                                    size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext) {
+                                                    size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext,
+                                                    int ext_mode) {
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -122,8 +123,13 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                 m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
-                    const uint8_t *p = rgb2 + q * 3;
-                    r = p[0]; g = p[1]; b = p[2];
+                    if (ext_mode == SUCRE_EXT_COLOUR) {  // float32 colour image (resized inputs): the planes carry I
+                        const float *pf = reinterpret_cast<const float *>(rgb2) + q * 3;
+                        c2[0] = pf[0]; c2[1] = pf[1]; c2[2] = pf[2];
+                    } else {
+                        const uint8_t *p = rgb2 + q * 3;
+                        r = p[0]; g = p[1]; b = p[2];
+                    }
                 }
             }
             zo[j] = z;
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
             c[0] = r4; c[64] = g4; c[128] = b4;
-            if (ext) {  // light model only: the camera-frame point cP of every observation (loader.py:113), 3 planes
+            if (ext) {  // extension planes: the camera-frame point cP of every observation (light model,
+                        // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
                 uint8_t *e = ext + ((size_t)tile * n_views + k) * kExtChunk;
                 *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(cx[0], cx[1], cx[2], cx[3]);
                 *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(cy[0], cy[1], cy[2], cy[3]);
@@ -318,12 +325,12 @@ static CamDev to_cam(const sucre_view_t &v) {
 }
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s, uint8_t *ext) {
+                        int k0, int k1, hipStream_t s, uint8_t *ext, int ext_mode) {
     const int tiles_per_xcd = (L.n_tiles + 7) / 8;
     const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
     hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
                        reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
-                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext);
+                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, ext_mode);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ class DeviceView:
     """What the engine needs from one sfm.Image: pixels on the GPU + float32 camera/pose matrices computed on
     the host the way the reference computes them (sfm.py:42-47, 92)."""
     depth: torch.Tensor   # (H,W) float32, cuda
-    rgb: torch.Tensor     # (H,W,3) uint8, cuda
+    rgb: torch.Tensor     # (H,W,3) uint8, cuda (float32 for resized inputs, see Restoration(float_colour=True))
     K: torch.Tensor       # (3,3) float32, cpu
     R: torch.Tensor       # (3,3) float32, cpu   world-from-camera
     t: torch.Tensor       # (3,1) float32, cpu
@@ -40,7 +40,7 @@ class DeviceView:
     def _build_struct(self) -> _lib.SucreView:
         H, W = self.depth.shape
         assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
-        assert self.rgb.dtype == torch.uint8 and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
+        assert self.rgb.dtype in (torch.uint8, torch.float32) and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
         K = self.K.to(torch.float32).cpu()
         R = self.R.to(torch.float32).cpu()
         t = self.t.to(torch.float32).cpu().view(3, 1)
@@ -64,11 +64,16 @@ class Restoration:
     MatchesData of the reference, loader.py:56-130)."""
 
     def __init__(self, height: int, width: int, n_views: int, device: str | torch.device = 'cuda', light: bool = False,
-                 obs_format: str = 'f32'):
+                 obs_format: str = 'f32', float_colour: bool = False):
         """``obs_format``: 'f32' = 7 B/observation, lossless (default); 'u16mm' = 5 B/observation, ranges rounded to
-        the millimetre (BASELINE config 5; include/sucre_hip.h SUCRE_OBS_U16MM)."""
+        the millimetre (BASELINE config 5; include/sucre_hip.h SUCRE_OBS_U16MM).  ``float_colour``: the views' colour
+        images are float32 (resized inputs, --image-scale: loader.py:156-163 resizes in float64, so colours are no
+        longer k/255); the observations then carry float32 colours in the extension workspace (SUCRE_EXT_COLOUR)."""
         self.lib = _lib.load()
         self.light = bool(light)
+        self.float_colour = bool(float_colour)
+        if self.float_colour and (self.light or obs_format != 'f32'):
+            raise NotImplementedError('float32 colours share the extension planes with the light model and need the f32 store')
         if obs_format not in _lib.OBS_FORMATS:
             raise ValueError(f'obs_format must be one of {sorted(_lib.OBS_FORMATS)}, not {obs_format!r}')
         if self.light and obs_format != 'f32':
@@ -86,7 +91,7 @@ class Restoration:
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
         self.lws = None
-        if self.light:  # extension workspace of the artificial-light model (camera points + 19 parameters)
+        if self.light or self.float_colour:  # extension workspace: camera points / float colours + 19 parameters
             lbytes = self.lib.sucre_light_workspace_bytes(self.H, self.W, self.n_views)
             self.lws = torch.empty(lbytes, dtype=torch.uint8, device=self.device)
             assert self.lws.data_ptr() % 256 == 0
@@ -117,10 +122,12 @@ class Restoration:
         self._keepalive = [target, views]
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            if self.light:
+            want = torch.float32 if self.float_colour else torch.uint8
+            assert all(v.rgb.dtype == want for v in views), f'this restoration takes {want} colour images'
+            if self.light or self.float_colour:
                 lws = C.c_void_p(self.lws.data_ptr())
-                _lib.check(self.lib.sucre_match_views_light(ws, lws, H, W, n, C.byref(tgt),
-                                                            C.c_void_p(self._views_dev.data_ptr()), 0, n, _stream_ptr()))
+                fn = self.lib.sucre_match_views_fcolour if self.float_colour else self.lib.sucre_match_views_light
+                _lib.check(fn(ws, lws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()), 0, n, _stream_ptr()))
                 _lib.check(self.lib.sucre_finalize_matches_light(ws, lws, H, W, n, float(min_cover), _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
@@ -190,11 +197,16 @@ class Restoration:
 
     # -- fit (sucre.py:36-82, 124-157) --------------------------------------------------------------------------
     def fit_init(self, target: DeviceView, params0=None, J0: torch.Tensor | None = None) -> None:
-        npar = 19 if self.light else 9
-        default = np.concatenate([np.full(9, 0.1), np.zeros(6), [1.0, 0.0, 0.0, 1.0]])[:npar]  # sucre.py:41-46
-        p0 = default.astype(np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(npar)
+        npar = 19 if (self.light or self.float_colour) else 9
+        default = np.concatenate([np.full(9, 0.1), np.zeros(6), [1.0, 0.0, 0.0, 1.0]])  # sucre.py:41-46
+        p0 = default.copy() if params0 is None else np.asarray(params0, np.float64).reshape(-1)
+        if self.float_colour and p0.size == 9:
+            p0 = np.concatenate([p0, default[9:]])   # no light: identity pose, unit beam (never updated)
+        p0 = p0.astype(np.float32).reshape(-1)[:npar] if params0 is None else p0.astype(np.float32).reshape(npar)
         p0c = (C.c_float * npar)(*p0.tolist())
         j0 = None
+        if J0 is None and self.float_colour:
+            J0 = target.rgb   # SUCRe.__init__: J starts at the image (sucre.py:47); NaN where depth <= 0 by the kernel
         if J0 is not None:
             j0 = J0.to(self.device, torch.float32).contiguous()
             assert j0.shape == (self.H, self.W, 3)
@@ -202,9 +214,9 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             j0p = C.c_void_p(j0.data_ptr()) if j0 is not None else None
-            if self.light:
+            if self.light or self.float_colour:
                 _lib.check(self.lib.sucre_fit_init_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
-                                                         C.c_void_p(target.rgb.data_ptr()),
+                                                         None if self.float_colour else C.c_void_p(target.rgb.data_ptr()),
                                                          C.c_void_p(target.depth.data_ptr()), p0c, j0p, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_fit_init(ws, H, W, n, C.c_void_p(target.rgb.data_ptr()),
@@ -217,13 +229,14 @@ class Restoration:
         device trace (cost, B, beta, gamma per iteration) or None.  In closed-form mode the C ABI appends the
         final ``update_J`` of sucre.py:156 to every ``sucre_fit_run`` call; that is idempotent, so a fit split
         into several calls (``finalize`` is kept for readability) ends in the same state."""
-        width = 20 if self.light else 10
+        ext = self.light or self.float_colour
+        width = 20 if ext else 10
         trace = torch.zeros((num_iter, width), dtype=torch.float64, device=self.device) if record_trace else None
-        flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag
+        flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag | (_lib.FIT_EXT_COLOUR if self.float_colour else 0)
         ws, H, W, n = self._geom
         tp = C.c_void_p(trace.data_ptr()) if trace is not None else None
         with torch.cuda.device(self.device):
-            if self.light:
+            if ext:
                 _lib.check(self.lib.sucre_fit_run_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self.steps_done,
                                                         int(num_iter), float(lr), float(betas[0]), float(betas[1]),
                                                         float(eps), flags, tp, _stream_ptr()))
@@ -232,22 +245,25 @@ class Restoration:
                                                   float(betas[0]), float(betas[1]), float(eps), flags, tp,
                                                   _stream_ptr()))
         self.steps_done += int(num_iter)
+        if trace is not None and self.float_colour:
+            trace = trace[:, :10]   # the light columns are constants here
         self.trace = trace
         return trace
 
     def update_J(self) -> None:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            if self.light:
-                _lib.check(self.lib.sucre_update_J_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, _stream_ptr()))
+            if self.light or self.float_colour:
+                _lib.check(self.lib.sucre_update_J_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
+                                                       _lib.FIT_EXT_COLOUR if self.float_colour else 0, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_update_J_fmt(ws, H, W, n, self._fmt, _stream_ptr()))
 
     def params(self) -> torch.Tensor:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
-        if self.light:
+        if self.light or self.float_colour:
             off = self.lib.sucre_light_params_offset(self.H, self.W, self.n_views)
-            return self.lws[off:off + 76].view(torch.float32)
+            return self.lws[off:off + (36 if self.float_colour else 76)].view(torch.float32)
         return self._region(_lib.WS_PARAMS, torch.float32, 9)
 
     def J(self) -> torch.Tensor:
@@ -272,6 +288,8 @@ class HipWaterBackend:
 
     def __init__(self, restoration: Restoration, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  use_closed_form: bool = False, trace: torch.Tensor | None = None):
+        if restoration.light or restoration.float_colour:
+            raise NotImplementedError('shared water parameters run on the plain water model with uint8 colours')
         self.r = restoration
         self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))
         self.flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | restoration._fmt_flag

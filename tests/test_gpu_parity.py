@@ -475,3 +475,46 @@ def test_closed_form_does_not_depend_on_the_starting_J(golden):
         assert np.array_equal(np.isnan(J), np.isnan(outs[0][0]))
         assert helpers.rms_per_channel(J, outs[0][0]).max() < 2e-5
         assert np.abs(tr[:, 1:] - outs[0][1][:, 1:]).max() < 1e-4
+
+
+@pytest.mark.parametrize('closed', [False, True])
+def test_float32_colour_store_vs_oracle(golden, closed):
+    """Resized inputs (--image-scale) have float32 colours that are not k/255: Restoration(float_colour=True) carries
+    them in the extension planes (SUCRE_EXT_COLOUR).  Same scene with its colours perturbed off the 1/255 grid: match
+    sets unchanged, fit against the oracle fed the same float colours."""
+    from sucre_amd import engine
+    sc = golden.scene
+    g = torch.Generator().manual_seed(7)
+    views, frgb = [], []
+    for v in sc.views:
+        f = (v.rgb_u8.to(torch.float64) / 255).to(torch.float32)
+        f = (f + (torch.rand(f.shape, generator=g) - 0.5) * 0.003).clamp(0, 1).contiguous()
+        frgb.append(f)
+        views.append(engine.DeviceView(depth=v.depth_f32().cuda().contiguous(), rgb=f.cuda(), K=sc.K, R=v.R, t=v.t, name=v.name))
+    r = engine.Restoration(sc.height, sc.width, len(views), float_colour=True)
+    r.match(views[sc.target], views)
+    assert r.view_counts().cpu().numpy().tolist() == golden['n_matches'].tolist()
+    r.fit_init(views[sc.target])
+    T = 60
+    trace = r.fit(T, use_closed_form=closed).cpu().numpy()
+    J = r.J().cpu().numpy()
+    assert trace.shape == (T, 10) and r.params().shape == (9,)
+    # oracle: same matches, colours gathered from the float images
+    tgt = sc.views[sc.target]
+    cam1 = helpers.oracle_cam(sc, tgt)
+    samples = []
+    for v, f in sorted(zip(sc.views, frgb), key=lambda p: p[0].name):
+        m = oracle.match_view(tgt.depth_f32().numpy(), cam1, v.depth_f32().numpy(), helpers.oracle_cam(sc, v))
+        if len(m) / (sc.width * sc.height) > 1e-6:
+            cP = oracle.unproject(helpers.oracle_cam(sc, v), m.u2, m.v2, m.d)
+            I = f.numpy()[m.v2.astype(np.int64), m.u2.astype(np.int64)].T.copy()
+            samples.append((m.u1, m.v1, cP, I))
+    J0 = None
+    if not closed:
+        J0 = frgb[sc.target].numpy().copy()
+        J0[tgt.depth_f32().numpy() <= 0] = np.nan
+    Jo, po, to = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T, use_closed_form=closed)
+    assert np.array_equal(np.isnan(J), np.isnan(Jo))
+    assert helpers.rms_per_channel(J, Jo).max() < (5e-5 if closed else 1e-6)
+    assert np.abs(trace[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
+    assert np.abs(trace[:, 0] / to[:, 0] - 1).max() < 1e-4
