@@ -37,6 +37,18 @@ class DeviceView:
         self.__dict__['_struct'] = ((self.depth.data_ptr(), self.rgb.data_ptr()), s)
         return s
 
+    def as_float_colour(self) -> 'DeviceView':
+        """This view with float32 colours (float32(float64(k)/255), loader.py:157-163): used when other views of the
+        same restoration are resized images, whose colours are float32 already."""
+        if self.rgb.dtype == torch.float32:
+            return self
+        twin = self.__dict__.get('_float_twin')
+        if twin is None:
+            twin = DeviceView(depth=self.depth, rgb=(self.rgb.to(torch.float64) / 255).to(torch.float32).contiguous(),
+                              K=self.K, R=self.R, t=self.t, name=self.name)
+            self.__dict__['_float_twin'] = twin
+        return twin
+
     def _build_struct(self) -> _lib.SucreView:
         H, W = self.depth.shape
         assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
@@ -358,17 +370,18 @@ _SLOT = 0          # the in-flight slot the calling code is working for (see in_
 
 
 def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
-                        obs_format: str | None = None) -> Restoration:
+                        obs_format: str | None = None, float_colour: bool = False) -> Restoration:
     """Workspace pool: one Restoration per (geometry, device, in-flight slot), reused image after image (the
     1080p x 65-view workspace is ~2 GB; re-allocating it per image would serialise on the allocator)."""
     dev = torch.device(device)
     if dev.type == 'cuda' and dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
     if obs_format is None:   # engine knob for the reference-compatible CLI, which has no flag for it
-        obs_format = 'f32' if light else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
-    key = (int(height), int(width), int(n_views), str(dev), bool(light), _SLOT, obs_format)
+        obs_format = 'f32' if (light or float_colour) else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
+    key = (int(height), int(width), int(n_views), str(dev), bool(light), _SLOT, obs_format, bool(float_colour))
     if key not in _POOL:
-        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light, obs_format=obs_format)
+        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light, obs_format=obs_format,
+                                 float_colour=float_colour)
     return _POOL[key]
 
 

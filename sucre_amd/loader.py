@@ -54,23 +54,41 @@ def _imread_depth_u16(path: Path) -> np.ndarray:
             return np.asarray(im)
 
 
-def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor:
-    """(H,W,3) uint8 colour image: the engine's input format (source pixels are exactly k/255)."""
+def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor | None:
+    """(H,W,3) uint8 colour image: the engine's compact input format (source pixels are exactly k/255).  None when the
+    file is not camera-sized: resized colours (--image-scale) are not multiples of 1/255, use ``load_rgb``."""
     rgb = _imread_rgb_u8(Path(rgb_path))
     if rgb.shape[0] != height or rgb.shape[1] != width:
-        raise NotImplementedError(
-            f'{rgb_path}: image is {rgb.shape[1]}x{rgb.shape[0]} but the camera is {width}x{height}; resized '
-            f'(--image-scale != 1) colours are not multiples of 1/255 and need the float32 observation format, '
-            f'which this build does not have yet')
+        return None
     return torch.from_numpy(np.array(rgb, dtype=np.uint8, order="C"))
+
+
+def _resize_rgb(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
+    """The reference's resize of the float64 colour image (loader.py:158-162): OpenCV INTER_AREA when shrinking,
+    INTER_CUBIC otherwise.  Without OpenCV, shrinking by integer factors -- what --image-scale 0.5 / 0.25 do -- is
+    done here the way INTER_AREA does it in that case: the block's pixels summed in row-major order, times 1/area."""
+    try:
+        import cv2
+        return cv2.resize(rgb, (width, height), interpolation=cv2.INTER_AREA if width < rgb.shape[1] else cv2.INTER_CUBIC)
+    except ImportError:
+        pass
+    H0, W0 = rgb.shape[:2]
+    if width < W0 and W0 % width == 0 and H0 % height == 0:
+        fx, fy = W0 // width, H0 // height
+        acc = np.zeros((height, width, rgb.shape[2]), np.float64)
+        for dy in range(fy):
+            for dx in range(fx):
+                acc += rgb[dy::fy, dx::fx]
+        return acc * (1.0 / (fx * fy))
+    raise NotImplementedError(f'resizing {W0}x{H0} to {width}x{height} (not an integer shrink factor) needs OpenCV, '
+                              f'which is not installed: its INTER_AREA / INTER_CUBIC kernels are not restated here')
 
 
 def load_rgb(rgb_path: Path, width: int, height: int) -> Tensor:
     """(H,W,3) float32 colour in [0,1]: ``uint8 / 255`` evaluated in float64 then cast (loader.py:156-163)."""
     rgb = _imread_rgb_u8(Path(rgb_path)) / 255
     if rgb.shape[0] != height or rgb.shape[1] != width:
-        import cv2  # resizing needs OpenCV's INTER_AREA / INTER_CUBIC to match the reference
-        rgb = cv2.resize(rgb, (width, height), interpolation=cv2.INTER_AREA if width < rgb.shape[1] else cv2.INTER_CUBIC)
+        rgb = _resize_rgb(rgb, width, height)
     return torch.tensor(rgb, dtype=torch.float32)
 
 
@@ -301,7 +319,8 @@ class MatchesFile:
             W2 = im.camera.width
             u2, v2 = p2 % W2, torch.div(p2, W2, rounding_mode='floor')
             view = im.device_view(r.device)
-            I = (view.rgb[v2, u2].to(torch.float64) / 255).to(torch.float32).T
+            I = view.rgb[v2, u2]
+            I = (I if I.dtype == torch.float32 else (I.to(torch.float64) / 255).to(torch.float32)).T
             groups[im.name] = dict(u1=u1.short().cpu().numpy(), v1=v1.short().cpu().numpy(),
                                    u2=u2.short().cpu().numpy(), v2=v2.short().cpu().numpy(),
                                    d=view.depth[v2, u2].cpu().numpy(), I=I.cpu().numpy())
@@ -329,7 +348,11 @@ class MatchesFile:
             u2, v2 = torch.tensor(ds['u2']), torch.tensor(ds['v2'])
             cP = im.unproject_depth(u=u2, v=v2, d=torch.tensor(ds['d']))
             z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
-            rgb = torch.tensor(np.rint(ds['I'].astype(np.float64) * 255).astype(np.uint8).T.copy())
+            k255 = ds['I'].astype(np.float64) * 255
+            if np.abs(k255 - np.rint(k255)).max() > 1e-3:
+                raise NotImplementedError(f'{self.path}: the kept colours are not multiples of 1/255 (matches of '
+                                          f'resized images); re-match with --force-compute-matches')
+            rgb = torch.tensor(np.rint(k255).astype(np.uint8).T.copy())
             images.append(im)
             lists.append((torch.tensor(ds['u1']), torch.tensor(ds['v1']), z, rgb))
         resto = engine.acquire_restoration(target_image.camera.height, target_image.camera.width, len(lists), device)

@@ -164,6 +164,8 @@ class Image:
                 return cached[1]
             PIXEL_CACHE.forget(self)
             rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
+            if rgb is None:   # --image-scale: colours resized in float64 like the reference -> float32 observations
+                rgb = self.get_rgb()
             mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
             if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
                 depth = self.get_depth_map().to(dev).contiguous()
@@ -174,7 +176,7 @@ class Image:
             if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
                 torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
             self._device_view = (dev, view)
-            PIXEL_CACHE.insert(self, view.depth.numel() * 4 + view.rgb.numel(), dev)
+            PIXEL_CACHE.insert(self, view.depth.numel() * 4 + view.rgb.numel() * view.rgb.element_size(), dev)
             return view
 
     def release_device(self) -> None:
@@ -193,7 +195,15 @@ class Image:
         loader.prefetch_device_views(image_list + [self], device, num_workers=num_workers)
         views = [im.device_view(device) for im in image_list]
         target = self.device_view(device)
-        resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device, light=light_model)
+        float_colour = any(v.rgb.dtype == torch.float32 for v in views + [target])   # resized inputs (--image-scale)
+        if float_colour:
+            if light_model:
+                raise NotImplementedError('--light-model together with resized images (--image-scale != 1): the light '
+                                          'model and float32 colours share the same extension planes')
+            views = [v.as_float_colour() for v in views]
+            target = target.as_float_colour()
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device, light=light_model,
+                                           float_colour=float_colour)
         resto.match(target, views, min_cover=min_cover)
         matches_file.attach(resto, target_image=self, image_list=list(image_list))
 
@@ -203,8 +213,12 @@ class Image:
         recomputes the unprojections on the device."""
         from . import engine
         views = [other.device_view(device)]
-        resto = engine.acquire_restoration(self.camera.height, self.camera.width, 1, device)
-        resto.match(self.device_view(device), views, min_cover=-1.0)
+        target = self.device_view(device)
+        float_colour = views[0].rgb.dtype == torch.float32 or target.rgb.dtype == torch.float32
+        if float_colour:
+            views, target = [views[0].as_float_colour()], target.as_float_colour()
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, 1, device, float_colour=float_colour)
+        resto.match(target, views, min_cover=-1.0)
         q = resto.match_map(0)
         v1, u1 = torch.where(q >= 0)
         p2 = q[v1, u1].long()

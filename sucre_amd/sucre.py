@@ -51,7 +51,7 @@ class SUCRe(torch.nn.Module):
                 # the pixels are already resident for the engine: same values as get_rgb() / get_depth_map()
                 # (float32(float64(k)/255), loader.py:157-163) without decoding the files a second time
                 view = cached[1]
-                J = (view.rgb.to(torch.float64) / 255).to(torch.float32)
+                J = view.rgb.clone() if view.rgb.dtype == torch.float32 else (view.rgb.to(torch.float64) / 255).to(torch.float32)
                 J[view.depth <= 0] = torch.nan
             else:
                 J = image.get_rgb()
@@ -234,6 +234,8 @@ def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData):
         raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
                            'needs were not kept (call Image.match_images(..., light_model=True))')
     target = sucre.image.device_view(resto.device)
+    if resto.float_colour:
+        target = target.as_float_colour()
     J0 = None if sucre.use_closed_form else sucre.J.detach()
     resto.fit_init(target, params0=sucre.water_vector().detach().cpu().numpy(), J0=J0)
     return resto

@@ -326,3 +326,37 @@ def test_check_store_flags_every_kind_of_damage(golden):
         mf = loader.MatchesFile.__new__(loader.MatchesFile)
         mf.path, mf.restoration = 'planted', r
         mf.check_integrity()
+
+
+def test_cli_image_scale_half(disk_scene, tmp_path):
+    """--image-scale 0.5 (sfm.py:193-199, loader.py:156-170): intrinsics rescaled, colours area-averaged in float64
+    (no longer k/255 -> float32 observations), depth nearest-neighbour.  The oracle is fed the same resized inputs."""
+    from sucre_amd import sfm, sucre
+    root, scene, _, _ = disk_scene
+    name = scene.names[scene.target]
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(tmp_path), '--image-name', name, '--num-iter', '15', '--image-scale', '0.5'])
+    state = torch.load(tmp_path / (Path(name).stem + '.pt'))
+    assert state['J'].shape == (32, 48, 3)
+    for f in ('_rgb.png', '_reconstruction.png'):
+        assert (tmp_path / (Path(name).stem + f)).exists()
+    model = sfm.COLMAPModel(root / 'model', root / 'images', root / 'depth', image_scale=0.5)
+    tgt = model[name]
+    H, W = tgt.camera.height, tgt.camera.width
+    assert (H, W) == (32, 48)
+    cam = lambda im: oracle.make_cam(H, W, **helpers.cam_matrices(im.camera.K, im.pose.R.contiguous(), im.pose.t.contiguous()))
+    d1 = tgt.get_depth_map().numpy()
+    samples = []
+    for im in sorted(model.images.values(), key=lambda i: i.name):
+        m = oracle.match_view(d1, cam(tgt), im.get_depth_map().numpy(), cam(im))
+        if len(m) / (W * H) > 1e-6:
+            cP = oracle.unproject(cam(im), m.u2, m.v2, m.d)
+            samples.append((m.u1, m.v1, cP, im.get_rgb().numpy()[m.v2.astype(np.int64), m.u2.astype(np.int64)].T.copy()))
+    J0 = tgt.get_rgb().numpy().copy()
+    assert np.abs(J0 * 255 - np.rint(J0 * 255)).max() > 0.05          # really off the 1/255 grid
+    J0[d1 <= 0] = np.nan
+    Jo, po, to = oracle.fit(H, W, samples, J0, num_iter=15)
+    J = state['J'].numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-6
+    got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
+    assert np.abs(got - po).max() < 1e-5

@@ -143,8 +143,15 @@ def test_pixel_loaders_reproduce_reference_quantisation(tmp_path):
     assert np.array_equal(loader.load_rgb_u8(tmp_path / 'a.png', 8, 6).numpy(), rgb)
     d = loader.load_depth_map(tmp_path / 'depth_a.png', width=8, height=6)
     assert np.array_equal(d.numpy(), (depth.astype(np.float64) / 1000).astype(np.float32))
-    with pytest.raises(NotImplementedError, match='image-scale'):
-        loader.load_rgb_u8(tmp_path / 'a.png', 4, 3)
+    assert loader.load_rgb_u8(tmp_path / 'a.png', 4, 3) is None        # not camera-sized: the float32 path takes over
+    half = loader.load_rgb(tmp_path / 'a.png', width=4, height=3)      # --image-scale 0.5: INTER_AREA, factor 2
+    x = rgb.astype(np.float64) / 255
+    want = (((x[0::2, 0::2] + x[0::2, 1::2]) + x[1::2, 0::2]) + x[1::2, 1::2]) * 0.25
+    assert half.dtype == torch.float32 and np.array_equal(half.numpy(), want.astype(np.float32))
+    dh = loader.load_depth_map(tmp_path / 'depth_a.png', width=4, height=3)
+    assert np.array_equal(dh.numpy(), (depth[0::2, 0::2].astype(np.float64) / 1000).astype(np.float32))
+    with pytest.raises(NotImplementedError, match='OpenCV'):
+        loader.load_rgb(tmp_path / 'a.png', width=5, height=4)
 
 
 def test_list_backed_matches_data_keeps_reference_semantics():
