@@ -248,6 +248,22 @@ class Matches:
         keep = (back[:, 0] == self.v1) & (back[:, 1] == self.u1)
         return Matches(self.image1, self.image2, self.u1[keep], self.v1[keep], self.u2[keep], self.v2[keep])
 
+    def plot(self, step: int = 10000, color: tuple[float, float, float] = None):
+        """Debug picture (sfm.py:161-169): the two images side by side, every ``step``-th match joined by a line
+        (random colours unless ``color`` is given)."""
+        from PIL import Image as PILImage, ImageDraw
+        left, right = self.image1.get_rgb(), self.image2.get_rgb()
+        canvas = np.zeros((max(left.shape[0], right.shape[0]), left.shape[1] + right.shape[1], 3), np.uint8)
+        canvas[:left.shape[0], :left.shape[1]] = np.uint8(left.numpy() * 255)
+        canvas[:right.shape[0], left.shape[1]:] = np.uint8(right.numpy() * 255)
+        picture = PILImage.fromarray(canvas)
+        pen = ImageDraw.Draw(picture)
+        rng = np.random.default_rng()
+        ends = torch.stack([self.u1, self.v1, self.u2 + left.shape[1], self.v2], dim=1)[::step].cpu().tolist()
+        for x1, y1, x2, y2 in ends:
+            pen.line([(x1, y1), (x2, y2)], fill=tuple(int(c) for c in rng.integers(0, 256, 3)) if color is None else color, width=3)
+        return picture
+
     def __len__(self) -> int:
         return int(self.u1.shape[0])
 

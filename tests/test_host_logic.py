@@ -305,3 +305,17 @@ def test_pixel_cache_evicts_least_recently_used(monkeypatch):
     assert cache.total == 100
     cache.insert(a, 1000, dev)          # a single image larger than the budget still stays (it is in use)
     assert a._device_view is not None and c._device_view is None and cache.total == 1000
+
+
+def test_matches_plot_draws_side_by_side(tmp_path):
+    from PIL import Image as PILImage
+    rng = np.random.default_rng(2)
+    for n in ('a', 'b'):
+        PILImage.fromarray(rng.integers(0, 256, size=(6, 8, 3), dtype=np.uint8)).save(tmp_path / f'{n}.png')
+    cam = sfm.Camera(1, 8, 6, torch.eye(3))
+    pose = sfm.Pose(torch.eye(3), torch.zeros(3, 1))
+    a = sfm.Image(1, tmp_path / 'a.png', tmp_path / 'd.png', pose, cam)
+    b = sfm.Image(2, tmp_path / 'b.png', tmp_path / 'd.png', pose, cam)
+    m = sfm.Matches(a, b, u1=torch.tensor([0, 1, 2]), v1=torch.tensor([0, 0, 1]), u2=torch.tensor([3, 4, 5]), v2=torch.tensor([1, 1, 2]))
+    pic = m.plot(step=2, color=(255, 0, 0))
+    assert pic.size == (16, 6) and (np.asarray(pic) == np.array([255, 0, 0])).all(axis=2).any()
