@@ -231,3 +231,46 @@ def make_survey(width: int, height: int, grid_x: int, grid_y: int, seed: int = 0
                                     seed=seed, relief=relief, invalid_frac=invalid_frac, device=device)
         views.append(SynthView(name=f'img_{q:04d}.png', R=R32, t=t32, depth_u16=depth_mm, rgb_u8=rgb))
     return SynthSurvey(width=width, height=height, K=K, views=views, grid=offs, seed=seed)
+
+
+def write_to_disk(scene, root, compress_level: int = 1) -> None:
+    """Writes a synthetic scene or survey the way a user of the reference has real data (README of the reference):
+    ``root/images/*.png``, ``root/depth/depth_<stem>.png`` (16-bit millimetres) and an undistorted PINHOLE COLMAP text
+    model in ``root/model``."""
+    from pathlib import Path
+
+    from PIL import Image as PILImage
+
+    from . import sfm
+    root = Path(root)
+    (root / 'images').mkdir(parents=True, exist_ok=True)
+    (root / 'depth').mkdir(parents=True, exist_ok=True)
+    for v in scene.views:
+        PILImage.fromarray(v.rgb_u8.cpu().numpy()).save(root / 'images' / v.name, compress_level=compress_level)
+        PILImage.fromarray(v.depth_u16.cpu().numpy().astype(np.uint16)).save(
+            root / 'depth' / ('depth_' + Path(v.name).stem + '.png'), compress_level=compress_level)
+    sfm.write_colmap_text(root / 'model', scene.K, scene.width, scene.height, [v.name for v in scene.views],
+                          [sfm.Pose(v.R.cpu(), v.t.cpu()) for v in scene.views])
+
+
+def main(argv=None) -> None:
+    """``python -m sucre_amd.synth --out DIR [--width 1920 --height 1080 --grid 6 5 --seed 0]``: a synthetic underwater
+    survey on disk (known water parameters B=(.05,.25,.35), beta=(.6,.2,.15), gamma=(.7,.3,.2)) to try the command
+    line of ``sucre_amd.sucre`` on."""
+    import argparse
+    p = argparse.ArgumentParser(description=main.__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument('--out', required=True)
+    p.add_argument('--width', type=int, default=1920)
+    p.add_argument('--height', type=int, default=1080)
+    p.add_argument('--grid', type=int, nargs=2, default=(6, 5), metavar=('NX', 'NY'))
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
+    a = p.parse_args(argv)
+    survey = make_survey(a.width, a.height, a.grid[0], a.grid[1], seed=a.seed, device=a.device)
+    write_to_disk(survey, a.out)
+    print(f'wrote {len(survey.views)} views to {a.out}; try:\n  python -m sucre_amd.sucre --image-dir {a.out}/images '
+          f'--depth-dir {a.out}/depth --model-dir {a.out}/model --output-dir {a.out}/restored --image-ids 1 {len(survey.views) + 1}')
+
+
+if __name__ == '__main__':
+    main()

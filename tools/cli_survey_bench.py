@@ -24,13 +24,8 @@ def main():
     survey = synth.make_survey(W, H, gx, gy, seed=3, device='cuda')
     with tempfile.TemporaryDirectory() as tmp:
         root = Path(tmp)
-        (root / 'images').mkdir(); (root / 'depth').mkdir()
         t0 = time.perf_counter()
-        for v in survey.views:
-            PILImage.fromarray(v.rgb_u8.cpu().numpy()).save(root / 'images' / v.name, compress_level=1)
-            PILImage.fromarray(v.depth_u16.cpu().numpy().astype(np.uint16)).save(
-                root / 'depth' / ('depth_' + Path(v.name).stem + '.png'), compress_level=1)
-        sfm.write_colmap_text(root / 'model', survey.K, W, H, [v.name for v in survey.views], [sfm.Pose(v.R.cpu(), v.t.cpu()) for v in survey.views])
+        synth.write_to_disk(survey, root)
         print(f'wrote {len(survey.views)} views in {time.perf_counter() - t0:.1f}s', flush=True)
         first = 1 if n >= gx * gy else gx * (gy // 2) + 1
         argv = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
