@@ -34,8 +34,8 @@ STATE_BYTES_PER_PX = 72  # J, exp_avg, exp_avg_sq: 3 planes x 3 channels x 4 B, 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=5)
-    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=2)
     p.add_argument('--width', type=int, default=1920)
     p.add_argument('--height', type=int, default=1080)
     p.add_argument('--neighbours', type=int, default=64)
