@@ -7,7 +7,7 @@
 //   1. count the valid observations of every pixel over the kept views,
 //   2. sort the pixels by that count, descending, with a deterministic stable counting sort
 //      (block histograms -> per-bin scan over blocks -> in-block stable rank),
-//   3. stack (gather) each pixel's observations, in view order, into "levels": chunk (tile', level) of the compact store
+//   3. stack each pixel's observations, in view order, into "levels": chunk (tile', level) of the compact store
 //      holds the level-th observation of the 256 pixels of sorted tile tile'.
 // A sorted tile's pixels have (nearly) equal counts, so it has max-count levels and almost no empty slot; tiles
 // come out heaviest first, which is also the better dispatch order.  J and the Adam moments live in the sorted
@@ -182,101 +182,35 @@ __global__ __launch_bounds__(256) void tile_offset_kernel(const uint32_t *__rest
     for (int i = lo; i < hi; ++i) { tile_off[i] = run * (unsigned long long)chunk_bytes(fmt); run += levels[i]; }
 }
 
-// 3c. gather: one thread per slot of the sorted order walks its pixel's view bitmask (next set bit = next level)
-//     and pulls that observation out of the dense store; every compact chunk is written whole and coalesced
-//     (a scatter from the dense side puts neighbouring pixels at different levels -> partial-line writes, 4x slower).
-//     kBatch levels are resolved first, then loaded, then stored.
+// 3c. the compaction itself, driven from the DENSE side.  One workgroup owns one dense tile: it stages the tile's
+//     chunks through LDS a group of views at a time -- every chunk is read from HBM exactly once, fully coalesced --
+//     and each thread (pixel) then walks its view bitmask (next set bit = next level) and emits its observations to
+//     its slot of the sorted order.  Pixels of one dense tile that fall into the same count bin are neighbours in the
+//     sorted order (the sort is stable), so these writes form runs.  (History: the first version gathered from the
+//     sorted side, one thread per sorted slot reading 4 + 3 x 1 bytes per observation from a different (tile, view)
+//     chunk; every dense chunk was re-read by the ~7 sorted tiles holding some of its pixels -- 3.9 GB fetched for
+//     0.55 GB of observations (rocprofv3 FETCH_SIZE), HBM-bound at 1.13 ms against 0.72 ms now.)
 //     kFmt = SUCRE_OBS_U16MM: the range is stored as uint16 millimetres, rint(1000 z) clamped to [1, 65535]
 //     (0 stays the empty-slot marker), colours unchanged -> 1280-byte chunks.
-template <int kFmt>
-__global__ __launch_bounds__(256) void gather_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
-                                                     size_t view_stride, const uint32_t *__restrict__ perm,
-                                                     const uint64_t *__restrict__ pmask, int mask_words,
-                                                     const uint32_t *__restrict__ levels,
-                                                     const uint64_t *__restrict__ tile_off,
-                                                     uint8_t *__restrict__ comp, int n_views,
-                                                     const uint8_t *__restrict__ ext_dense,
-                                                     uint8_t *__restrict__ ext_comp) {
-    const int dtile = blockIdx.x, t = threadIdx.x;
-    const uint32_t nl = levels[dtile];
-    if (nl == 0) return;
-    const uint32_t src = perm[(size_t)dtile * kTilePx + t];
-    const uint32_t stile = src / kTilePx, ss = src % kTilePx;
-    const uint8_t *sbase = obs + (size_t)stile * tile_stride;
-    const uint64_t *mask = pmask + (size_t)src * mask_words;
-    uint8_t *out = comp + tile_off[dtile];
-    unsigned long long cur = mask[0];
-    int wi = 0;
-    for (uint32_t l0 = 0; l0 < nl; l0 += kBatch) {
-        int kk[kBatch];
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            while (cur == 0ull && wi + 1 < mask_words) cur = mask[++wi];
-            if (cur != 0ull) {
-                kk[b] = wi * 64 + __builtin_ctzll(cur);
-                cur &= cur - 1ull;
-            } else {
-                kk[b] = -1;
-            }
-        }
-        float z[kBatch];
-        uint8_t r[kBatch], g[kBatch], bl[kBatch];
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            const uint8_t *chunk = sbase + (size_t)(kk[b] >= 0 ? kk[b] : 0) * view_stride;
-            const bool ok = kk[b] >= 0;
-            z[b] = ok ? reinterpret_cast<const float *>(chunk)[ss] : 0.0f;
-            r[b] = ok ? chunk[kChunkZ + ss] : 0;
-            g[b] = ok ? chunk[kChunkZ + kTilePx + ss] : 0;
-            bl[b] = ok ? chunk[kChunkZ + 2 * kTilePx + ss] : 0;
-        }
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            if (l0 + b < nl) {  // workgroup-uniform
-                uint8_t *o = out + (size_t)(l0 + b) * chunk_bytes(kFmt);
-                constexpr int zb = kFmt ? kChunkZ16 : kChunkZ;
-                if (kFmt) {
-                    const float mm = fminf(fmaxf(rintf(z[b] * kMmPerM), 1.0f), 65535.0f);
-                    reinterpret_cast<uint16_t *>(o)[t] = z[b] > 0.0f ? (uint16_t)mm : (uint16_t)0;
-                } else {
-                    reinterpret_cast<float *>(o)[t] = z[b];
-                }
-                o[zb + t] = r[b];
-                o[zb + kTilePx + t] = g[b];
-                o[zb + 2 * kTilePx + t] = bl[b];
-                if (kFmt == 0 && ext_dense) {  // light model: carry the camera point along (same chunk numbering, kExtChunk stride)
-                    const float *se = reinterpret_cast<const float *>(
-                        ext_dense + ((size_t)stile * n_views + (kk[b] >= 0 ? kk[b] : 0)) * kExtChunk);
-                    float *de = reinterpret_cast<float *>(ext_comp + (tile_off[dtile] / kChunk + l0 + b) * kExtChunk);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + t] = kk[b] >= 0 ? se[pl * kTilePx + ss] : 0.0f;
-                }
-            }
-        }
-    }
-}
+//     kExt: the three float32 extension planes of every chunk (camera points of the light model / float32
+//     colours) ride along, 3072 more bytes per staged view.
+template <bool kExt>
+struct StageCfg {
+    static constexpr int kViews = kExt ? 16 : 32;                 // 16 x 4864 B = 76 KB / 32 x 1792 B = 56 KB of LDS
+    static constexpr int kBytes = kChunk + (kExt ? kExtChunk : 0);
+};
 
-// 3c'. the same compaction driven from the DENSE side (the default; the gather above remains for the light model,
-//      whose camera-point planes ride along).  The gather reads 4 + 3 x 1 bytes per observation from a different
-//      (tile, view) chunk for every thread, and a dense chunk is re-read by every sorted tile that holds some of its
-//      pixels (~7 count bins per tile): 3.9 GB fetched for 0.55 GB of observations (rocprofv3 FETCH_SIZE), which makes
-//      it HBM-bound at 1.13 ms.  Here one workgroup owns one dense tile: it stages the tile's chunks through LDS
-//      32 views at a time -- every chunk is read from HBM exactly once, fully coalesced -- and each thread (pixel)
-//      then emits its observations level by level to its slot of the sorted order.  Pixels of one dense tile that fall
-//      into the same count bin are neighbours in the sorted order (the sort is stable), so these writes form runs.
-#ifndef SUCRE_STAGE_VIEWS
-#define SUCRE_STAGE_VIEWS 32
-#endif
-constexpr int kStageViews = SUCRE_STAGE_VIEWS;  // 32 x 1792 B = 56 KB of LDS: two workgroups per CU
-
-template <int kFmt>
+template <int kFmt, bool kExt>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
                                                       const uint32_t *__restrict__ levels,
                                                       const uint64_t *__restrict__ tile_off,
-                                                      uint8_t *__restrict__ comp, int n_views) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kChunk];
+                                                      uint8_t *__restrict__ comp, int n_views,
+                                                      const uint8_t *__restrict__ ext_dense,
+                                                      uint8_t *__restrict__ ext_comp) {
+    constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kStageBytes];
     __shared__ uint32_t present;
     __shared__ uint8_t vl[kStageViews];
     const int tile = blockIdx.x, t = threadIdx.x;
@@ -284,10 +218,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     const uint32_t dtile = dst / kTilePx, dslot = dst % kTilePx;
     const uint32_t nl = levels[dtile];
     uint8_t *out = comp + tile_off[dtile];
+    float *eout = kExt ? reinterpret_cast<float *>(ext_comp + (tile_off[dtile] / kChunk) * kExtChunk) : nullptr;
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     const uint8_t *tbase = obs + (size_t)tile * tile_stride;
     constexpr int cb = kFmt ? kChunk16 : kChunk, zb = kFmt ? kChunkZ16 : kChunkZ;
-    constexpr int kUnits = kChunk / 16;  // 16-byte pieces of a chunk
+    constexpr int kUnits = kStageBytes / 16;  // 16-byte pieces of a staged view
+    constexpr int kMainUnits = kChunk / 16;
     uint32_t lv = 0;
     for (int g0 = 0; g0 < n_views; g0 += kStageViews) {
         const uint32_t bits = (uint32_t)(mask[g0 >> 6] >> (g0 & 63)) &
@@ -303,8 +239,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         const int total = __builtin_popcount(p) * kUnits;
         for (int u = t; u < total; u += 256) {
             const int i = vl[u / kUnits], w = u % kUnits;
-            *reinterpret_cast<uint4 *>(&stage[i][w * 16]) =
-                *reinterpret_cast<const uint4 *>(tbase + (size_t)(g0 + i) * view_stride + (size_t)w * 16);
+            const uint8_t *src = (!kExt || w < kMainUnits)
+                ? tbase + (size_t)(g0 + i) * view_stride + (size_t)w * 16
+                : ext_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits) * 16;
+            *reinterpret_cast<uint4 *>(&stage[i][w * 16]) = *reinterpret_cast<const uint4 *>(src);
         }
         __syncthreads();
         uint32_t m = bits;
@@ -322,6 +260,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
             o[zb + dslot] = stage[i][kChunkZ + t];
             o[zb + kTilePx + dslot] = stage[i][kChunkZ + kTilePx + t];
             o[zb + 2 * kTilePx + dslot] = stage[i][kChunkZ + 2 * kTilePx + t];
+            if (kExt) {
+                const float *se = reinterpret_cast<const float *>(&stage[i][kChunk]);
+                float *de = eout + (size_t)lv * (kExtChunk / 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + dslot] = se[pl * kTilePx + t];
+            }
             ++lv;
         }
         __syncthreads();  // everyone is done with the stage before the next group overwrites it
@@ -333,6 +277,11 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         o[zb + dslot] = 0;
         o[zb + kTilePx + dslot] = 0;
         o[zb + 2 * kTilePx + dslot] = 0;
+        if (kExt) {
+            float *de = eout + (size_t)lv * (kExtChunk / 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + dslot] = 0.0f;
+        }
     }
 }
 
@@ -360,17 +309,18 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
                        reinterpret_cast<uint32_t *>(ws + L.off_full));
     hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
-    if (ext_dense) {  // light model: float32 store only, camera points carried by the gather
-        hipLaunchKernelGGL(gather_kernel<0>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                           L.obs_view_stride, perm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views,
-                           ext_dense, ext_comp);
-    } else if (fmt) {
-        hipLaunchKernelGGL(scatter_kernel<1>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                           L.obs_view_stride, invperm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views);
-    } else {
-        hipLaunchKernelGGL(scatter_kernel<0>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, L.obs_tile_stride,
-                           L.obs_view_stride, invperm, pmask, L.mask_words, levels, tile_off, ws + L.off_comp, L.n_views);
-    }
+    const dim3 grid(L.n_tiles), block(256);
+    const uint8_t *obs = ws + L.off_obs;
+    uint8_t *comp = ws + L.off_comp;
+    if (ext_dense)  // light model / float32 colours: float32 store only
+        hipLaunchKernelGGL((scatter_kernel<0, true>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
+    else if (fmt)
+        hipLaunchKernelGGL((scatter_kernel<1, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
+    else
+        hipLaunchKernelGGL((scatter_kernel<0, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
     return hipGetLastError();
 }
 
