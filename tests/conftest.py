@@ -11,6 +11,11 @@ for p in (ROOT, ROOT / 'tests'):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the CPU oracle once
+    from sucre_amd import _lib
+    if not _lib.LIB_PATH.exists() or not list((ROOT / 'oracle').glob('*.so')):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope='session', params=['plane_64x48_n4', 'relief_96x64_n6'])
