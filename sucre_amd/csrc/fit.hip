@@ -511,7 +511,13 @@ __global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
     if (!fmt_ok) acc.cost = __builtin_nanf("");
 
+#ifdef SUCRE_EXP_SNAKE
+    for (int stripe = 0; stripe * n_blocks < n_tiles; ++stripe) {
+        const int tile = stripe * n_blocks + ((stripe & 1) ? n_blocks - 1 - (int)blockIdx.x : (int)blockIdx.x);
+        if (tile >= n_tiles) continue;
+#else
     for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
+#endif
         const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
         const uint8_t *tile_obs = comp + tile_off[tile];
         float *Jtile = Jt + (size_t)tile * 3 * kTilePx;

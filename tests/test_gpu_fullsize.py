@@ -1,0 +1,117 @@
+"""GPU parity at the sizes the bench runs at: the HIP engine against the CPU oracle on the SAME full-size inputs.
+
+The golden fixtures and the parameter sweep stop at ~1 M observations; BASELINE config 2 has 79 M and per-pixel
+gradients near Adam's eps, so the float32 per-thread carries of the fit kernel and the float64 reduction tree are
+exercised here where they matter.  Bars (task 1): per-channel RMS(J) <= 1e-5,
+B/beta/gamma <= 1e-5 absolute, cost <= 1e-5 relative -- ten times tighter than the north-star bar of 1e-4 against
+the reference, which the oracle itself meets to 1e-7 on the fixtures (tests/test_oracle_golden.py).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+RMS_BAR = 1e-5
+PARAM_BAR = 1e-5
+COST_BAR = 1e-5
+
+
+def _host_scene(scene, keep=None):
+    """CPU copy of a scene rendered on the GPU (optionally restricted to the views `keep`, target included)."""
+    sub = copy.copy(scene)
+    idx = list(range(len(scene.views))) if keep is None else sorted(keep)
+    sub.views = []
+    for i in idx:
+        v = copy.copy(scene.views[i])
+        v.depth_u16 = v.depth_u16.cpu()
+        v.rgb_u8 = v.rgb_u8.cpu()
+        sub.views.append(v)
+    sub.target = idx.index(scene.target)
+    return sub
+
+
+def _engine_fit(scene_dev, T, closed, obs_format='f32'):
+    from sucre_amd import engine
+    views = engine.device_views_from_scene(scene_dev, 'cuda')
+    r = engine.Restoration(scene_dev.height, scene_dev.width, len(views), obs_format=obs_format)
+    r.match(views[scene_dev.target], views)
+    r.fit_init(views[scene_dev.target])
+    trace = r.fit(T, use_closed_form=closed)
+    torch.cuda.synchronize()
+    out = r.J().cpu().numpy(), r.params().cpu().numpy().copy(), trace.cpu().numpy(), r.n_obs(), \
+        r.view_counts().cpu().numpy().tolist()
+    del r, views
+    torch.cuda.empty_cache()
+    return out
+
+
+def _oracle_fit(scene_host, T, closed, quantize=False):
+    per_view, samples = helpers.oracle_scene_samples(scene_host)
+    if quantize:
+        samples = oracle.quantize_ranges_u16mm(samples)
+    tgt = scene_host.views[scene_host.target]
+    J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    Jo, po, to = oracle.fit(scene_host.height, scene_host.width, samples, J0, num_iter=T, use_closed_form=closed)
+    return Jo, po, to, sum(len(s[0]) for s in samples), [len(m) for _, _, m in per_view]
+
+
+def _compare(eng, orc, rms_bar=RMS_BAR, param_bar=PARAM_BAR, cost_bar=COST_BAR, label=''):
+    J, p, t, n, counts = eng
+    Jo, po, to, no, countso = orc
+    assert counts == countso and n == no, f'{label}: match counts differ'
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)), f'{label}: NaN mask differs'
+    rms = helpers.rms_per_channel(J, Jo)
+    dpar = np.abs(t[:, 1:] - to[:, 1:]).max()
+    dcost = np.abs(t[:, 0] / to[:, 0] - 1).max()
+    print(f'{label}: n_obs={n} rms(J)={rms} max|dparams|={dpar:.3e} max rel dcost={dcost:.3e}')
+    assert rms.max() < rms_bar, (label, rms)
+    assert dpar < param_bar, (label, dpar)
+    assert dcost < cost_bar, (label, dcost)
+    assert np.array_equal(p, t[-1, 1:].astype(np.float32))
+    return rms, dpar, dcost
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('closed', [False, True], ids=['J-parameter', 'closed-form'])
+def test_config2_vs_oracle_10_iterations(closed):
+    """BASELINE config 2 (1920x1080, 64 neighbours + self, seed 0 = the bench's own image): 10 Adam iterations of
+    the engine against the oracle on identical inputs -- 79 M observations."""
+    from sucre_amd import synth
+    scene = synth.make_scene(1920, 1080, 64, seed=0, device='cuda')
+    eng = _engine_fit(scene, 10, closed)
+    orc = _oracle_fit(_host_scene(scene), 10, closed)
+    # closed-form mode re-solves J from scratch every iteration: its conditioning (not the size) sets the bar
+    _compare(eng, orc, rms_bar=5e-5 if closed else RMS_BAR, param_bar=2e-5 if closed else PARAM_BAR,
+             label=f'config2 closed={closed}')
+
+
+@pytest.mark.timeout(900)
+def test_200_iterations_mid_size_vs_oracle():
+    """A whole 200-iteration run at 800x600 x 9 views (3 M observations) against the oracle: trajectories must
+    not drift apart over a full fit."""
+    from sucre_amd import synth
+    scene = synth.make_scene(800, 600, 8, seed=5, device='cuda')
+    eng = _engine_fit(scene, 200, False)
+    orc = _oracle_fit(_host_scene(scene), 200, False)
+    _compare(eng, orc, label='800x600x9, 200 iterations')
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('closed', [False, True], ids=['J-parameter', 'closed-form'])
+def test_config5_shape_u16mm_vs_oracle(closed):
+    """BASELINE config 5 shape (3840x2160, compact 5 B/obs store) on the 24 views nearest to the target of the
+    257-view scene (the full 605 M-observation list does not fit the oracle's 28 B/obs host format in the time
+    budget): 3 iterations against the oracle fed `quantize_ranges_u16mm`."""
+    from sucre_amd import synth
+    W, H = 3840, 2160
+    scene = synth.make_scene(W, H, 24, seed=2, device='cuda', spacing=0.05)
+    eng = _engine_fit(scene, 3, closed, obs_format='u16mm')
+    orc = _oracle_fit(_host_scene(scene), 3, closed, quantize=True)
+    _compare(eng, orc, rms_bar=5e-5 if closed else RMS_BAR, param_bar=2e-5 if closed else PARAM_BAR,
+             label=f'config5-shape u16mm closed={closed}')
