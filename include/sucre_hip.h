@@ -47,6 +47,9 @@ extern "C" {
 /* fit flags */
 #define SUCRE_FIT_CLOSED_FORM 1u /* --use-closed-form: J is a closed-form buffer, sucre.py:66-77,141 */
 #define SUCRE_FIT_OBS_U16MM 2u   /* the store was finalised with SUCRE_OBS_U16MM (must match, see below) */
+#define SUCRE_FIT_KEEP_J 8u      /* with SUCRE_FIT_CLOSED_FORM: do not append the final update_J (sucre.py:156), i.e. leave
+                                    J = J(theta_k) of the last iteration k next to theta_{k+1} -- the pair the reference
+                                    plots at a --save-interval stop (sucre.py:141,153-154) */
 
 /*
  * Observation formats of the store the fit streams.  SUCRE_OBS_F32: float32 range + 3 uint8
@@ -156,7 +159,9 @@ int sucre_fit_init(void *ws, int H, int W, int n_views, const uint8_t *rgb1_dev,
  * sucre.adam (sucre.py:124-157): iterations t0+1 .. t0+T of torch.optim.Adam(lr, betas, eps) on {B,beta,gamma,J}
  * (or {B,beta,gamma} with SUCRE_FIT_CLOSED_FORM), all enqueued without a host sync.  trace_dev (nullable) gets
  * T x 10 float64: the cost sum r^2 the reference logs (sucre.py:146,150) and the nine parameters after the step.
- * With SUCRE_FIT_CLOSED_FORM the final update_J of sucre.py:156 is included.
+ * With SUCRE_FIT_CLOSED_FORM the final update_J of sucre.py:156 is included (unless SUCRE_FIT_KEEP_J), and a run that
+ * starts at t0 = 0 first solves J once from the initial parameters, so that the one-pass kernel measures its
+ * residuals from a J that is already close (accuracy only: iteration 0 re-solves J from the observations anyway).
  */
 int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr, double beta1, double beta2,
                   double eps, unsigned flags, double *trace_dev, void *stream);

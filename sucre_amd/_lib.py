@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent 
 FIT_CLOSED_FORM = 1
 FIT_OBS_U16MM = 2
 FIT_EXT_COLOUR = 4
+FIT_KEEP_J = 8
 OBS_F32, OBS_U16MM = 0, 1
 OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)

@@ -158,6 +158,9 @@ int sucre_fit_grad(void *ws, int H, int W, int n_views, int step, double lr, dou
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
     if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && step == 1)  // see sucre_fit_run: start the one-pass kernel from a solved J
+        if (int rc = check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), (flags & SUCRE_FIT_OBS_U16MM) ? SUCRE_OBS_U16MM : SUCRE_OBS_F32,
+                                               static_cast<hipStream_t>(stream)), "sucre_fit_grad/update_J")) return rc;
     return check_hip(launch_fit_grad(L, static_cast<uint8_t *>(ws), adam_coef(step, lr, beta1, beta2, eps), flags,
                                      static_cast<hipStream_t>(stream)), "sucre_fit_grad");
 }
@@ -178,18 +181,23 @@ int sucre_fit_run(void *ws, int H, int W, int n_views, int t0, int T, double lr,
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
-    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM | SUCRE_FIT_KEEP_J)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
     auto *w = static_cast<uint8_t *>(ws);
     auto s = static_cast<hipStream_t>(stream);
+    const int fmt = (flags & SUCRE_FIT_OBS_U16MM) ? SUCRE_OBS_U16MM : SUCRE_OBS_F32;
+    // The one-pass closed-form kernel forms its sums relative to the previous J (fit.hip, AccOne): at t0 = 0 that is
+    // the initial image, far from the solved J, and the differences S - dJ S' cancel digits in iteration 0 (seen as
+    // 2.6e-5 relative on the logged cost at 4K x 25 views).  One plain update_J first makes dJ small from the start.
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && t0 == 0 && T > 0)
+        if (int rc = check_hip(launch_update_J(L, w, fmt, s), "sucre_fit_run/initial update_J")) return rc;
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
         if (int rc = check_hip(launch_fit_iter_fused(L, w, co, flags, trace_dev ? trace_dev + (size_t)it * 10 : nullptr, s),
                                "sucre_fit_run")) return rc;
     }
-    if (flags & SUCRE_FIT_CLOSED_FORM)
-        return check_hip(launch_update_J(L, w, (flags & SUCRE_FIT_OBS_U16MM) ? SUCRE_OBS_U16MM : SUCRE_OBS_F32, s),
-                         "sucre_fit_run/update_J");
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && !(flags & SUCRE_FIT_KEEP_J))
+        return check_hip(launch_update_J(L, w, fmt, s), "sucre_fit_run/update_J");
     return SUCRE_OK;
 }
 
@@ -330,14 +338,14 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
-    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_KEEP_J)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
         if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co, flags,
                                                  trace_dev ? trace_dev + (size_t)it * 20 : nullptr,
                                                  static_cast<hipStream_t>(stream)), "sucre_fit_run_light")) return rc;
     }
-    if (flags & SUCRE_FIT_CLOSED_FORM)  // the final update_J of sucre.py:156
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && !(flags & SUCRE_FIT_KEEP_J))  // the final update_J of sucre.py:156
         return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
                                                flags & SUCRE_FIT_EXT_COLOUR, static_cast<hipStream_t>(stream)),
                          "sucre_fit_run_light/update_J");

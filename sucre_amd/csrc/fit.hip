@@ -170,7 +170,7 @@ struct __attribute__((aligned(16))) FitLds {
     } u;
     double stot[kSumsPad];
     float wsum[4][kNumSums];
-    int is_last;
+    int is_last, is_last_total;  // one flag word per arrive_last level: no wave can see the second verdict as the first
 };
 
 struct __attribute__((aligned(16))) FitLdsOne {
@@ -180,7 +180,7 @@ struct __attribute__((aligned(16))) FitLdsOne {
     } u;
     double stot[kSumsPad];
     float wsum[4][kNumSums];
-    int is_last;
+    int is_last, is_last_total;  // one flag word per arrive_last level: no wave can see the second verdict as the first
 };
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
@@ -473,7 +473,7 @@ __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums],
         const unsigned gsize = (unsigned)(min((g + 1) * kGroup, n_blocks) - g * kGroup);
         if (arrive_last(ticket + (size_t)(1 + g) * kTicketStride, gsize, &lds.is_last)) {  // workgroup-uniform
             reduce_group(partials, n_blocks, g, gpart, n_groups);
-            if (arrive_last(ticket, (unsigned)n_groups, &lds.is_last)) {
+            if (arrive_last(ticket, (unsigned)n_groups, &lds.is_last_total)) {
                 reduce_total(gpart, n_groups, lds.stot, sums);
                 // every other workgroup has finished (it arrived after its last use of the parameters)
                 if (t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);

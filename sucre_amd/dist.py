@@ -23,7 +23,10 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = os.environ.get('SUCRE_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
+            # RCCL needs one GPU per rank; several ranks sharing a GPU (a 1-GPU test box) talk over gloo instead.
+            # device_count() does not initialise the GPU.
+            enough = torch.cuda.device_count() >= int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            backend = os.environ.get('SUCRE_DIST_BACKEND', 'nccl' if (torch.cuda.is_available() and enough) else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

@@ -236,15 +236,18 @@ class Restoration:
         self.steps_done = 0
 
     def fit(self, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
-            eps: float = 1e-8, record_trace: bool = True, finalize: bool = True) -> torch.Tensor | None:
+            eps: float = 1e-8, record_trace: bool = True, keep_J: bool = False) -> torch.Tensor | None:
         """Enqueues ``num_iter`` Adam iterations without any host sync; returns the (num_iter,10) float64
         device trace (cost, B, beta, gamma per iteration) or None.  In closed-form mode the C ABI appends the
-        final ``update_J`` of sucre.py:156 to every ``sucre_fit_run`` call; that is idempotent, so a fit split
-        into several calls (``finalize`` is kept for readability) ends in the same state."""
+        final ``update_J`` of sucre.py:156 to a ``sucre_fit_run`` call (idempotent, so a fit split into several
+        calls ends in the same state) unless ``keep_J``: then J stays the J(theta_k) the last iteration k solved,
+        next to theta_{k+1} -- what the reference holds when it plots at a --save-interval stop (sucre.py:141,153)."""
         ext = self.light or self.float_colour
         width = 20 if ext else 10
         trace = torch.zeros((num_iter, width), dtype=torch.float64, device=self.device) if record_trace else None
         flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag | (_lib.FIT_EXT_COLOUR if self.float_colour else 0)
+        if keep_J and use_closed_form:
+            flags |= _lib.FIT_KEEP_J
         ws, H, W, n = self._geom
         tp = C.c_void_p(trace.data_ptr()) if trace is not None else None
         with torch.cuda.device(self.device):

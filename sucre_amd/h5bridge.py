@@ -3,7 +3,8 @@
     /<image name>/u1, v1, u2, v2   int16[n]        d  float32[n]        I  float32[3, n]
 
 h5py is used in-process when importable; otherwise the small converter ``_h5_helper.py`` is run under an
-interpreter that has it (``SUCRE_H5PY_PYTHON``, default ``/opt/conda/bin/python3.9``) with an ``.npz`` hand-over.
+interpreter that has it, named by the environment variable ``SUCRE_H5PY_PYTHON`` (no default: nothing outside the
+environment is probed), with an ``.npz`` hand-over.  Without either, ``loader.MatchesFile`` keeps matches as ``.npz``.
 """
 from __future__ import annotations
 
@@ -19,8 +20,8 @@ DATASETS = ('u1', 'v1', 'u2', 'v2', 'd', 'I')
 
 
 def _external_python() -> str | None:
-    cand = os.environ.get('SUCRE_H5PY_PYTHON', '/opt/conda/bin/python3.9')
-    return cand if Path(cand).exists() else None
+    cand = os.environ.get('SUCRE_H5PY_PYTHON')
+    return cand if cand and Path(cand).exists() else None
 
 
 def available() -> bool:
@@ -33,6 +34,12 @@ def available() -> bool:
 
 def _flatten(groups: dict) -> dict:
     return {f'{g}/{k}': np.asarray(v) for g, ds in groups.items() for k, v in ds.items()}
+
+
+def read_npz_groups(path: Path) -> dict:
+    """The ``.npz`` fallback written by ``loader.MatchesFile.save`` when no h5py is around -> same dict as ``read_groups``."""
+    with np.load(Path(path)) as data:
+        return _unflatten({k: data[k] for k in data.files})
 
 
 def _unflatten(flat) -> dict:

@@ -133,7 +133,10 @@ def prefetch_device_views(images, device, num_workers: int = 0, background: bool
     global _PREFETCH_POOL
     from .sfm import _canonical_device
     dev = _canonical_device(device)
-    todo = [im for im in {id(i): i for i in images}.values() if im._device_view is None or im._device_view[0] != dev]
+    def missing(im) -> bool:
+        cached = im._device_view   # read once: the pixel cache may drop the entry (set it to None) concurrently
+        return cached is None or cached[0] != dev
+    todo = [im for im in {id(i): i for i in images}.values() if missing(im)]
     if not todo:
         return
     n = decode_threads(num_workers)
@@ -244,8 +247,9 @@ class MatchesFile:
 
     ``path`` is kept for interface parity; the matches themselves live in the engine's workspace, attached by
     ``sfm.Image.match_images``.  With ``persist=True`` (``--keep-matches``) ``save`` writes the reference's
-    dataset names (``<image name>/{u1,v1,u2,v2,d,I}``) to ``path`` -- as HDF5 when h5py is importable, else as a
-    ``.npz`` next to it -- so a later run can tell that matching was already done.
+    dataset names (``<image name>/{u1,v1,u2,v2,d,I}``) to ``path`` -- as HDF5 when h5py is reachable
+    (``h5bridge.available``), else as a ``.npz`` next to it; ``on_disk`` / ``load_file`` accept either, so a later run
+    consumes the kept matches instead of re-matching (sucre.py:185).
     """
 
     def __init__(self, path: Path, colmap_model=None, overwrite: bool = False):
@@ -331,14 +335,17 @@ class MatchesFile:
 
     def on_disk(self) -> bool:
         """True when a matches file written earlier (by this engine or by the reference) can be loaded."""
-        return self.path.exists() and h5bridge.available()
+        return (self.path.exists() and h5bridge.available()) or self._npz_path.exists()
 
     def load_file(self, target_image, device='cuda') -> None:
         """Consumes an existing HDF5 matches file instead of matching (what the reference does when the file is
         already there, sucre.py:185): every group becomes one view of the engine's store.  cP / z are rebuilt like
         loader.py:113 + sucre.py:53 (float32, same operation order as the match kernel)."""
         from . import engine
-        groups = h5bridge.read_groups(self.path)
+        if self.path.exists() and h5bridge.available():
+            groups = h5bridge.read_groups(self.path)
+        else:
+            groups = h5bridge.read_npz_groups(self._npz_path)
         images, lists = [], []
         for name, ds in groups.items():
             im = self.colmap_model[name]
@@ -349,7 +356,7 @@ class MatchesFile:
             cP = im.unproject_depth(u=u2, v=v2, d=torch.tensor(ds['d']))
             z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
             k255 = ds['I'].astype(np.float64) * 255
-            if np.abs(k255 - np.rint(k255)).max() > 1e-3:
+            if k255.size and np.abs(k255 - np.rint(k255)).max() > 1e-3:
                 raise NotImplementedError(f'{self.path}: the kept colours are not multiples of 1/255 (matches of '
                                           f'resized images); re-match with --force-compute-matches')
             rgb = torch.tensor(np.rint(k255).astype(np.uint8).T.copy())

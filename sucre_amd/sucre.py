@@ -214,16 +214,19 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
         stops = [num_iter]
     done = 0
     for stop in stops:
+        snapshot = save_dir is not None and save_interval is not None and (stop - 1) % save_interval == 0
         if stop > done:
-            trace = resto.fit(stop - done, lr=lr, use_closed_form=sucre.use_closed_form, finalize=(stop == num_iter))
+            # at a snapshot stop closed-form J stays J(theta_k) of the last iteration k: the pair
+            # (J(theta_k), theta_{k+1}) is what the reference plots (sucre.py:141,153-154)
+            trace = resto.fit(stop - done, lr=lr, use_closed_form=sucre.use_closed_form, keep_J=snapshot)
             if verbose:
                 _log_trace(trace.cpu().numpy(), done)
             done = stop
-        if save_dir is not None and save_interval is not None and (done - 1) % save_interval == 0:
-            if sucre.use_closed_form and done != num_iter:
-                resto.update_J()
+        if snapshot:
             _pull_results(sucre, resto)
             sucre.save_plots(save_dir=save_dir, iteration=done - 1)
+            if sucre.use_closed_form and done == num_iter:
+                resto.update_J()   # the final update_J of sucre.py:156, held back for the snapshot
     _pull_results(sucre, resto)
     return sucre
 

@@ -1,0 +1,65 @@
+"""N > 1 on the GPU box: two real processes share the one GPU (gloo carries the all-reduce, the kernels are the HIP
+ones), so the multi-process path -- HipWaterBackend under dist.fit_shared_water, and bench.py's own rank launcher --
+is exercised before the driver runs it on eight GPUs over RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_shared_water_hip_backend(golden, tmp_path):
+    """Both ranks' traces are bitwise equal (identical step everywhere) and match the golden produced by two
+    reference SUCRe modules with tied B, beta, gamma (tests/golden/ref_harness.py::reference_shared_water)."""
+    T = int(golden['shared_trace'].shape[0])
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', LOCAL_WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SUCRE_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / 'tests' / 'dist_worker.py'), str(tmp_path), golden.name, str(T)],
+                                      env=env))
+    assert [p.wait(timeout=500) for p in procs] == [0, 0]
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    assert str(r0['backend']) == 'gloo' and int(r0['world']) == 2
+    assert np.array_equal(r0['trace'], r1['trace'])
+    assert np.array_equal(r0['params'], r1['params'])
+    rt = golden['shared_trace']
+    assert np.abs(r0['trace'][:, 1:] - rt[:, 1:]).max() < 1e-5
+    assert np.abs(r0['trace'][:, 0] / rt[:, 0] - 1).max() < 1e-4
+    for r, key in ((r0, 'shared_J0'), (r1, 'shared_J1')):
+        assert np.array_equal(np.isnan(r['J']), np.isnan(golden[key]))
+        assert helpers.rms_per_channel(r['J'], golden[key]).max() < 1e-4
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('extra', [[], ['--shared-water']], ids=['per-image', 'shared-water'])
+def test_bench_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks itself and rank 0 prints one JSON
+    line that saw both of them."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--width', '320',
+           '--height', '240', '--neighbours', '8', '--num-iter', '6', '--no-cpu-baseline', '--solo-images', '1'] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['ranks_seen'] == 2 and len(rec['config']['devices']) == 2
+    assert rec['value'] > 0 and rec['scaling'] == 'weak'
