@@ -7,12 +7,12 @@
 //   1. count the valid observations of every pixel over the kept views,
 //   2. sort the pixels by that count, descending, with a deterministic stable counting sort
 //      (block histograms -> per-bin scan over blocks -> in-block stable rank),
-//   3. stack each pixel's observations, in view order, into "levels": chunk (tile', level) of the compact store
-//      holds the level-th observation of the 256 pixels of sorted tile tile'.
-// A sorted tile's pixels have (nearly) equal counts, so it has max-count levels and almost no empty slot; tiles
-// come out heaviest first, which is also the better dispatch order.  J and the Adam moments live in the sorted
-// pixel order; fit_init / export_J translate through perm / invperm.  Everything is fixed-order: results stay
-// bitwise reproducible.
+//   3. stack each pixel's observations, in view order, into "levels", and cut the sorted pixels into strips of 64:
+//      a strip is stored as chunks of 64 pixels x 4 levels (layout.h, StripMeta), one pixel per lane of the wave
+//      that fits the strip.
+// A strip's pixels have (nearly) equal counts, so it has max-count levels and almost no empty slot; strips come out
+// heaviest first.  J and the Adam moments live in the sorted pixel order; fit_init / export_J translate through
+// perm / invperm.  Everything is fixed-order: results stay bitwise reproducible.
 #include "launch.h"
 
 namespace sucre {
@@ -143,55 +143,59 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint16_t *__restrict
     invperm[src] = dst;
 }
 
-// 3a. levels of every sorted tile = the largest pixel count in it; the levels below the smallest count are
-//     completely full (every slot a real observation), which lets the fit skip the validity select there.
-__global__ __launch_bounds__(256) void tile_levels_kernel(const uint16_t *__restrict__ pcount,
-                                                          const uint32_t *__restrict__ perm,
-                                                          uint32_t *__restrict__ levels, uint32_t *__restrict__ full) {
-    __shared__ uint32_t mx[256], mn[256];
+// 3a. levels of every strip (64 consecutive sorted pixels) = the largest pixel count in it; the chunks wholly below
+//     the smallest count hold real observations only, which lets the fit skip the validity select there.
+//     One workgroup per sorted tile = four strips, one per wave.
+__global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__restrict__ pcount,
+                                                           const uint32_t *__restrict__ perm,
+                                                           StripMeta *__restrict__ meta) {
     const int t = threadIdx.x;
-    mx[t] = mn[t] = pcount[perm[(size_t)blockIdx.x * kTilePx + t]];
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (t < w) { mx[t] = max(mx[t], mx[t + w]); mn[t] = min(mn[t], mn[t + w]); }
-        __syncthreads();
+    uint32_t mx = pcount[perm[(size_t)blockIdx.x * kTilePx + t]], mn = mx;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
     }
-    if (t == 0) { levels[blockIdx.x] = mx[0]; full[blockIdx.x] = mn[0]; }
+    if ((t & 63) == 0) {
+        StripMeta *m = meta + (size_t)blockIdx.x * kStripsPerTile + (t >> 6);
+        m->levels = mx;
+        m->full = mn;
+    }
 }
 
-// 3b. byte offset of every sorted tile's first chunk (exclusive scan of levels; one workgroup).
-__global__ __launch_bounds__(256) void tile_offset_kernel(const uint32_t *__restrict__ levels, int n_tiles,
-                                                          uint64_t *__restrict__ tile_off,
-                                                          uint64_t *__restrict__ total_chunks, int fmt) {
+// 3b. where every strip's chunks start, in levels (exclusive scan of the strips' level counts; one workgroup).
+__global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict__ meta, int n_strips,
+                                                           uint64_t *__restrict__ total_levels, int fmt) {
     __shared__ unsigned long long part[256];
     const int t = threadIdx.x;
-    const int per = (n_tiles + 255) / 256;
-    const int lo = t * per, hi = min(lo + per, n_tiles);
+    const int per = (n_strips + 255) / 256;
+    const int lo = t * per, hi = min(lo + per, n_strips);
     unsigned long long s = 0;
-    for (int i = lo; i < hi; ++i) s += levels[i];
+    for (int i = lo; i < hi; ++i) s += meta[i].levels;
     part[t] = s;
     __syncthreads();
     if (t == 0) {
         unsigned long long run = 0;
         for (int i = 0; i < 256; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-        *total_chunks = run;
-        *reinterpret_cast<uint32_t *>(total_chunks + 1) = (uint32_t)fmt;  // what the fit kernels must be told
+        *total_levels = run;
+        *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
     }
     __syncthreads();
     unsigned long long run = part[t];
-    for (int i = lo; i < hi; ++i) { tile_off[i] = run * (unsigned long long)chunk_bytes(fmt); run += levels[i]; }
+    for (int i = lo; i < hi; ++i) { meta[i].lvoff = run; run += meta[i].levels; }
 }
 
 // 3c. the compaction itself, driven from the DENSE side.  One workgroup owns one dense tile: it stages the tile's
 //     chunks through LDS a group of views at a time -- every chunk is read from HBM exactly once, fully coalesced --
-//     and each thread (pixel) then walks its view bitmask (next set bit = next level) and emits its observations to
-//     its slot of the sorted order.  Pixels of one dense tile that fall into the same count bin are neighbours in the
-//     sorted order (the sort is stable), so these writes form runs.  (History: the first version gathered from the
-//     sorted side, one thread per sorted slot reading 4 + 3 x 1 bytes per observation from a different (tile, view)
-//     chunk; every dense chunk was re-read by the ~7 sorted tiles holding some of its pixels -- 3.9 GB fetched for
-//     0.55 GB of observations (rocprofv3 FETCH_SIZE), HBM-bound at 1.13 ms against 0.72 ms now.)
+//     and each thread (pixel) then walks its view bitmask (next set bit = next level), collects four levels at a
+//     time and writes them to its pixel's place in its strip: one 16-byte store of ranges and three dwords of
+//     colours per full chunk (StripMeta / layout.h).  Pixels of one dense tile that fall into the same count bin are
+//     neighbours in the sorted order (the sort is stable), so these writes form runs.  (History: the first version
+//     gathered from the sorted side, one thread per sorted slot reading 4 + 3 x 1 bytes per observation from a
+//     different (tile, view) chunk; every dense chunk was re-read by the ~7 sorted tiles holding some of its pixels
+//     -- 3.9 GB fetched for 0.55 GB of observations (rocprofv3 FETCH_SIZE), HBM-bound at 1.13 ms.)
 //     kFmt = SUCRE_OBS_U16MM: the range is stored as uint16 millimetres, rint(1000 z) clamped to [1, 65535]
-//     (0 stays the empty-slot marker), colours unchanged -> 1280-byte chunks.
+//     (0 stays the empty-slot marker), colours unchanged.
 //     kExt: the three float32 extension planes of every chunk (camera points of the light model / float32
 //     colours) ride along, 3072 more bytes per staged view.
 template <bool kExt>
@@ -200,12 +204,73 @@ struct StageCfg {
     static constexpr int kBytes = kChunk + (kExt ? kExtChunk : 0);
 };
 
+// Four consecutive levels of one pixel on their way to the strip store.
+template <bool kExt>
+struct LevelGroup {
+    float z[kGroupLv];
+    uint32_t c[3];              // four bytes per colour plane, level j in byte j
+    float e[kExt ? 3 : 1][kGroupLv];
+};
+
+template <int kFmt>
+__device__ __forceinline__ uint32_t range_mm(float z) {
+    const float mm = fminf(fmaxf(rintf(z * kMmPerM), 1.0f), 65535.0f);
+    return z > 0.0f ? (uint32_t)mm : 0u;
+}
+
+// Writes chunk g (r of its four levels exist in the strip) of pixel `lane`.
+template <int kFmt, bool kExt>
+__device__ __forceinline__ void store_group(uint8_t *strip, float *estrip, uint32_t g, uint32_t r, uint32_t lane,
+                                            const LevelGroup<kExt> &q) {
+    uint8_t *ch = strip + (size_t)g * (kGroupLv * level_bytes(kFmt));
+    constexpr uint32_t zb = kFmt ? 2 : 4;   // bytes per range
+    if (r == kGroupLv) {
+        if (kFmt) {
+            *reinterpret_cast<uint2 *>(ch + lane * 8) =
+                make_uint2(range_mm<kFmt>(q.z[0]) | (range_mm<kFmt>(q.z[1]) << 16), range_mm<kFmt>(q.z[2]) | (range_mm<kFmt>(q.z[3]) << 16));
+        } else {
+            *reinterpret_cast<float4 *>(ch + lane * 16) = make_float4(q.z[0], q.z[1], q.z[2], q.z[3]);
+        }
+        uint32_t *cp = reinterpret_cast<uint32_t *>(ch + zb * kStripPx * kGroupLv) + lane;
+        cp[0] = q.c[0]; cp[kStripPx] = q.c[1]; cp[2 * kStripPx] = q.c[2];
+        if (kExt) {
+            float *e = estrip + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<float4 *>(e + pl * (kStripPx * kGroupLv) + lane * 4) = make_float4(q.e[pl][0], q.e[pl][1], q.e[pl][2], q.e[pl][3]);
+        }
+    } else {   // the strip's last chunk: r < 4 levels, same arrangement with rows of r
+        for (uint32_t j = 0; j < r; ++j) {
+            if (kFmt) reinterpret_cast<uint16_t *>(ch)[lane * r + j] = (uint16_t)range_mm<kFmt>(q.z[j]);
+            else reinterpret_cast<float *>(ch)[lane * r + j] = q.z[j];
+            uint8_t *cb = ch + zb * kStripPx * r;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) cb[pl * kStripPx * r + lane * r + j] = (uint8_t)(q.c[pl] >> (8 * j));
+            if (kExt) {
+                float *e = estrip + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) e[pl * kStripPx * r + lane * r + j] = q.e[pl][j];
+            }
+        }
+    }
+}
+
+template <bool kExt>
+__device__ __forceinline__ void clear_group(LevelGroup<kExt> &q) {
+#pragma unroll
+    for (int j = 0; j < kGroupLv; ++j) {
+        q.z[j] = 0.0f;
+#pragma unroll
+        for (int pl = 0; pl < (kExt ? 3 : 1); ++pl) q.e[pl][j] = 0.0f;
+    }
+    q.c[0] = q.c[1] = q.c[2] = 0u;
+}
+
 template <int kFmt, bool kExt>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
-                                                      const uint32_t *__restrict__ levels,
-                                                      const uint64_t *__restrict__ tile_off,
+                                                      const StripMeta *__restrict__ meta,
                                                       uint8_t *__restrict__ comp, int n_views,
                                                       const uint8_t *__restrict__ ext_dense,
                                                       uint8_t *__restrict__ ext_comp) {
@@ -215,16 +280,18 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     __shared__ uint8_t vl[kStageViews];
     const int tile = blockIdx.x, t = threadIdx.x;
     const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
-    const uint32_t dtile = dst / kTilePx, dslot = dst % kTilePx;
-    const uint32_t nl = levels[dtile];
-    uint8_t *out = comp + tile_off[dtile];
-    float *eout = kExt ? reinterpret_cast<float *>(ext_comp + (tile_off[dtile] / kChunk) * kExtChunk) : nullptr;
+    const uint32_t dlane = dst % kStripPx;
+    const StripMeta sm = meta[dst / kStripPx];
+    const uint32_t nl = sm.levels;
+    uint8_t *out = comp + sm.lvoff * (uint64_t)level_bytes(kFmt);
+    float *eout = kExt ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr;
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     const uint8_t *tbase = obs + (size_t)tile * tile_stride;
-    constexpr int cb = kFmt ? kChunk16 : kChunk, zb = kFmt ? kChunkZ16 : kChunkZ;
     constexpr int kUnits = kStageBytes / 16;  // 16-byte pieces of a staged view
     constexpr int kMainUnits = kChunk / 16;
     uint32_t lv = 0;
+    LevelGroup<kExt> q;
+    clear_group(q);
     for (int g0 = 0; g0 < n_views; g0 += kStageViews) {
         const uint32_t bits = (uint32_t)(mask[g0 >> 6] >> (g0 & 63)) &
                               (kStageViews == 32 ? 0xffffffffu : ((1u << (kStageViews & 31)) - 1u));  // views g0 .. g0+kStageViews-1
@@ -249,39 +316,35 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         while (m) {
             const int i = __builtin_ctz(m);
             m &= m - 1u;
+            const uint32_t j = lv & 3u;
+            // select-style updates (no dynamic register indexing)
             const float z = reinterpret_cast<const float *>(&stage[i][0])[t];
-            uint8_t *o = out + (size_t)lv * cb;
-            if (kFmt) {
-                const float mm = fminf(fmaxf(rintf(z * kMmPerM), 1.0f), 65535.0f);
-                reinterpret_cast<uint16_t *>(o)[dslot] = z > 0.0f ? (uint16_t)mm : (uint16_t)0;
-            } else {
-                reinterpret_cast<float *>(o)[dslot] = z;
-            }
-            o[zb + dslot] = stage[i][kChunkZ + t];
-            o[zb + kTilePx + dslot] = stage[i][kChunkZ + kTilePx + t];
-            o[zb + 2 * kTilePx + dslot] = stage[i][kChunkZ + 2 * kTilePx + t];
-            if (kExt) {
-                const float *se = reinterpret_cast<const float *>(&stage[i][kChunk]);
-                float *de = eout + (size_t)lv * (kExtChunk / 4);
+            const uint32_t cr = stage[i][kChunkZ + t], cg = stage[i][kChunkZ + kTilePx + t], cb = stage[i][kChunkZ + 2 * kTilePx + t];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + dslot] = se[pl * kTilePx + t];
-            }
+            for (int jj = 0; jj < kGroupLv; ++jj)
+                if (j == (uint32_t)jj) {
+                    q.z[jj] = z;
+                    if (kExt) {
+                        const float *se = reinterpret_cast<const float *>(&stage[i][kChunk]);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) q.e[pl][jj] = se[pl * kTilePx + t];
+                    }
+                }
+            q.c[0] |= cr << (8 * j); q.c[1] |= cg << (8 * j); q.c[2] |= cb << (8 * j);
             ++lv;
+            if ((lv & 3u) == 0u) {   // four levels collected: this pixel's share of chunk lv/4 - 1 (a full one)
+                store_group<kFmt, kExt>(out, eout, (lv >> 2) - 1u, kGroupLv, dlane, q);
+                clear_group(q);
+            }
         }
         __syncthreads();  // everyone is done with the stage before the next group overwrites it
     }
-    for (; lv < nl; ++lv) {  // padding slots of this pixel: the sorted tile has more levels than it has observations
-        uint8_t *o = out + (size_t)lv * cb;
-        if (kFmt) reinterpret_cast<uint16_t *>(o)[dslot] = 0;
-        else reinterpret_cast<float *>(o)[dslot] = 0.0f;
-        o[zb + dslot] = 0;
-        o[zb + kTilePx + dslot] = 0;
-        o[zb + 2 * kTilePx + dslot] = 0;
-        if (kExt) {
-            float *de = eout + (size_t)lv * (kExtChunk / 4);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) de[pl * kTilePx + dslot] = 0.0f;
-        }
+    // the open group (zero-filled past the pixel's last observation), then the all-zero groups up to the strip's
+    // level count: the strip has as many levels as its richest pixel
+    for (uint32_t g = lv >> 2; g * kGroupLv < nl; ++g) {
+        const uint32_t r = min((uint32_t)kGroupLv, nl - g * kGroupLv);
+        store_group<kFmt, kExt>(out, eout, g, r, dlane, q);
+        clear_group(q);
     }
 }
 
@@ -296,8 +359,7 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     auto *bin_base = totals + kMaxBins;
     auto *perm = reinterpret_cast<uint32_t *>(ws + L.off_perm);
     auto *invperm = reinterpret_cast<uint32_t *>(ws + L.off_invperm);
-    auto *levels = reinterpret_cast<uint32_t *>(ws + L.off_levels);
-    auto *tile_off = reinterpret_cast<uint64_t *>(ws + L.off_tile_off);
+    auto *meta = reinterpret_cast<StripMeta *>(ws + L.off_strip_meta);
     const int bins = num_bins(L.n_views);
     hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, keep, L.n_views,
                        L.n_tiles, L.obs_tile_stride, L.obs_view_stride, pcount, pmask, L.mask_words, blockhist);
@@ -305,23 +367,23 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, s, totals, bins, bin_base);
     hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, bin_base, L.n_views,
                        L.n_tiles, perm, invperm);
-    hipLaunchKernelGGL(tile_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, levels,
-                       reinterpret_cast<uint32_t *>(ws + L.off_full));
-    hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(256), 0, s, levels, L.n_tiles, tile_off,
+    hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta);
+    hipLaunchKernelGGL(strip_offset_kernel, dim3(1), dim3(256), 0, s, meta, L.n_strips,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
     const dim3 grid(L.n_tiles), block(256);
     const uint8_t *obs = ws + L.off_obs;
     uint8_t *comp = ws + L.off_comp;
     if (ext_dense)  // light model / float32 colours: float32 store only
         hipLaunchKernelGGL((scatter_kernel<0, true>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
     else if (fmt)
         hipLaunchKernelGGL((scatter_kernel<1, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
     else
         hipLaunchKernelGGL((scatter_kernel<0, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, levels, tile_off, comp, L.n_views, ext_dense, ext_comp);
-    return hipGetLastError();
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return launch_plan(L, ws, fmt, s);   // the fit waves' item streams over the store just written (fit.hip)
 }
 
 }  // namespace sucre

@@ -5,13 +5,18 @@
 // the ten global sums and -- in the workgroup that arrives last -- applies Adam to B, beta, gamma and logs the row.
 // The split form (launch_fit_grad + launch_fit_step) leaves the sums in the workspace for a host all-reduce.
 //
-// Work decomposition: 1536 persistent 256-thread workgroups, each looping over 16x16-pixel tiles of the sorted
-// compact store (csrc/compact.hip).  Phase 1 is level-parallel: the tile's levels are dealt round-robin to the four
-// waves, each lane owning 4 pixels x 3 channels; a chunk is copied HBM -> LDS by two LDS-DMA instructions into a
-// per-wave ring, so the per-pixel sums need no atomics and prefetch depth costs no registers.  Phase 2 adds the four
-// waves' per-pixel sums through LDS in a fixed order; phase 3 is pixel-parallel (one pixel per thread):
-// torch.optim.Adam on J.  The ten global sums go wave shuffle -> LDS -> one float32 partial per workgroup ->
-// float64 fixed-order two-level reduction, so results are bitwise reproducible.
+// Work decomposition: 1536 persistent 256-thread workgroups; every WAVE works alone on strips of 64 count-sorted
+// pixels (csrc/compact.hip, layout.h), one pixel per lane, and never synchronises with the other waves until the
+// launch's final reduction.  A strip is a sequence of ITEMS -- its J plane (768 B), its observation chunks (64 pixels
+// x 4 levels, 1792 B; the last one may hold fewer levels) and, in J-parameter mode, its Adam moments (1536 B) --
+// and the strips of a wave follow each other without a gap, so a wave sees ONE stream of items.  Every item is
+// copied HBM -> LDS by two LDS-DMA instructions into a private ring of kRing slots, kAhead items ahead of the one
+// being consumed, across strip boundaries: prefetch depth costs LDS, not registers, no latency is exposed between
+// strips, and the only ordinary memory instructions of the loop are the stores of J (and the moments) at a strip's
+// end.  Per-pixel sums live in the lane that owns the pixel: no atomics, no cross-wave reduction, and Adam on J
+// (torch.optim.Adam restated op for op, fit_math.h) runs in the same lane.  The ten global sums go
+// lane -> wave shuffle -> LDS -> one float32 partial per workgroup -> float64 fixed-order two-level reduction, so
+// results are bitwise reproducible.
 //
 // Model (sucre.py:79-82, l = 1):  Ihat = J a + B (1 - g),  a = exp(-beta z),  g = exp(-gamma z),  r = I - Ihat.
 // With L = sum r^2 / (3 n_obs) and s = (1/3)/n_obs (sucre.py:145):
@@ -36,65 +41,91 @@ __device__ __forceinline__ Water load_water(const float *__restrict__ params) {
     return w;
 }
 
-// What one pass over a view accumulates.
-enum Pass { kPassGradJ = 0, kPassClosedJ = 1 };
-
-// The kernel is VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 89 % of the launch): 15 instructions per
-// observation-channel in the select-free loop, 4 cycles each, 8 for v_exp_f32.  Packed v_pk_*_f32 issues at half
-// rate on gfx950 (tools/probes/valu_probe.hip), so writing the loop two-wide saved instructions but no time (and
-// cost 20 VGPRs); it stays scalar.
-struct Acc {
-    float pa[3][4];  // per pixel-channel: sum r a           | closed-form numerator   sum (I - b) a
-    float pb[3][4];  // per pixel-channel: sum r a z         | closed-form denominator sum a^2
-    float sB[3];     // sum r (1 - g)
-    float sGZ[3];    // sum r g z
-    float cost;      // sum r^2
-};
-
 constexpr float kInv255 = (float)(1.0 / 255.0);
 
-// kMasked = false: every slot of the chunk is a real observation (levels below the tile's smallest pixel count in
-// the compact store), so the z > 0 test and the selects are compiled out.
-template <int kPass, bool kMasked>
-__device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
-                                                const float (&J)[3][4], Acc &acc) {
-    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-    const uint32_t cc[3] = {c3.x, c3.y, c3.z};
-#ifdef SUCRE_EXP_NOCOMPUTE  // experiment build only (tools/microbench.py): touch the data, skip the model
-    acc.cost += (z4.x + z4.y) + (z4.z + z4.w) + (float)(c3.x ^ c3.y ^ c3.z);
+// ---------------------------------------------------------------------------------------------------------------
+// Arithmetic of one chunk: four levels of this lane's pixel.
+//
+// The loop is VALU-bound next to the stream (tools/probes/loop_probe.hip): 13 plain instructions (~1.1 ns per
+// wave-instruction per SIMD) and 2 v_exp_f32 (~4.5 ns each, not overlapped with anything) per observation-channel.
+// The 24 exponentials of a chunk are issued back to back, their arguments before them and their uses after them:
+// interleaved with their dependent arithmetic they cost 6.7 ns each (measured: 337 -> 296 ns per chunk per SIMD).
+// ---------------------------------------------------------------------------------------------------------------
+struct Acc {
+    float pa[3];   // this pixel: sum r a
+    float pb[3];   // this pixel: sum r a z
+    float sB[3];   // lane's share of sum r (1 - g)
+    float sGZ[3];  // lane's share of sum r g z
+    float cost;    // lane's share of sum r^2
+};
+
+struct Exps { float a[kGroupLv][3], g[kGroupLv][3]; };
+
+__device__ __forceinline__ void chunk_exps(const float (&zz)[kGroupLv], const Water &w, Exps &e) {
+#pragma unroll
+    for (int j = 0; j < kGroupLv; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { e.a[j][c] = zz[j] * w.nb[c]; e.g[j][c] = zz[j] * w.ng[c]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < kGroupLv; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { e.a[j][c] = fast_exp2(e.a[j][c]); e.g[j][c] = fast_exp2(e.g[j][c]); }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// kMasked = false: every level of the chunk is a real observation of every pixel of the strip (chunks wholly below
+// the strip's smallest pixel count), so the z > 0 test and the selects are compiled out.
+template <bool kMasked>
+__device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], const uint32_t (&cc)[3], const Water &w,
+                                                 const float (&J)[3], Acc &acc) {
+#ifdef SUCRE_EXP_NOCOMPUTE  // experiment build only: touch the data, skip the model
+    acc.cost += (zz[0] + zz[1]) + (zz[2] + zz[3]) + (float)(cc[0] ^ cc[1] ^ cc[2]);
     return;
 #endif
+    Exps e;
+    chunk_exps(zz, w, e);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kGroupLv; ++j) {
         const float z = zz[j];
         const bool valid = !kMasked || z > 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const uint32_t k = (cc[c] >> (8 * j)) & 255u;
-            const float a = fast_exp2(z * w.nb[c]);
-            const float g = fast_exp2(z * w.ng[c]);
+            const float a = e.a[j][c], g = e.g[j][c];
             const float omg = 1.0f - g;
-            const float bt = w.B[c] * omg;
-            if (kPass == kPassClosedJ) {
-                // sucre.py:73-76: numerator += (I - backscatter) * absorption ; denominator += absorption^2
-                const float I = unit_from_u8(k);
-                const float y = valid ? (I - bt) : 0.0f;
-                const float a2 = valid ? a * a : 0.0f;
-                acc.pa[c][j] = __builtin_fmaf(y, a, acc.pa[c][j]);
-                acc.pb[c][j] += a2;
-            } else {
-                const float Ihat = __builtin_fmaf(J[c][j], a, bt);
-                // I = k/255 folded into the residual: one rounding instead of two, two VALU ops fewer
-                float r = __builtin_fmaf((float)k, kInv255, -Ihat);
-                r = valid ? r : 0.0f;  // select, not multiply: J may be NaN where unobserved
-                const float rz = r * z;
-                acc.cost = __builtin_fmaf(r, r, acc.cost);
-                acc.pa[c][j] = __builtin_fmaf(r, a, acc.pa[c][j]);
-                acc.pb[c][j] = __builtin_fmaf(rz, a, acc.pb[c][j]);
-                acc.sB[c] = __builtin_fmaf(r, omg, acc.sB[c]);
-                acc.sGZ[c] = __builtin_fmaf(rz, g, acc.sGZ[c]);
-            }
+            const float Ihat = __builtin_fmaf(J[c], a, w.B[c] * omg);
+            // I = k/255 folded into the residual: one rounding instead of two, two VALU ops fewer
+            float r = __builtin_fmaf((float)k, kInv255, -Ihat);
+            r = valid ? r : 0.0f;  // select, not multiply: J may be NaN where unobserved
+            const float rz = r * z;
+            acc.cost = __builtin_fmaf(r, r, acc.cost);
+            acc.pa[c] = __builtin_fmaf(r, a, acc.pa[c]);
+            acc.pb[c] = __builtin_fmaf(rz, a, acc.pb[c]);
+            acc.sB[c] = __builtin_fmaf(r, omg, acc.sB[c]);
+            acc.sGZ[c] = __builtin_fmaf(rz, g, acc.sGZ[c]);
         }
+    }
+}
+
+// One level (a strip's last, short chunk): same arithmetic, always masked.
+__device__ __forceinline__ void accumulate_level(float z, const uint32_t (&k)[3], const Water &w, const float (&J)[3],
+                                                 Acc &acc) {
+    const bool valid = z > 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = fast_exp2(z * w.nb[c]);
+        const float g = fast_exp2(z * w.ng[c]);
+        const float omg = 1.0f - g;
+        const float Ihat = __builtin_fmaf(J[c], a, w.B[c] * omg);
+        float r = __builtin_fmaf((float)k[c], kInv255, -Ihat);
+        r = valid ? r : 0.0f;
+        const float rz = r * z;
+        acc.cost = __builtin_fmaf(r, r, acc.cost);
+        acc.pa[c] = __builtin_fmaf(r, a, acc.pa[c]);
+        acc.pb[c] = __builtin_fmaf(rz, a, acc.pb[c]);
+        acc.sB[c] = __builtin_fmaf(r, omg, acc.sB[c]);
+        acc.sGZ[c] = __builtin_fmaf(rz, g, acc.sGZ[c]);
     }
 }
 
@@ -113,71 +144,75 @@ __device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3,
 __device__ __forceinline__ float finite_or_zero(float x) { return __builtin_isfinite(x) ? x : 0.0f; }
 
 struct AccOne {
-    float q[9][3][4];  // N, D, S1..S7 per pixel-channel
+    float q[9][3];  // N, D, S1..S7 of this pixel, per channel
 };
 
-template <int kPass, bool kMasked>
-__device__ __forceinline__ void accumulate_view(const float4 z4, const uint3 c3, const Water &w,
-                                                const float (&Jp)[3][4], AccOne &acc) {
-    const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-    const uint32_t cc[3] = {c3.x, c3.y, c3.z};
+__device__ __forceinline__ void closed_terms(float z, float a, float g, uint32_t k, bool valid, float Bc, float Jp,
+                                             float &q0, float &q1, float &q2, float &q3, float &q4, float &q5,
+                                             float &q6, float &q7, float &q8) {
+    const float omg = 1.0f - g;
+    const float y = unit_from_u8(k) - Bc * omg;
+    float p = __builtin_fmaf(-Jp, a, y);
+    p = valid ? p : 0.0f;  // a padding slot contributes nothing (its Jp a is not zero)
+    const float za = z * a, zg = z * g;  // a padding slot has z = 0, g = 1: it only touches D (masked below)
+    q0 = __builtin_fmaf(p, a, q0);
+    q1 += valid ? a * a : 0.0f;
+    q2 = __builtin_fmaf(p, omg, q2);
+    q3 = __builtin_fmaf(a, omg, q3);
+    q4 = __builtin_fmaf(p, za, q4);
+    q5 = __builtin_fmaf(a, za, q5);
+    q6 = __builtin_fmaf(p, zg, q6);
+    q7 = __builtin_fmaf(a, zg, q7);
+    q8 = __builtin_fmaf(p, p, q8);
+}
+
+template <bool kMasked>
+__device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], const uint32_t (&cc)[3], const Water &w,
+                                                 const float (&Jp)[3], AccOne &acc) {
+    Exps e;
+    chunk_exps(zz, w, e);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kGroupLv; ++j) {
         const float z = zz[j];
         const bool valid = !kMasked || z > 0.0f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const uint32_t k = (cc[c] >> (8 * j)) & 255u;
-            const float a = fast_exp2(z * w.nb[c]);
-            const float g = fast_exp2(z * w.ng[c]);
-            const float omg = 1.0f - g;
-            const float y = unit_from_u8(k) - w.B[c] * omg;
-            float p = __builtin_fmaf(-Jp[c][j], a, y);
-            p = valid ? p : 0.0f;  // a padding slot contributes nothing (its Jp a is not zero)
-            const float za = z * a, zg = z * g;  // a padding slot has z = 0, g = 1: it only touches D (masked below)
-            acc.q[0][c][j] = __builtin_fmaf(p, a, acc.q[0][c][j]);
-            if (kMasked) acc.q[1][c][j] += valid ? a * a : 0.0f;
-            else acc.q[1][c][j] = __builtin_fmaf(a, a, acc.q[1][c][j]);
-            acc.q[2][c][j] = __builtin_fmaf(p, omg, acc.q[2][c][j]);
-            acc.q[3][c][j] = __builtin_fmaf(a, omg, acc.q[3][c][j]);
-            acc.q[4][c][j] = __builtin_fmaf(p, za, acc.q[4][c][j]);
-            acc.q[5][c][j] = __builtin_fmaf(a, za, acc.q[5][c][j]);
-            acc.q[6][c][j] = __builtin_fmaf(p, zg, acc.q[6][c][j]);
-            acc.q[7][c][j] = __builtin_fmaf(a, zg, acc.q[7][c][j]);
-            acc.q[8][c][j] = __builtin_fmaf(p, p, acc.q[8][c][j]);
-        }
+        for (int c = 0; c < 3; ++c)
+            closed_terms(z, e.a[j][c], e.g[j][c], (cc[c] >> (8 * j)) & 255u, valid, w.B[c], Jp[c], acc.q[0][c], acc.q[1][c],
+                         acc.q[2][c], acc.q[3][c], acc.q[4][c], acc.q[5][c], acc.q[6][c], acc.q[7][c], acc.q[8][c]);
     }
 }
 
+__device__ __forceinline__ void accumulate_level(float z, const uint32_t (&k)[3], const Water &w, const float (&Jp)[3],
+                                                 AccOne &acc) {
+    const bool valid = z > 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        closed_terms(z, fast_exp2(z * w.nb[c]), fast_exp2(z * w.ng[c]), k[c], valid, w.B[c], Jp[c], acc.q[0][c], acc.q[1][c],
+                     acc.q[2][c], acc.q[3][c], acc.q[4][c], acc.q[5][c], acc.q[6][c], acc.q[7][c], acc.q[8][c]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// Observation streaming: per-wave LDS-DMA ring.
+// Item stream: per-wave LDS-DMA ring.
 //
-// Each wave consumes levels wave, wave+4, ... of its (sorted) tile in the compact store (csrc/compact.hip).  A chunk is copied HBM -> LDS by
-// two LDS-DMA instructions (global_load_lds_dwordx4: 64 lanes = 1 KiB of ranges, 48 lanes = 768 B of colours)
-// into one of kRing private slots; kAhead = kRing-1 chunks stay in flight behind the one being consumed.
-// The DMAs have no VGPR destination, so prefetch depth costs LDS, not registers, and hipcc can neither sink them
-// next to their use nor drain them early: they live in inline asm and are waited for by hand-counted
-// s_waitcnt vmcnt(2 * chunks still allowed in flight) (vmcnt retires in issue order; cdna_hip_programming.md 5.7).
+// An item is copied by two LDS-DMA instructions (global_load_lds_dwordx4: lane i moves 16 bytes from src + 16 i to
+// slot + 16 i -- a dwordx3 one also strides by 16 and leaves holes, tools/probes/lds_dma_probe.hip) of nA and nB
+// active lanes, the second one continuing where the first ends, so the LDS image is a byte-exact copy of
+// 16 (nA + nB) bytes.  The DMAs have no VGPR destination: hipcc can neither sink them next to their use nor drain
+// them early; they live in inline asm and are waited for by hand-counted s_waitcnt vmcnt (vmcnt retires in issue
+// order; cdna_hip_programming.md 5.7).  What may still be outstanding when item q is needed: the items issued after
+// it (two instructions each) and, if they were issued after it, the stores of the previous strip's end.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kRing = 3;
+#ifndef SUCRE_RING
+#define SUCRE_RING 3
+#endif
+// waves per SIMD the fit kernels are compiled for (register budget 512 / waves) = workgroups per CU of their
+// persistent grids: kFitWaves / kClosedWaves (layout.h)
+constexpr int kRing = SUCRE_RING;
 constexpr int kAhead = kRing - 1;
-constexpr int kSlot = kChunk;  // LDS image of one chunk = byte-exact copy
+constexpr int kSlot = kChunk;  // largest item: a full float32 chunk (1792 B)
 
 struct __attribute__((aligned(16))) FitLds {
-    union {
-        uint8_t ring[4][kRing][kSlot];  // phase 1: per-wave chunk ring
-        float red[4][6][kTilePx];        // phase 2: per-pixel sums of the four waves (ring is dead by then)
-    } u;
-    double stot[kSumsPad];
-    float wsum[4][kNumSums];
-    int is_last, is_last_total;  // one flag word per arrive_last level: no wave can see the second verdict as the first
-};
-
-struct __attribute__((aligned(16))) FitLdsOne {
-    union {
-        uint8_t ring[4][kRing][kSlot];
-        float red[4][9][kTilePx];        // one round = one triple of quantities x 3 channels of the four waves
-    } u;
+    uint8_t ring[4][kRing][kSlot];  // per-wave item ring
     double stot[kSumsPad];
     float wsum[4][kNumSums];
     int is_last, is_last_total;  // one flag word per arrive_last level: no wave can see the second verdict as the first
@@ -188,162 +223,210 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 }
 
 #ifndef SUCRE_DMA_POLICY
-#define SUCRE_DMA_POLICY " nt"  // chunks are read once per launch: streaming policy (measured -20 % vs default)
+#define SUCRE_DMA_POLICY " nt"  // items are read once per launch: streaming policy (measured -20 % vs default)
 #endif
 
-// chunk (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address); lane offsets are loop constants.
-// A dwordx4 LDS-DMA writes lane i's 16 bytes at slot + 16 i (a dwordx3 one also strides by 16, leaving holes --
-// measured, tools/probes/lds_dma_probe.hip), so the 768 colour bytes are moved by the first 48 lanes of a second
-// dwordx4: the LDS image is a byte-exact copy of the 1792-byte chunk.  EXEC is all ones here (whole workgroup
-// runs this code) and is restored inside the statement; M0 is written in the statement that reads it.
-template <int kFmt>
-__device__ __forceinline__ void dma_chunk(const uint8_t *chunk, uint32_t slot, uint32_t voff) {
-#ifndef SUCRE_EXP_NOLOAD
+__device__ __forceinline__ uint64_t lane_mask(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+// src (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address).  EXEC is all ones on entry (whole
+// waves run this code) and is restored inside the statement; M0 is written in the statement that reads it.
+__device__ __forceinline__ void dma_item(const uint8_t *src, uint32_t slot, uint32_t lane, uint32_t nA, uint32_t nB) {
+#ifdef SUCRE_EXP_NOLOAD  // experiment build only: the ring keeps whatever LDS holds
+    return;
+#endif
     unsigned keep;
-    const uint32_t slot_c = slot + kChunkZ;
-    if (kFmt == 0) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
-            "s_mov_b32 m0, %4\n\t"
-            "s_mov_b32 exec_hi, 0xffff\n\t"
-            "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
-            "s_mov_b32 exec_hi, -1\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
-            : "memory");
-    } else {
-        // 1280-byte chunk (512 B of uint16 ranges + 768 B of colours): 64 lanes move the first KiB, 16 lanes the rest
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
-            "s_mov_b32 m0, %4\n\t"
-            "s_mov_b64 exec, 0xffff\n\t"
-            "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
-            "s_mov_b64 exec, -1\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(chunk), "s"(slot), "s"(slot_c), "v"(voff + kChunkZ)
-            : "memory");
+    const uint32_t voffA = lane * 16u, voffB = voffA + nA * 16u;
+    const uint32_t slotB = slot + nA * 16u;
+    const uint64_t mA = lane_mask(nA), mB = lane_mask(nB);
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b64 exec, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_mov_b64 exec, %7\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voffA), "s"(src), "s"(slot), "s"(slotB), "v"(voffB), "s"(mA), "s"(mB)
+        : "memory");
+}
+
+// Waits until at most n vector-memory instructions of this wave are outstanding (n <= 2 kAhead + 9).
+__device__ __forceinline__ void wait_vm(uint32_t n) {
+#define SUCRE_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        SUCRE_W(0) SUCRE_W(1) SUCRE_W(2) SUCRE_W(3) SUCRE_W(4) SUCRE_W(5) SUCRE_W(6) SUCRE_W(7) SUCRE_W(8) SUCRE_W(9)
+        SUCRE_W(10) SUCRE_W(11) SUCRE_W(12) SUCRE_W(13) SUCRE_W(14) SUCRE_W(15) SUCRE_W(16) SUCRE_W(17) SUCRE_W(18)
+        SUCRE_W(19) SUCRE_W(20) SUCRE_W(21)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // never weaker than asked
     }
-#endif
+#undef SUCRE_W
+}
+static_assert(2 * kAhead + 9 <= 21, "wait_vm covers 2 * {0..kAhead} + {0, 3, 9} outstanding instructions");
+
+// Which strips a wave works on: strip k W + wid on even passes k, k W + (W - 1 - wid) on odd ones (the strips are
+// sorted heaviest first, so this boustrophedon deal balances the waves), W = waves of the launch.
+struct WaveDeal {
+    uint32_t wid, W, n_strips, K;
+    __host__ __device__ __forceinline__ uint32_t strip(uint32_t k) const { return k * W + ((k & 1u) ? W - 1u - wid : wid); }
+};
+
+__host__ __device__ __forceinline__ WaveDeal make_deal(uint32_t wid, uint32_t W, uint32_t n_strips) {
+    WaveDeal d;
+    d.wid = wid; d.W = W; d.n_strips = n_strips;
+    const uint32_t full = n_strips / W, rem = n_strips % W;
+    d.K = full + ((((full & 1u) ? W - 1u - wid : wid) < rem) ? 1u : 0u);
+    return d;
 }
 
-// Waits until at most 2*ahead DMA instructions are outstanding.
-template <int kAheadNow>
-__device__ __forceinline__ void wait_chunks() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAheadNow) : "memory");
+// ---------------------------------------------------------------------------------------------------------------
+// The plan: every wave's item stream, written once per image (launch_plan, called by the compaction) so that the
+// per-iteration kernels do no bookkeeping.  (History: the first strip kernel walked the strips itself with two
+// cursors; 136 scalar instructions per item on the CU's one scalar unit put a 74 us floor under the launch,
+// measured with both the loads and the arithmetic compiled out.)
+//
+// PlanItem.bits: [6:0] nA, [14:8] nB (lanes of the two DMA instructions), [18:16] kind, [22:20] levels of a short
+// chunk, [28:24] how many of this wave's vector-memory instructions may still be outstanding when the item is needed
+// (the items issued after it, two instructions each, plus the stores of the previous strip's end if they were
+// issued after it), [31] the strip ends with this item.
+// ---------------------------------------------------------------------------------------------------------------
+enum ItemKind : uint32_t { kItemJ = 0, kItemChunk = 1, kItemChunkMasked = 2, kItemTail = 3, kItemMoments = 4 };
+
+__host__ __device__ __forceinline__ uint32_t item_bits(uint32_t nA, uint32_t nB, uint32_t kind, uint32_t r, bool end) {
+    return nA | (nB << 8) | (kind << 16) | (r << 20) | (end ? 0x80000000u : 0u);
 }
 
-// Number of levels (wave, wave+4, ...) this wave consumes.
-__device__ __forceinline__ uint32_t views_of_wave(uint32_t n, int wave) {
-    return n > (uint32_t)wave ? (n - (uint32_t)wave + 3u) / 4u : 0u;
-}
-
-// Ring prologue: put the first kAhead chunks in flight.
-template <int kFmt, class FitLds>
-__device__ __forceinline__ void stream_begin(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, int wave,
-                                             int lane) {
-    const uint32_t voff = lane * 16;
-    const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
-#ifdef SUCRE_EXP_NOLOAD  // experiment build only: no DMA; the ring holds plausible constant data instead
-    for (int sl = 0; sl < kRing; ++sl) {
-        *reinterpret_cast<float4 *>(&lds.u.ring[wave][sl][lane * 16]) = make_float4(2.5f, 2.75f, 3.0f, 3.25f);
-        if (lane < 48) *reinterpret_cast<uint4 *>(&lds.u.ring[wave][sl][kChunkZ + lane * 16]) =
-            make_uint4(0x10203040u, 0x50607080u, 0x11223344u, 0x55667788u);
-    }
-#endif
-#pragma unroll
-    for (uint32_t d = 0; d < (uint32_t)kAhead; ++d)
-        if (d < r) dma_chunk<kFmt>(tile_obs + (size_t)(wave + 4u * d) * chunk_bytes(kFmt), ring0 + d * kSlot, voff);
-}
-
-// Ring steady state for this wave's levels v0 <= v < v1 (of r); slot / slot_in carry the ring position across calls.
-template <int kPass, bool kMasked, int kFmt, class FitLds, class AccT>
-__device__ __forceinline__ void stream_range(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r, uint32_t v0,
-                                             uint32_t v1, int wave, int lane, const Water &w, const float (&J)[3][4],
-                                             AccT &acc, uint32_t &slot, uint32_t &slot_in) {
-    const uint32_t voff = lane * 16;
-    const uint32_t ring0 = lds_addr(&lds.u.ring[wave][0][0]);
-    for (uint32_t v = v0; v < v1; ++v) {
-        if (v + kAhead < r)
-            dma_chunk<kFmt>(tile_obs + (size_t)(wave + 4u * (v + kAhead)) * chunk_bytes(kFmt), ring0 + slot_in * kSlot, voff);
-        const uint32_t ahead = min((uint32_t)kAhead, r - 1u - v);  // chunks allowed to stay in flight
-        if (ahead >= (uint32_t)kAhead) wait_chunks<kAhead>();
-        else if (kAhead > 2 && ahead == 2u) wait_chunks<2>();
-        else if (ahead == 1u) wait_chunks<1>();
-        else wait_chunks<0>();
-        const uint8_t *sp = &lds.u.ring[wave][slot][0];
-        float4 z4;
-        if (kFmt == 0) {
-            z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
-        } else {  // uint16 millimetres -> metres, the same float32 product the CPU restatement forms
-            const uint2 q = *reinterpret_cast<const uint2 *>(sp + lane * 8);
-            z4 = make_float4((float)(q.x & 0xffffu) * kMPerMm, (float)(q.x >> 16) * kMPerMm,
-                             (float)(q.y & 0xffffu) * kMPerMm, (float)(q.y >> 16) * kMPerMm);
+// kMode 0: J plane, chunks, moments (J-parameter iteration, 9 stores at a strip's end); 1: J plane, chunks
+// (closed-form iteration and update_J, 3 stores).  One thread per wave of the fit launch.
+template <int kMode>
+__global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, int fmt, uint32_t W,
+                                                   uint32_t stride, PlanItem *__restrict__ plan,
+                                                   uint32_t *__restrict__ count, uint64_t comp_off, uint64_t state_off) {
+    const uint32_t wid = blockIdx.x * 256u + threadIdx.x;
+    if (wid >= W) return;
+    const WaveDeal d = make_deal(wid, W, (uint32_t)n_strips);
+    PlanItem *out = plan + (size_t)wid * stride;
+    const uint32_t lb = (uint32_t)level_bytes(fmt);
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < d.K; ++k) {
+        const uint32_t strip = d.strip(k);
+        const StripMeta m = meta[strip];
+        const uint32_t nch = (m.levels + 3u) >> 2;
+        const uint64_t st = state_off + (uint64_t)strip * (kStateFloats * 4);
+        out[n++] = PlanItem{(uint32_t)(st >> 6), item_bits(32u, 16u, kItemJ, 0u, kMode != 0 && nch == 0u), strip, 0u};
+        for (uint32_t g = 0; g < nch; ++g) {
+            const uint32_t r = min((uint32_t)kGroupLv, m.levels - g * kGroupLv);
+            const uint64_t src = comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb;
+            const uint32_t kind = r < (uint32_t)kGroupLv ? kItemTail : ((g + 1u) * kGroupLv <= m.full ? kItemChunk : kItemChunkMasked);
+            out[n++] = PlanItem{(uint32_t)(src >> 6), item_bits((fmt ? 8u : 16u) * r, 12u * r, kind, r, kMode != 0 && g + 1u == nch),
+                                strip, 0u};
         }
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + (kFmt ? kChunkZ16 : kChunkZ)) + lane;  // planar R | G | B
-        const uint3 c3 = make_uint3(cp[0], cp[64], cp[128]);
-        accumulate_view<kPass, kMasked>(z4, c3, w, J, acc);
-        slot = slot + 1 == kRing ? 0 : slot + 1;
-        slot_in = slot_in + 1 == kRing ? 0 : slot_in + 1;
+        if (kMode == 0) out[n++] = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_bits(64u, 32u, kItemMoments, 0u, true), strip, 0u};
+    }
+    count[wid] = n;
+    // the wait of every item: replay the issue order (item i is consumed after items up to i + kAhead were issued)
+    constexpr uint32_t kStores = kMode == 0 ? 9u : 3u;
+    uint32_t store_after = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t issued = min(n, i + 1u + (uint32_t)kAhead);
+        const uint32_t vm = 2u * (issued - 1u - i) + (i < store_after ? kStores : 0u);
+        const uint32_t bits = out[i].bits;
+        out[i].bits = bits | (vm << 24);
+        if (bits & 0x80000000u) store_after = issued;
     }
 }
 
-// Ring steady state + drain; stream_begin must have been called for the same (tile, wave).  The levels below
-// nfull (the tile's smallest pixel count) hold 256 real observations each: they run the select-free loop; the
-// few levels above it run the masked one.  Two separate loops on purpose: as one loop with a uniform branch hipcc
-// if-converted both bodies into one (41 selects, 127 VGPRs).
-template <int kPass, int kFmt, class FitLds, class AccT>
-__device__ __forceinline__ void stream_views(FitLds &lds, const uint8_t *__restrict__ tile_obs, uint32_t r,
-                                             uint32_t nfull, int wave, int lane, const Water &w,
-                                             const float (&J)[3][4], AccT &acc) {
-    uint32_t slot = 0, slot_in = kAhead;  // slot_in = (v + kAhead) % kRing
-    const uint32_t rf = min(r, views_of_wave(nfull, wave));
-    stream_range<kPass, false, kFmt>(lds, tile_obs, r, 0u, rf, wave, lane, w, J, acc, slot, slot_in);
-    stream_range<kPass, true, kFmt>(lds, tile_obs, r, rf, r, wave, lane, w, J, acc, slot, slot_in);
-    wait_chunks<0>();  // nothing of ours is in flight past this point
-}
-static_assert(kAhead == 2 || kAhead == 3, "wait ladder in stream_views covers kAhead 2 and 3");
+__device__ __forceinline__ uint32_t item_kind(uint32_t bits) { return (bits >> 16) & 7u; }
 
-__device__ __forceinline__ void zero_acc(Acc &a) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a.pa[c][j] = 0.f; a.pb[c][j] = 0.f; }
-        a.sB[c] = 0.f;
-        a.sGZ[c] = 0.f;
+// Issues item `it` into `slot` (LDS byte address).
+__device__ __forceinline__ void issue_item(const PlanItem &it, const uint8_t *__restrict__ ws, uint32_t slot, uint32_t lane) {
+    const uint8_t *src = ws + ((uint64_t)it.src64 << 6);
+    dma_item(src, slot, lane, it.bits & 127u, (it.bits >> 8) & 127u);
+}
+
+// A full chunk in a ring slot -> this lane's four ranges and three colour dwords.
+template <int kFmt>
+__device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&zz)[kGroupLv], uint32_t (&cc)[3]) {
+    if (kFmt == 0) {
+        const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
+        zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
+    } else {  // uint16 millimetres -> metres, the same float32 product the CPU restatement forms
+        const uint2 q = *reinterpret_cast<const uint2 *>(sp + lane * 8);
+        zz[0] = (float)(q.x & 0xffffu) * kMPerMm; zz[1] = (float)(q.x >> 16) * kMPerMm;
+        zz[2] = (float)(q.y & 0xffffu) * kMPerMm; zz[3] = (float)(q.y >> 16) * kMPerMm;
     }
-    a.cost = 0.f;
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + (kFmt ? 2 : 4) * kStripPx * kGroupLv) + lane;
+    cc[0] = cp[0]; cc[1] = cp[kStripPx]; cc[2] = cp[2 * kStripPx];
 }
 
-// Adds the four waves' per-pixel sums (fixed order) and returns, for pixel slot `t`, the six totals.
-// The leading barrier retires every wave's ring before `red` (which overlays it) is written.
-template <class FitLds>
-__device__ __forceinline__ void reduce_pixels(FitLds &lds, const Acc &acc, int wave, int lane, int t, float out[6]) {
-    __syncthreads();
+// Level j of a short chunk (r < 4 levels, rows of r) in a ring slot.
+template <int kFmt>
+__device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t r, uint32_t j, float &z, uint32_t (&k)[3]) {
+    if (kFmt == 0) z = reinterpret_cast<const float *>(sp)[lane * r + j];
+    else z = (float)reinterpret_cast<const uint16_t *>(sp)[lane * r + j] * kMPerMm;
+    const uint8_t *cb = sp + (kFmt ? 2 : 4) * kStripPx * r;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        *reinterpret_cast<float4 *>(&lds.u.red[wave][c][lane * 4]) =
-            make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
-        *reinterpret_cast<float4 *>(&lds.u.red[wave][3 + c][lane * 4]) =
-            make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
+    for (int c = 0; c < 3; ++c) k[c] = cb[c * kStripPx * r + lane * r + j];
+}
+
+// The streaming skeleton shared by the fit kernels: the wave's items in plan order, kAhead of them in flight.
+//   on_J(slot pointer)                      a strip begins: its J plane has landed
+//   on_chunk(slot pointer, masked)          a full chunk
+//   on_tail(slot pointer, r)                the strip's short last chunk
+//   on_end(strip, slot pointer or nullptr)  the strip is complete (J-parameter mode: its moments have landed);
+//                                           must issue exactly the mode's number of vector stores per lane
+template <int kFmt, class OnJ, class OnChunk, class OnTail, class OnEnd>
+__device__ __forceinline__ void stream_items(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n,
+                                             const uint8_t *__restrict__ ws, int wave, int lane, OnJ on_J,
+                                             OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
+    if (n == 0) return;
+    const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
+    // descriptors of the items in flight: d[S] describes the item that lives in ring slot S
+    PlanItem d[kRing];
+#pragma unroll
+    for (int S = 0; S < kRing; ++S) d[S] = plan[(uint32_t)S < n ? S : 0];
+#pragma unroll
+    for (int S = 0; S < kAhead; ++S)
+        if ((uint32_t)S < n) issue_item(d[S], ws, ring0 + (uint32_t)S * kSlot, lane);
+    uint32_t i = 0;
+    bool more = true;
+    while (more) {
+        // the loop is unrolled over the ring, so slots and descriptor registers are compile-time: one step consumes
+        // item i from slot S, issues item i + kAhead into slot (S + kAhead) % kRing, and refills d[S] with the
+        // descriptor of item i + kRing
+#pragma unroll
+        for (int S = 0; S < kRing; ++S) {
+            if (more) {
+                const int Sin = (S + kAhead) % kRing;
+                if (i + (uint32_t)kAhead < n) issue_item(d[Sin], ws, ring0 + (uint32_t)Sin * kSlot, lane);
+                const uint32_t bits = d[S].bits, strip = d[S].strip;
+                if (i + (uint32_t)kRing < n) d[S] = plan[i + (uint32_t)kRing];
+                const uint32_t vm = (bits >> 24) & 31u;
+                if (vm == 2u * kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead) : "memory");  // the steady state
+                else wait_vm(vm);
+                const uint8_t *sp = &lds.ring[wave][S][0];
+                const uint32_t kind = item_kind(bits);
+                if (kind == kItemChunk) on_chunk(sp, false);
+                else if (kind == kItemChunkMasked) on_chunk(sp, true);
+                else if (kind == kItemJ) on_J(sp);
+                else if (kind == kItemTail) on_tail(sp, (bits >> 20) & 7u);
+                if (bits & 0x80000000u) on_end(strip, kind == kItemMoments ? sp : (const uint8_t *)nullptr);
+                ++i;
+                more = i < n;
+            }
+        }
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 6; ++q)
-        out[q] = ((lds.u.red[0][q][t] + lds.u.red[1][q][t]) + lds.u.red[2][q][t]) + lds.u.red[3][q][t];
+    wait_vm(0);  // nothing of ours is in flight past this point
 }
 
-// Two-level, fixed-order float64 reduction of the per-tile partials (layout [kNumSums][n_tiles]):
-//   gpart[q][g] = sum of the 32 tiles of group g       (one load per lane + fixed-shape shuffle tree)
+
+// Two-level, fixed-order float64 reduction of the per-workgroup partials (layout [kNumSums][n_blocks]):
+//   gpart[q][g] = sum of the 32 workgroups of group g  (one load per lane + fixed-shape shuffle tree)
 //   sums[q]     = sum over the groups                  (4 loads per lane + the same tree)
 // The same two functions run in the fused tail (group-last / global-last workgroup) and in the split-path
 // kernel, so both paths produce the same bits.  All hand-off data move with agent-scope (sc1) accesses.
@@ -353,14 +436,14 @@ __device__ __forceinline__ double wave_sum_fixed(double x) {  // fixed-shape tre
     return x;
 }
 
-// 256 threads: wave w reduces quantities q = w, w+4, w+8; lane l holds tile 32 g + l (lanes >= 32 hold 0).
-__device__ __forceinline__ void reduce_group(const float *partials, int n_tiles, int g, double *gpart, int n_groups) {
+// 256 threads: wave w reduces quantities q = w, w+4, w+8; lane l holds workgroup 32 g + l (lanes >= 32 hold 0).
+__device__ __forceinline__ void reduce_group(const float *partials, int n_blocks, int g, double *gpart, int n_groups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = g * kGroup + lane;
+    const int b = g * kGroup + lane;
     for (int q = wave; q < kNumSums; q += 4) {
         double x = 0.0;
-        if (lane < kGroup && tile < n_tiles)
-            x = (double)__hip_atomic_load(partials + (size_t)q * n_tiles + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < kGroup && b < n_blocks)
+            x = (double)__hip_atomic_load(partials + (size_t)q * n_blocks + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = wave_sum_fixed(x);
         if (lane == 0) __hip_atomic_store(gpart + (size_t)q * n_groups + g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -434,9 +517,9 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
     }
 }
 
-// End of a fit launch: the workgroup's ten sums -> one float32 partial each -> (fused form) two-level last-arriver
-// reduction in float64 and the Adam step on B, beta, gamma by the workgroup that arrives last.
-template <bool kFused, class FitLds>
+// End of a fit launch: the lanes' ten sums -> one float32 partial per workgroup -> (fused form) two-level
+// last-arriver reduction in float64 and the Adam step on B, beta, gamma by the workgroup that arrives last.
+template <bool kFused>
 __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums], float *partials, const AdamCoef &co,
                                               unsigned *ticket, double *gpart, int n_groups, double *sums,
                                               float *pstate, const uint64_t *__restrict__ n_obs_total,
@@ -482,224 +565,167 @@ __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums],
     }
 }
 
+// J-parameter iteration (sucre.py:142-148 with J among the parameters).
 template <bool kFused, int kFmt>
-__global__ __launch_bounds__(256) void fit_grad_kernel(const uint8_t *__restrict__ comp,
-                                                       const uint64_t *__restrict__ tile_off,
-                                                       const uint32_t *__restrict__ levels,
-                                                       const uint32_t *__restrict__ full, int n_tiles,
+__global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t *__restrict__ ws,
+                                                       const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
-                                                       float *__restrict__ Jt, float *__restrict__ mt,
-                                                       float *__restrict__ vt, float *partials, const AdamCoef co,
+                                                       float *__restrict__ state, float *partials, const AdamCoef co,
                                                        unsigned *ticket, double *gpart, int n_groups, double *sums,
                                                        double *trace_row, const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLds lds;  // 24.9 KB: 6 workgroups per CU
-    const int n_blocks = gridDim.x;
+    __shared__ FitLds lds;  // 21.9 KB
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
-
-    // The workgroup is persistent over tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the compact store's tiles are
-    // sorted heaviest first, so this deal is balanced).  The per-thread global sums simply keep accumulating across
-    // its tiles; the shuffle reduction, the sc1 publish and the ticket hand-off -- measured at ~40 us per launch when
-    // done once per tile (bisected with early-return builds) -- happen once per workgroup.
-    Acc acc;
-    zero_acc(acc);
-    float sBetaAcc[3] = {0.f, 0.f, 0.f};
+#ifdef SUCRE_EXP_CLOCK  // experiment build only: shader clock held during the launch (MI355X_MICROARCH.md, DVFS item 6)
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // a store compacted in the other format is not read at all; the logged cost turns NaN instead
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
-    if (!fmt_ok) acc.cost = __builtin_nanf("");
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t n_items = fmt_ok ? plan_count[wid] : 0u;
 
-#ifdef SUCRE_EXP_SNAKE
-    for (int stripe = 0; stripe * n_blocks < n_tiles; ++stripe) {
-        const int tile = stripe * n_blocks + ((stripe & 1) ? n_blocks - 1 - (int)blockIdx.x : (int)blockIdx.x);
-        if (tile >= n_tiles) continue;
-#else
-    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
-#endif
-        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
-        const uint8_t *tile_obs = comp + tile_off[tile];
-        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
-        const uint32_t r = views_of_wave(n, wave);
-        float J[3][4];
-        float tot[6];
-        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-        {
-            // J of this lane's four pixels: ordinary loads issued BEHIND the ring prologue.  hipcc does not count
-            // the asm DMAs, so the wait it emits for J (vmcnt(0)) would also drain whatever DMA is in flight at J's
-            // first use; the empty asm makes that first use happen here, where only the prologue (issued at the same
-            // time, hence landing at the same time) is outstanding: one shared start-up latency per tile.
-            float4 jv[3];
+    // The lane's shares of the global sums keep accumulating across its strips; the per-pixel sums restart with
+    // every strip.
+    Acc acc;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+    for (int c = 0; c < 3; ++c) { acc.pa[c] = 0.f; acc.pb[c] = 0.f; acc.sB[c] = 0.f; acc.sGZ[c] = 0.f; }
+    acc.cost = fmt_ok ? 0.f : __builtin_nanf("");
+    float sBeta[3] = {0.f, 0.f, 0.f};
+    float J[3] = {0.f, 0.f, 0.f};
+
+    stream_items<kFmt>(
+        lds, plan + (size_t)wid * plan_stride, n_items, ws, wave, lane,
+        [&](const uint8_t *sp) {  // J plane
+            const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
-                J[c][0] = jv[c].x; J[c][1] = jv[c].y; J[c][2] = jv[c].z; J[c][3] = jv[c].w;
+            for (int c = 0; c < 3; ++c) { J[c] = f[c * kStripPx + lane]; acc.pa[c] = 0.f; acc.pb[c] = 0.f; }
+        },
+        [&](const uint8_t *sp, bool masked) {  // chunk of four levels
+            float zz[kGroupLv];
+            uint32_t cc[3];
+            read_chunk<kFmt>(sp, lane, zz, cc);
+            if (masked) accumulate_chunk<true>(zz, cc, w, J, acc);
+            else accumulate_chunk<false>(zz, cc, w, J, acc);
+        },
+        [&](const uint8_t *sp, uint32_t r) {  // the strip's short last chunk
+            for (uint32_t j = 0; j < r; ++j) {
+                float z;
+                uint32_t k[3];
+                read_level<kFmt>(sp, lane, r, j, z, k);
+                accumulate_level(z, k, w, J, acc);
             }
-        }
-
-        // per-pixel sums restart with every tile; the global sums (sB, sGZ, cost) carry on
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
-        stream_views<kPassGradJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-        reduce_pixels(lds, acc, wave, lane, t, tot);
-
-        // pixel-parallel tail: this thread owns pixel slot t
-        {
-            float *mtile = mt + (size_t)tile * 3 * kTilePx;
-            float *vtile = vt + (size_t)tile * 3 * kTilePx;
+        },
+        [&](uint32_t strip, const uint8_t *sp) {  // moments landed: torch.optim.Adam on this pixel's J
+            const float *f = reinterpret_cast<const float *>(sp);
+            float *st = state + (size_t)strip * kStateFloats;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
+                float Jc = J[c], m = f[c * kStripPx + lane], v = f[(3 + c) * kStripPx + lane];
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
-                sBetaAcc[c] += (tot[3 + c] == 0.0f) ? 0.0f : Jc * tot[3 + c];
-                adam_update(Jc, m, v, gscale * tot[c], co);
-                Jtile[c * kTilePx + t] = Jc;
-                mtile[c * kTilePx + t] = m;
-                vtile[c * kTilePx + t] = v;
+                sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
+                adam_update(Jc, m, v, gscale * acc.pa[c], co);
+                st[c * kStripPx + lane] = Jc;
+                st[(3 + c) * kStripPx + lane] = m;
+                st[(6 + c) * kStripPx + lane] = v;
             }
-        }
-        __syncthreads();  // `red` retired before the next tile's ring prologue overwrites the LDS
-    }
+        });
 
+#ifdef SUCRE_EXP_CLOCK
+    if (t == 0 && blockIdx.x == 7) {   // stamps go to the two padding slots of `sums`, which nothing reads
+        sums[10] = (double)(__builtin_amdgcn_s_memtime() - clk0);
+        sums[11] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+    if (lane == 0 && trace_row) {      // every wave's life, behind the row (the experiment passes a larger buffer)
+        trace_row[16 + 2 * (blockIdx.x * 4 + wave)] = (double)rt0;
+        trace_row[17 + 2 * (blockIdx.x * 4 + wave)] = (double)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
-                         sBetaAcc[0], sBetaAcc[1], sBetaAcc[2], acc.cost};
+                         sBeta[0], sBeta[1], sBeta[2], acc.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
 }
 
-// Closed-form mode, one observation pass per iteration (see AccOne).
-template <bool kFused, int kFmt>
-__global__ __launch_bounds__(256) void fit_closed_kernel(const uint8_t *__restrict__ comp,
-                                                         const uint64_t *__restrict__ tile_off,
-                                                         const uint32_t *__restrict__ levels,
-                                                         const uint32_t *__restrict__ full, int n_tiles,
+// Closed-form mode, one observation pass per iteration (see AccOne); kJOnly: SUCRe.update_J alone (sucre.py:66-77,
+// 156): J = sum (I - b) a / sum a^2 from the current parameters, nothing else.
+template <bool kFused, int kFmt, bool kJOnly>
+__global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uint8_t *__restrict__ ws,
+                                                         const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
                                                          float *pstate, const uint64_t *__restrict__ n_obs_total,
-                                                         float *__restrict__ Jt, float *partials, const AdamCoef co,
+                                                         float *__restrict__ state, float *partials, const AdamCoef co,
                                                          unsigned *ticket, double *gpart, int n_groups, double *sums,
                                                          double *trace_row, const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLdsOne lds;  // 37 KB; the kernel is register-bound (3 workgroups per CU) before it is LDS-bound
-    const int n_blocks = gridDim.x;
+    __shared__ FitLds lds;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
+    // plan was written for the store's format, so the items themselves are sound)
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t n_items = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;
     float sB[3] = {0.f, 0.f, 0.f}, sGZ[3] = {0.f, 0.f, 0.f}, sBeta[3] = {0.f, 0.f, 0.f};
     float cost = fmt_ok ? 0.f : __builtin_nanf("");
+    AccOne acc;
+    float Jp[3] = {0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
-        const uint32_t n = fmt_ok ? levels[tile] : 0u, nfull = fmt_ok ? full[tile] : 0u;
-        const uint8_t *tile_obs = comp + tile_off[tile];
-        const uint32_t r = views_of_wave(n, wave);
-        AccOne acc;
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc.q[q][c][j] = 0.f;
-        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
-        stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-        // previous J of this lane's four pixels: ordinary loads issued behind the ring prologue (see fit_grad_kernel)
-        float Jp[3][4];
-        {
-            float4 jv[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) jv[c] = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
+    stream_items<kFmt>(
+        lds, plan + (size_t)wid * plan_stride, n_items, ws, wave, lane,
+        [&](const uint8_t *sp) {  // previous J of this pixel
+            const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                asm volatile("" : "+v"(jv[c].x), "+v"(jv[c].y), "+v"(jv[c].z), "+v"(jv[c].w));
-                // a pixel that had no J so far (NaN: never observed, or a warm start without it) is measured from 0
-                Jp[c][0] = finite_or_zero(jv[c].x); Jp[c][1] = finite_or_zero(jv[c].y);
-                Jp[c][2] = finite_or_zero(jv[c].z); Jp[c][3] = finite_or_zero(jv[c].w);
+                // a pixel that had no J so far (NaN: never observed, or a warm start without it) is measured from 0;
+                // update_J measures from 0 always (J = N / D exactly as sucre.py:77 forms it)
+                Jp[c] = kJOnly ? 0.0f : finite_or_zero(f[c * kStripPx + lane]);
             }
-        }
-        stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, Jp, acc);
-
-        // the four waves' per-pixel sums, three quantities (x 3 channels) per round through `red`
-        float tot[9][3];
 #pragma unroll
-        for (int round = 0; round < 3; ++round) {
-            __syncthreads();  // ring (round 0) / previous round retired
+            for (int q = 0; q < 9; ++q)
 #pragma unroll
-            for (int qq = 0; qq < 3; ++qq)
+                for (int c = 0; c < 3; ++c) acc.q[q][c] = 0.f;
+        },
+        [&](const uint8_t *sp, bool masked) {
+            float zz[kGroupLv];
+            uint32_t cc[3];
+            read_chunk<kFmt>(sp, lane, zz, cc);
+            if (masked) accumulate_chunk<true>(zz, cc, w, Jp, acc);
+            else accumulate_chunk<false>(zz, cc, w, Jp, acc);
+        },
+        [&](const uint8_t *sp, uint32_t r) {
+            for (uint32_t j = 0; j < r; ++j) {
+                float z;
+                uint32_t k[3];
+                read_level<kFmt>(sp, lane, r, j, z, k);
+                accumulate_level(z, k, w, Jp, acc);
+            }
+        },
+        [&](uint32_t strip, const uint8_t *) {  // all levels seen: re-solve J, form the pixel's share of the sums
+            float *st = state + (size_t)strip * kStateFloats;
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    *reinterpret_cast<float4 *>(&lds.u.red[wave][qq * 3 + c][lane * 4]) =
-                        make_float4(acc.q[round * 3 + qq][c][0], acc.q[round * 3 + qq][c][1],
-                                    acc.q[round * 3 + qq][c][2], acc.q[round * 3 + qq][c][3]);
-            __syncthreads();
-#pragma unroll
-            for (int qq = 0; qq < 3; ++qq)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int pl = qq * 3 + c;
-                    tot[round * 3 + qq][c] =
-                        ((lds.u.red[0][pl][t] + lds.u.red[1][pl][t]) + lds.u.red[2][pl][t]) + lds.u.red[3][pl][t];
+            for (int c = 0; c < 3; ++c) {
+                const float N = acc.q[0][c], D = acc.q[1][c];
+                const float dJ = N / D;                          // 0/0 = NaN where nothing was observed (sucre.py:77)
+                const float Jc = fmt_ok ? Jp[c] + dJ : __builtin_nanf("");   // = sum y a / sum a^2
+                st[c * kStripPx + lane] = Jc;
+                if (!kJOnly && D != 0.0f) {
+                    sB[c] += __builtin_fmaf(-dJ, acc.q[3][c], acc.q[2][c]);
+                    sBeta[c] += Jc * __builtin_fmaf(-dJ, acc.q[5][c], acc.q[4][c]);
+                    sGZ[c] += __builtin_fmaf(-dJ, acc.q[7][c], acc.q[6][c]);
+                    cost += __builtin_fmaf(-dJ, N, acc.q[8][c]);
                 }
-        }
-        // pixel-parallel tail: this thread owns pixel slot t
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float N = tot[0][c], D = tot[1][c];
-            const float dJ = N / D;                          // 0/0 = NaN where nothing was observed (sucre.py:77)
-            const float Jc = finite_or_zero(Jtile[c * kTilePx + t]) + dJ;    // = sum y a / sum a^2
-            Jtile[c * kTilePx + t] = Jc;
-            if (D != 0.0f) {
-                sB[c] += __builtin_fmaf(-dJ, tot[3][c], tot[2][c]);
-                sBeta[c] += Jc * __builtin_fmaf(-dJ, tot[5][c], tot[4][c]);
-                sGZ[c] += __builtin_fmaf(-dJ, tot[7][c], tot[6][c]);
-                cost += __builtin_fmaf(-dJ, N, tot[8][c]);
             }
-        }
-        __syncthreads();  // `red` retired before the next tile's ring prologue overwrites the LDS
-    }
+        });
+    if (kJOnly) return;
     float s[kNumSums] = {sB[0], sB[1], sB[2], sGZ[0], sGZ[1], sGZ[2], sBeta[0], sBeta[1], sBeta[2], cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
 }
 
-// SUCRe.update_J alone (sucre.py:66-77, 156)
-template <int kFmt>
-__global__ __launch_bounds__(256) void update_J_kernel(const uint8_t *__restrict__ comp,
-                                                       const uint64_t *__restrict__ tile_off,
-                                                       const uint32_t *__restrict__ levels,
-                                                       const uint32_t *__restrict__ full,
-                                                       const float *__restrict__ params, float *__restrict__ Jt,
-                                                       const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLds lds;
-    const int tile = blockIdx.x;
-    if (*obs_format != (uint32_t)kFmt) {  // wrong format announced by the caller: poison instead of misreading
-        for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + threadIdx.x] = __builtin_nanf("");
-        return;
-    }
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(params);
-    const uint32_t r = views_of_wave(levels[tile], wave), nfull = full[tile];
-    const uint8_t *tile_obs = comp + tile_off[tile];
-    float J[3][4];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) J[c][j] = 0.f;
-    Acc acc;
-    zero_acc(acc);
-    stream_begin<kFmt>(lds, tile_obs, r, wave, lane);
-    stream_views<kPassClosedJ, kFmt>(lds, tile_obs, r, nfull, wave, lane, w, J, acc);
-    float tot[6];
-    reduce_pixels(lds, acc, wave, lane, t, tot);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Jt[((size_t)tile * 3 + c) * kTilePx + t] = tot[c] / tot[3 + c];
-}
-
-__global__ __launch_bounds__(256) void reduce_groups_kernel(const float *partials, int n_tiles, double *gpart,
+__global__ __launch_bounds__(256) void reduce_groups_kernel(const float *partials, int n_blocks, double *gpart,
                                                             int n_groups) {
-    reduce_group(partials, n_tiles, blockIdx.x, gpart, n_groups);
+    reduce_group(partials, n_blocks, blockIdx.x, gpart, n_groups);
 }
 
 __global__ __launch_bounds__(256) void reduce_sums_kernel(const double *gpart, int n_groups, double *__restrict__ sums) {
@@ -715,11 +741,12 @@ __global__ __launch_bounds__(64) void param_step_kernel(const double *__restrict
 
 struct Params9 { float v[9]; };
 
+// SUCRe.__init__ (sucre.py:36-50) in the sorted pixel order: one workgroup per sorted tile = four strips.
 __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict__ rgb1,
                                                        const float *__restrict__ depth1,
                                                        const float *__restrict__ J0, int H, int W, int tiles_x,
-                                                       const uint32_t *__restrict__ perm, float *__restrict__ Jt, float *__restrict__ mt,
-                                                       float *__restrict__ vt, float *__restrict__ pstate,
+                                                       const uint32_t *__restrict__ perm, float *__restrict__ state,
+                                                       float *__restrict__ pstate,
                                                        unsigned *__restrict__ ticket, int n_tickets,
                                                        const Params9 p0) {
     const int tile = blockIdx.x, t = threadIdx.x;  // sorted tile / slot; perm gives the pixel that lives there
@@ -730,20 +757,20 @@ __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict
     const bool inside = v < H && u < W;
     const size_t o = inside ? (size_t)v * W + u : 0;
     const bool valid = inside && !(depth1[o] <= 0.0f);  // self.J[depth <= 0] = nan, sucre.py:48
+    float *st = state + ((size_t)tile * kStripsPerTile + (t >> 6)) * kStateFloats + (t & 63);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float Jc = __builtin_nanf("");
         if (valid) Jc = J0 ? J0[o * 3 + c] : unit_from_u8(rgb1[o * 3 + c]);
-        const size_t i = ((size_t)tile * 3 + c) * kTilePx + t;
-        Jt[i] = Jc;
-        mt[i] = 0.f;
-        vt[i] = 0.f;
+        st[c * kStripPx] = Jc;
+        st[(3 + c) * kStripPx] = 0.f;
+        st[(6 + c) * kStripPx] = 0.f;
     }
     if (tile == 0 && t < 27) pstate[t] = t < 9 ? p0.v[t] : 0.f;
     for (int i = tile * 256 + t; i < n_tickets; i += gridDim.x * 256) ticket[i] = 0u;
 }
 
-__global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__ Jt, int H, int W, int tiles_x,
+__global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__ state, int H, int W, int tiles_x,
                                                        const uint32_t *__restrict__ invperm, float *__restrict__ J) {
     const int tile = blockIdx.x, t = threadIdx.x;  // image tile / slot; invperm says where the pixel was sorted to
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -751,8 +778,9 @@ __global__ __launch_bounds__(256) void export_J_kernel(const float *__restrict__
     if (v >= H || u >= W) return;
     const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
     const size_t o = ((size_t)v * W + u) * 3;
+    const float *st = state + (size_t)(dst / kStripPx) * kStateFloats + dst % kStripPx;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) J[o + c] = Jt[((size_t)(dst / kTilePx) * 3 + c) * kTilePx + dst % kTilePx];
+    for (int c = 0; c < 3; ++c) J[o + c] = st[c * kStripPx];
 }
 
 __global__ void set_n_obs_total_kernel(uint64_t *dst, uint64_t v) { *dst = v; }
@@ -762,39 +790,23 @@ hipError_t launch_fit_init(const Layout &L, uint8_t *ws, const uint8_t *rgb1, co
     Params9 p0;
     for (int i = 0; i < 9; ++i) p0.v[i] = params0[i];
     hipLaunchKernelGGL(fit_init_kernel, dim3(L.n_tiles), dim3(256), 0, s, rgb1, depth1, J0, L.H, L.W, L.tiles_x,
-                       reinterpret_cast<const uint32_t *>(ws + L.off_perm), reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
-                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_params),
-                       reinterpret_cast<unsigned *>(ws + L.off_ticket), (1 + L.n_groups) * kTicketStride, p0);
+                       reinterpret_cast<const uint32_t *>(ws + L.off_perm), reinterpret_cast<float *>(ws + L.off_state),
+                       reinterpret_cast<float *>(ws + L.off_params),
+                       reinterpret_cast<unsigned *>(ws + L.off_ticket), (1 + L.n_groups) * kTicketStride, p0);  // n_groups = the larger grid's
     return hipGetLastError();
 }
 
-template <bool kFused, int kFmt>
-static void launch_grad_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_grad_kernel<kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
-                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
+template <class Kernel>
+static void launch_fit_kernel(Kernel kernel, int mode, const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(kernel, dim3(L.fit_blocks[mode]), dim3(256), 0, s, ws,
+                       reinterpret_cast<const PlanItem *>(ws + L.off_plan[mode]),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_plan_count[mode]), (uint32_t)L.plan_stride[mode],
                        reinterpret_cast<float *>(ws + L.off_params),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
-                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
-                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(ws + L.off_partials), co,
+                       reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(ws + L.off_partials), co,
                        reinterpret_cast<unsigned *>(ws + L.off_ticket),
-                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups,
-                       reinterpret_cast<double *>(ws + L.off_sums), trace_row,
-                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
-}
-
-template <bool kFused, int kFmt>
-static void launch_closed_fmt(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s) {
-    hipLaunchKernelGGL((fit_closed_kernel<kFused, kFmt>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
-                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_full), L.n_tiles,
-                       reinterpret_cast<float *>(ws + L.off_params),
-                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
-                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_partials), co,
-                       reinterpret_cast<unsigned *>(ws + L.off_ticket),
-                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups,
+                       reinterpret_cast<double *>(ws + L.off_gpartials), L.fit_groups[mode],
                        reinterpret_cast<double *>(ws + L.off_sums), trace_row,
                        reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
 }
@@ -805,11 +817,11 @@ static void launch_grad_variant(const Layout &L, uint8_t *ws, const AdamCoef &co
                                 hipStream_t s) {
     const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
     if (flags & SUCRE_FIT_CLOSED_FORM) {
-        if (u16) launch_closed_fmt<kFused, 1>(L, ws, co, trace_row, s);
-        else launch_closed_fmt<kFused, 0>(L, ws, co, trace_row, s);
+        if (u16) launch_fit_kernel(fit_closed_kernel<kFused, 1, false>, 1, L, ws, co, trace_row, s);
+        else launch_fit_kernel(fit_closed_kernel<kFused, 0, false>, 1, L, ws, co, trace_row, s);
     } else {
-        if (u16) launch_grad_fmt<kFused, 1>(L, ws, co, trace_row, s);
-        else launch_grad_fmt<kFused, 0>(L, ws, co, trace_row, s);
+        if (u16) launch_fit_kernel(fit_grad_kernel<kFused, 1>, 0, L, ws, co, trace_row, s);
+        else launch_fit_kernel(fit_grad_kernel<kFused, 0>, 0, L, ws, co, trace_row, s);
     }
 }
 
@@ -824,11 +836,12 @@ hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &c
 // all-reduce; launch_fit_step applies them.
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s) {
     launch_grad_variant<false>(L, ws, co, flags, nullptr, s);
-    hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.n_groups), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(ws + L.off_partials), L.n_blocks,
-                       reinterpret_cast<double *>(ws + L.off_gpartials), L.n_groups);
+    const int mode = (flags & SUCRE_FIT_CLOSED_FORM) ? 1 : 0;
+    hipLaunchKernelGGL(reduce_groups_kernel, dim3(L.fit_groups[mode]), dim3(256), 0, s,
+                       reinterpret_cast<const float *>(ws + L.off_partials), L.fit_blocks[mode],
+                       reinterpret_cast<double *>(ws + L.off_gpartials), L.fit_groups[mode]);
     hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(256), 0, s,
-                       reinterpret_cast<const double *>(ws + L.off_gpartials), L.n_groups,
+                       reinterpret_cast<const double *>(ws + L.off_gpartials), L.fit_groups[mode],
                        reinterpret_cast<double *>(ws + L.off_sums));
     return hipGetLastError();
 }
@@ -840,25 +853,28 @@ hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, dou
     return hipGetLastError();
 }
 
-template <int kFmt>
-static void launch_update_J_fmt(const Layout &L, uint8_t *ws, hipStream_t s) {
-    hipLaunchKernelGGL(update_J_kernel<kFmt>, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_comp,
-                       reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_levels),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_full),
-                       reinterpret_cast<const float *>(ws + L.off_params), reinterpret_cast<float *>(ws + L.off_J),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks + sizeof(uint64_t)));
+hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
+    if (fmt) launch_fit_kernel(fit_closed_kernel<false, 1, true>, 1, L, ws, AdamCoef{}, nullptr, s);
+    else launch_fit_kernel(fit_closed_kernel<false, 0, true>, 1, L, ws, AdamCoef{}, nullptr, s);
+    return hipGetLastError();
 }
 
-hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
-    if (fmt) launch_update_J_fmt<1>(L, ws, s);
-    else launch_update_J_fmt<0>(L, ws, s);
+// Writes both plans (J-parameter and closed-form item streams) for the store the compaction has just built.
+hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
+    auto *meta = reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta);
+    const uint32_t W0 = (uint32_t)L.fit_blocks[0] * 4u, W1 = (uint32_t)L.fit_blocks[1] * 4u;
+    hipLaunchKernelGGL(plan_kernel<0>, dim3((W0 + 255) / 256), dim3(256), 0, s, meta, L.n_strips, fmt, W0, (uint32_t)L.plan_stride[0],
+                       reinterpret_cast<PlanItem *>(ws + L.off_plan[0]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[0]),
+                       (uint64_t)L.off_comp, (uint64_t)L.off_state);
+    hipLaunchKernelGGL(plan_kernel<1>, dim3((W1 + 255) / 256), dim3(256), 0, s, meta, L.n_strips, fmt, W1, (uint32_t)L.plan_stride[1],
+                       reinterpret_cast<PlanItem *>(ws + L.off_plan[1]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[1]),
+                       (uint64_t)L.off_comp, (uint64_t)L.off_state);
     return hipGetLastError();
 }
 
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s) {
     hipLaunchKernelGGL(export_J_kernel, dim3(L.n_tiles), dim3(256), 0, s,
-                       reinterpret_cast<const float *>(ws + L.off_J), L.H, L.W, L.tiles_x,
+                       reinterpret_cast<const float *>(ws + L.off_state), L.H, L.W, L.tiles_x,
                        reinterpret_cast<const uint32_t *>(ws + L.off_invperm), J);
     return hipGetLastError();
 }

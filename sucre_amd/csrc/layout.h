@@ -17,20 +17,55 @@ constexpr int kChunk16 = kChunkZ16 + kChunkRGB;  // 1280 bytes per (sorted tile,
 constexpr float kMmPerM = 1000.0f, kMPerMm = 0.001f;
 __host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt ? kChunk16 : kChunk; }
 constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
+// Compact store (what the fit streams): the count-sorted pixels are cut into STRIPS of 64 consecutive pixels -- one
+// pixel per lane of the wave that owns the strip.  A strip with n levels is stored as ceil(n/4) chunks of 64 pixels x
+// r levels, r = 4 except in the last one (r = n - 4 g): [z: 64 x r ranges, pixel-major][R: 64 x r bytes][G][B], i.e.
+// kLevelBytes x r bytes.  A full chunk has the size of a dense one (1792 B / 1280 B) and a lane reads its pixel's
+// four levels as one float4 (uint2) + three dwords.
+constexpr int kStripPx = 64;
+constexpr int kStripsPerTile = kTilePx / kStripPx;
+constexpr int kGroupLv = 4;                       // levels per full chunk
+constexpr int kStateFloats = 9 * kStripPx;        // J[3], exp_avg[3], exp_avg_sq[3] planes of a strip (2304 B)
+__host__ __device__ constexpr int level_bytes(int fmt) { return (fmt ? 2 : 4) * kStripPx + 3 * kStripPx; }  // 448 / 320
+constexpr int kExtLevelBytes = 3 * 4 * kStripPx;  // extension planes of one level of a strip: 3 floats x 64 pixels
+
+struct StripMeta {
+    uint64_t lvoff;   // levels of all earlier strips: the strip's chunks start at comp + lvoff * level_bytes(fmt)
+    uint32_t levels;  // largest pixel count in the strip
+    uint32_t full;    // smallest pixel count: chunks wholly below it hold 64 x 4 real observations (no select needed)
+};
 constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
 constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)
 constexpr int kTicketStride = 16;    // uint32 words between tickets: every counter on its own 64-byte line
-constexpr int kFitGrid = 1536;       // persistent fit workgroups (6 per CU x 256 CUs); a constant, so the reduction
-                                     // order -- hence every result bit -- does not depend on the device
+#ifndef SUCRE_FIT_WAVES
+#define SUCRE_FIT_WAVES 6
+#endif
+#ifndef SUCRE_CLOSED_WAVES
+#define SUCRE_CLOSED_WAVES 4
+#endif
+constexpr int kFitWaves = SUCRE_FIT_WAVES;        // waves per SIMD of fit_grad_kernel (80 VGPRs)
+constexpr int kClosedWaves = SUCRE_CLOSED_WAVES;  // ... of fit_closed_kernel (27 accumulators per lane: 118 VGPRs)
+constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (kFitWaves per CU x 256 CUs: all resident
+                                     // at once); constants, so the reduction order -- hence every result bit -- does
+                                     // not depend on the device
+constexpr int kClosedGrid = 256 * kClosedWaves;
 constexpr int kMaxViews = 4096;
+
+// One entry of a wave's item stream (fit.hip, plan_kernel): what to copy into the LDS ring and what it is.
+struct PlanItem {
+    uint32_t src64;   // source address: workspace base + 64 * src64
+    uint32_t bits;    // lanes of the two DMA instructions, kind, wait count, end-of-strip flag (fit.hip)
+    uint32_t strip;   // the strip the item belongs to
+    uint32_t pad;
+};
 
 struct Layout {
     int H, W, n_views, tiles_x, tiles_y, n_tiles;
     size_t off_obs;         // uint8  chunks of kChunk bytes, chunk(tile, k) at tile*obs_tile_stride + k*obs_view_stride
     size_t obs_tile_stride, obs_view_stride;
     size_t off_cnt;         // uint16 [n_tiles][n_views]   matches of view k inside the tile
-    size_t off_comp;        // uint8  compact store: chunk (sorted tile, level) at tile_off[tile] + level*kChunk
+    size_t off_comp;        // uint8  compact store: strip s at lvoff[s] * level_bytes(fmt), see StripMeta
     size_t off_pcount;      // uint16 [n_tiles*256]        observations of every pixel over the kept views
     size_t off_pmask;       // uint64 [n_tiles*256][mask_words]  which views observe the pixel (bit k = view k)
     int mask_words;
@@ -38,10 +73,9 @@ struct Layout {
     size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
     size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)
     size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
-    size_t off_levels;      // uint32 [n_tiles]            chunks (levels) of every sorted tile (= largest pixel count in it)
-    size_t off_full;        // uint32 [n_tiles]            levels with all 256 slots occupied (= smallest pixel count)
-    size_t off_tile_off;    // uint64 [n_tiles]            byte offset of a sorted tile's first chunk in the compact store
-    size_t off_total_chunks;// uint64 [1], then uint32 [1]: observation format of the compact store (SUCRE_OBS_*)
+    int n_strips;           // n_tiles * 4 strips of 64 sorted pixels
+    size_t off_strip_meta;  // StripMeta [n_strips]
+    size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [1]: observation format of the compact store (SUCRE_OBS_*)
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]
     size_t off_n_obs;       // uint64 [1]
@@ -50,9 +84,13 @@ struct Layout {
     size_t off_sums;        // double [kSumsPad]
     size_t off_ticket;      // uint32 [(1 + n_groups) * kTicketStride]  arrival counters: [0] = groups done, [1+g] = tiles of group g done
     size_t off_gpartials;   // double [kNumSums][n_groups]  per-group sums
-    int n_blocks, n_groups; // fit grid (min(n_tiles, kFitGrid)) and its 32-workgroup reduction groups
+    int n_blocks, n_groups; // largest fit grid (min(n_tiles, kFitGrid)) and its 32-workgroup reduction groups
+    int fit_blocks[2], fit_groups[2];  // grid / reduction groups of the J-parameter [0] and closed-form [1] kernels
     size_t off_partials;    // float  [kNumSums][n_blocks]  one partial per fit workgroup
-    size_t off_J, off_m, off_v;  // float [n_tiles][3][256]
+    size_t off_state;       // float [n_strips][9][64]: J, exp_avg, exp_avg_sq (three channel planes each) of every strip
+    size_t off_plan[2];     // PlanItem [4 n_blocks][plan_stride]: item streams of the fit waves (J-parameter / closed-form)
+    size_t off_plan_count[2];  // uint32 [4 n_blocks] items of every wave
+    size_t plan_stride[2];  // items reserved per wave
     size_t total;
 };
 
@@ -82,9 +120,8 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_bin_totals = take(512 * sizeof(uint32_t));
     L->off_perm = take(nt * kTilePx * sizeof(uint32_t));
     L->off_invperm = take(nt * kTilePx * sizeof(uint32_t));
-    L->off_levels = take(nt * sizeof(uint32_t));
-    L->off_full = take(nt * sizeof(uint32_t));
-    L->off_tile_off = take(nt * sizeof(uint64_t));
+    L->n_strips = L->n_tiles * kStripsPerTile;
+    L->off_strip_meta = take((size_t)L->n_strips * sizeof(StripMeta));
     L->off_total_chunks = take(sizeof(uint64_t));
     L->off_view_count = take(nv * sizeof(uint64_t));
     L->off_view_keep = take(nv * sizeof(uint32_t));
@@ -94,12 +131,21 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_sums = take(kSumsPad * sizeof(double));
     L->n_blocks = L->n_tiles < kFitGrid ? L->n_tiles : kFitGrid;
     L->n_groups = (L->n_blocks + kGroup - 1) / kGroup;
+    L->fit_blocks[0] = L->n_blocks;
+    L->fit_blocks[1] = L->n_tiles < kClosedGrid ? L->n_tiles : kClosedGrid;
+    for (int m = 0; m < 2; ++m) L->fit_groups[m] = (L->fit_blocks[m] + kGroup - 1) / kGroup;
     L->off_ticket = take((size_t)(1 + L->n_groups) * kTicketStride * sizeof(uint32_t));
     L->off_gpartials = take((size_t)kNumSums * L->n_groups * sizeof(double));
     L->off_partials = take(nt * kNumSums * sizeof(float));
-    L->off_J = take(nt * 3 * kTilePx * sizeof(float));
-    L->off_m = take(nt * 3 * kTilePx * sizeof(float));
-    L->off_v = take(nt * 3 * kTilePx * sizeof(float));
+    L->off_state = take((size_t)L->n_strips * kStateFloats * sizeof(float));
+    {   // a wave gets at most ceil(n_strips / waves) strips of at most ceil(n_views / 4) chunks + J plane + moments
+        for (int m = 0; m < 2; ++m) {
+            const size_t waves = (size_t)L->fit_blocks[m] * 4;
+            L->plan_stride[m] = (((size_t)L->n_strips + waves - 1) / waves) * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2);
+            L->off_plan[m] = take(waves * L->plan_stride[m] * sizeof(PlanItem));
+            L->off_plan_count[m] = take(waves * sizeof(uint32_t));
+        }
+    }
     L->total = o;
     return true;
 }

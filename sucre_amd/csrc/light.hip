@@ -10,7 +10,7 @@
 // plus the 19 parameters (B, beta, gamma, cam2light[6], sigma[4]), their Adam moments, and the reduction buffers.
 // Everything of the default path (J planes, compact store, perm, levels) is reused from the main workspace.
 //
-// One iteration = light_grad_kernel (persistent workgroups like fit_grad_kernel; 26 sums) -> light_reduce_kernel
+// One iteration = light_grad_kernel (persistent waves on strips like fit_grad_kernel; 26 sums) -> light_reduce_kernel
 // (fixed-order float64) -> light_step_kernel (chain rule through Sigma^-1 and through the matrix exponential --
 // six 8x8 block exponentials evaluated in parallel in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1).
 // This mode is built for correctness first: plain loads instead of the LDS-DMA ring.
@@ -22,7 +22,7 @@ constexpr int kLightSums = 26;   // sB[3] sGZ[3] sBeta[3] cost | dR[9] dt[3] dM[
 constexpr int kLightParams = 19;
 
 struct LightLayout {
-    size_t off_ext_dense, off_ext_comp;   // float [chunk][3][256]
+    size_t off_ext_dense, off_ext_comp;   // dense: float [chunk][3][256]; compact: kExtLevelBytes per level of a strip
     size_t off_params;                    // float [19] params, [19] exp_avg, [19] exp_avg_sq
     size_t off_geom;                      // float [16]: R[9], t[3], M[4] = Sigma^-1 (row-major)
     size_t off_partials;                  // float [26][n_blocks]
@@ -127,8 +127,7 @@ __global__ __launch_bounds__(512) void light_geometry_kernel(const float *pstate
 
 // ---- gradient pass ---------------------------------------------------------------------------------------------------
 struct LightAcc {
-    float pa[3][4], pb[3][4];      // per pixel-channel: sum r l a ; sum r l a z
-    float s[kLightSums];           // thread-level global sums (slots 6..8 = sBeta are filled per tile)
+    float s[kLightSums];           // lane-level global sums (slots 6..8 = sBeta are filled at the end of every strip)
 };
 
 // l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
@@ -158,16 +157,35 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
 
 struct LightChunk { float zz[4], xx[4], yy[4], ww[4]; uint32_t cc[3]; };
 
-__device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *tobs, const uint8_t *text, uint32_t lv, int lane) {
-    const uint8_t *ch = tobs + (size_t)lv * kChunk;
-    const float *ex = reinterpret_cast<const float *>(text + (size_t)lv * kExtChunk);
-    const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
-    const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + kChunkZ) + lane;
-    const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
-    const float4 y4 = *reinterpret_cast<const float4 *>(ex + kTilePx + lane * 4);
-    const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kTilePx + lane * 4);
-    LightChunk c = {{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
-                    {cp[0], cp[64], cp[128]}};
+// Chunk g of a strip (r of its four levels exist, layout.h / compact.hip) -> this lane's pixel: ranges, extension
+// planes (camera point or float colour) and colour bytes of up to four levels; levels that do not exist read z = 0.
+__device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, const uint8_t *sext, uint32_t g, uint32_t r, int lane) {
+    const uint8_t *ch = sobs + (size_t)g * (kGroupLv * level_bytes(0));
+    const float *ex = reinterpret_cast<const float *>(sext + (size_t)g * (kGroupLv * kExtLevelBytes));
+    LightChunk c;
+    if (r == kGroupLv) {
+        const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + 4 * kStripPx * kGroupLv) + lane;
+        const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
+        const float4 y4 = *reinterpret_cast<const float4 *>(ex + kStripPx * kGroupLv + lane * 4);
+        const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kStripPx * kGroupLv + lane * 4);
+        c = LightChunk{{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
+                       {cp[0], cp[kStripPx], cp[2 * kStripPx]}};
+    } else {
+        c.cc[0] = c.cc[1] = c.cc[2] = 0u;
+        const uint8_t *cb = ch + 4 * kStripPx * r;
+#pragma unroll
+        for (int j = 0; j < kGroupLv; ++j) {
+            const bool has = (uint32_t)j < r;
+            const uint32_t i = lane * r + (has ? j : 0);
+            c.zz[j] = has ? reinterpret_cast<const float *>(ch)[i] : 0.0f;
+            c.xx[j] = has ? ex[i] : 0.0f;
+            c.yy[j] = has ? ex[kStripPx * r + i] : 0.0f;
+            c.ww[j] = has ? ex[2 * kStripPx * r + i] : 0.0f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) c.cc[pl] |= (has ? (uint32_t)cb[pl * kStripPx * r + i] : 0u) << (8 * j);
+        }
+    }
     return c;
 }
 
@@ -175,17 +193,14 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *tobs, cons
 // backscatter = l B (1 - g)) and is a constant of the gradient; kJOnly: only that closed-form J (final update_J).
 // kColour (SUCRE_EXT_COLOUR): the extension planes carry the observation's float32 colour instead of its camera
 // point; there is no light then (l = 1, z = the stored range) and the light sums stay zero.
+// Every wave works alone on strips of 64 sorted pixels, one pixel per lane (the deal of fit.hip).
 template <bool kClosed, bool kJOnly, bool kColour>
 __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restrict__ comp, const uint8_t *__restrict__ ext,
-                                                         const uint64_t *__restrict__ tile_off,
-                                                         const uint32_t *__restrict__ levels, int n_tiles,
+                                                         const StripMeta *__restrict__ meta, int n_strips,
                                                          const float *__restrict__ pstate, const float *__restrict__ geom,
                                                          const uint64_t *__restrict__ n_obs_total,
-                                                         float *__restrict__ Jt, float *__restrict__ mt,
-                                                         float *__restrict__ vt, float *__restrict__ partials,
+                                                         float *__restrict__ state, float *__restrict__ partials,
                                                          const AdamCoef co) {
-    __shared__ __attribute__((aligned(16))) float red[4][6][kTilePx];
-    __shared__ __attribute__((aligned(16))) float jbuf[3][kTilePx];
     __shared__ float wsum[4][kLightSums];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -210,109 +225,89 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
 #pragma unroll
     for (int q = 0; q < kLightSums; ++q) acc.s[q] = 0.f;
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += n_blocks) {
-        const uint32_t n = levels[tile];
-        const uint8_t *tobs = comp + tile_off[tile];
-        const uint8_t *text = ext + (tile_off[tile] / kChunk) * kExtChunk;
-        float *Jtile = Jt + (size_t)tile * 3 * kTilePx;
-        float J[3][4];
+    const uint32_t W = (uint32_t)n_blocks * 4u, wid = blockIdx.x * 4u + (uint32_t)wave;
+    for (uint32_t k = 0;; ++k) {
+        const uint32_t strip = k * W + ((k & 1u) ? W - 1u - wid : wid);   // boustrophedon deal, as in fit.hip
+        if (k * W >= (uint32_t)n_strips) break;
+        if (strip >= (uint32_t)n_strips) continue;
+        const StripMeta sm = meta[strip];
+        const uint32_t n = sm.levels, nch = (n + 3u) >> 2;
+        const uint8_t *sobs = comp + sm.lvoff * (uint64_t)level_bytes(0);
+        const uint8_t *sext = ext + sm.lvoff * (uint64_t)kExtLevelBytes;
+        float *st = state + (size_t)strip * kStateFloats + lane;
+        float J[3];
         if (kClosed) {
-            // closed-form J of the tile: numerator / denominator per pixel-channel over all levels
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; }
-            for (uint32_t lv = wave; lv < n; lv += 4) {
-                const LightChunk k = load_light_chunk(tobs, text, lv, lane);
+            // closed-form J of this pixel: numerator / denominator per channel over all levels
+            float num[3] = {0.f, 0.f, 0.f}, den[3] = {0.f, 0.f, 0.f};
+            for (uint32_t g = 0; g < nch; ++g) {
+                const LightChunk kk = load_light_chunk(sobs, sext, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (!(k.zz[j] > 0.0f)) continue;
-                    const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
+                    if (!(kk.zz[j] > 0.0f)) continue;
+                    const float cP[3] = {kk.xx[j], kk.yy[j], kk.ww[j]};
                     LightObs o;
-                    if (kColour) { o.l = 1.0f; o.z = k.zz[j]; }
-                    else o = light_obs(cP, k.zz[j], R, tl, M);
+                    if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
+                    else o = light_obs(cP, kk.zz[j], R, tl, M);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float a = o.l * fast_exp2(o.z * nb[c]);
                         const float b = o.l * B[c] * (1.0f - fast_exp2(o.z * ng[c]));
-                        const float I = kColour ? cP[c] : unit_from_u8((k.cc[c] >> (8 * j)) & 255u);
-                        acc.pa[c][j] = __builtin_fmaf(I - b, a, acc.pa[c][j]);
-                        acc.pb[c][j] = __builtin_fmaf(a, a, acc.pb[c][j]);
+                        const float I = kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
+                        num[c] = __builtin_fmaf(I - b, a, num[c]);
+                        den[c] = __builtin_fmaf(a, a, den[c]);
                     }
                 }
             }
-            __syncthreads();
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) = make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
-                *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) = make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
+                J[c] = num[c] / den[c];  // 0/0 = NaN where nothing was observed
+                st[c * kStripPx] = J[c];
             }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float num = ((red[0][c][t] + red[1][c][t]) + red[2][c][t]) + red[3][c][t];
-                const float den = ((red[0][3 + c][t] + red[1][3 + c][t]) + red[2][3 + c][t]) + red[3][3 + c][t];
-                const float Jc = num / den;  // 0/0 = NaN where nothing was observed
-                Jtile[c * kTilePx + t] = Jc;
-                jbuf[c][t] = Jc;
-            }
-            __syncthreads();
             if (kJOnly) continue;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 v = *reinterpret_cast<const float4 *>(&jbuf[c][lane * 4]);
-                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
-            }
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float4 v = *reinterpret_cast<const float4 *>(Jtile + c * kTilePx + lane * 4);
-                J[c][0] = v.x; J[c][1] = v.y; J[c][2] = v.z; J[c][3] = v.w;
-            }
+            for (int c = 0; c < 3; ++c) J[c] = st[c * kStripPx];
         }
-        float bJ[3][4];   // beta J of this lane's pixels: constant over the tile's observations
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc.pa[c][j] = 0.f; acc.pb[c][j] = 0.f; bJ[c][j] = beta[c] * J[c][j]; }
-        for (uint32_t lv = wave; lv < n; lv += 4) {
-            const LightChunk k = load_light_chunk(tobs, text, lv, lane);
+        float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
+        const float bJ[3] = {beta[0] * J[0], beta[1] * J[1], beta[2] * J[2]};   // constant over the pixel's observations
+        for (uint32_t g = 0; g < nch; ++g) {
+            const LightChunk kk = load_light_chunk(sobs, sext, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (!(k.zz[j] > 0.0f)) continue;  // padding slot
-                const float cP[3] = {k.xx[j], k.yy[j], k.ww[j]};
+                if (!(kk.zz[j] > 0.0f)) continue;  // padding slot
+                const float cP[3] = {kk.xx[j], kk.yy[j], kk.ww[j]};
                 LightObs o;
-                if (kColour) { o.l = 1.0f; o.z = k.zz[j]; }
-                else o = light_obs(cP, k.zz[j], R, tl, M);
+                if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
+                else o = light_obs(cP, kk.zz[j], R, tl, M);
                 const float l = o.l, z = o.z;
                 float dl = 0.f, dz = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float a = fast_exp2(z * nb[c]), g = fast_exp2(z * ng[c]);
-                    const float omg = 1.0f - g;
-                    const float E = __builtin_fmaf(J[c][j], a, B[c] * omg);
+                    const float a = fast_exp2(z * nb[c]), g2 = fast_exp2(z * ng[c]);
+                    const float omg = 1.0f - g2;
+                    const float E = __builtin_fmaf(J[c], a, B[c] * omg);
                     // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
                     // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
-                    const uint32_t kb = (k.cc[c] >> (8 * j)) & 255u;
+                    const uint32_t kb = (kk.cc[c] >> (8 * j)) & 255u;
                     const float r = kColour ? cP[c] - l * E
                                   : kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
                     const float rl = r * l;
                     const float rlz = rl * z;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
-                    acc.pa[c][j] = __builtin_fmaf(rl, a, acc.pa[c][j]);
-                    acc.pb[c][j] = __builtin_fmaf(rlz, a, acc.pb[c][j]);
+                    pa[c] = __builtin_fmaf(rl, a, pa[c]);
+                    pb[c] = __builtin_fmaf(rlz, a, pb[c]);
                     acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
-                    acc.s[3 + c] = __builtin_fmaf(rlz, g, acc.s[3 + c]);
+                    acc.s[3 + c] = __builtin_fmaf(rlz, g2, acc.s[3 + c]);
                     dl = __builtin_fmaf(r, E, dl);
-                    dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g, -(bJ[c][j] * a)), dz);
+                    dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g2, -(bJ[c] * a)), dz);
                 }
                 if (kColour) continue;  // no light: nothing flows into cam2light / sigma
                 // chain rule into lP (common factor -2 s applied in the step kernel); M symmetric:
                 // d(lp^T M lp)/dlp = 2 M lp = 2 (w0, w1)
-                const float kk = dl * (-0.5f * l);
-                const float kk2 = kk + kk;
-                const float dlp0 = kk2 * o.w0;
-                const float dlp1 = kk2 * o.w1;
+                const float kf = dl * (-0.5f * l);
+                const float kf2 = kf + kf;
+                const float dlp0 = kf2 * o.w0;
+                const float dlp1 = kf2 * o.w1;
                 const float iz = o.iz, inl = o.inl;
                 float dlP[3];
                 dlP[0] = dz * o.lP[0] * inl + dlp0 * iz;
@@ -324,34 +319,23 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
 #pragma unroll
                     for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
                 }
-                acc.s[22] = __builtin_fmaf(kk * o.lp0, o.lp0, acc.s[22]);
-                acc.s[23] = __builtin_fmaf(kk * o.lp0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
-                acc.s[25] = __builtin_fmaf(kk * o.lp1, o.lp1, acc.s[25]);
+                acc.s[22] = __builtin_fmaf(kf * o.lp0, o.lp0, acc.s[22]);
+                acc.s[23] = __builtin_fmaf(kf * o.lp0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
+                acc.s[25] = __builtin_fmaf(kf * o.lp1, o.lp1, acc.s[25]);
             }
         }
-        // per-pixel sums of the four waves (fixed order), then the pixel-parallel tail
-        __syncthreads();
+        // the pixel's tail, in the lane that owns it
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            *reinterpret_cast<float4 *>(&red[wave][c][lane * 4]) = make_float4(acc.pa[c][0], acc.pa[c][1], acc.pa[c][2], acc.pa[c][3]);
-            *reinterpret_cast<float4 *>(&red[wave][3 + c][lane * 4]) = make_float4(acc.pb[c][0], acc.pb[c][1], acc.pb[c][2], acc.pb[c][3]);
-        }
-        __syncthreads();
-        float *mtile = mt + (size_t)tile * 3 * kTilePx, *vtile = vt + (size_t)tile * 3 * kTilePx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float ta = ((red[0][c][t] + red[1][c][t]) + red[2][c][t]) + red[3][c][t];
-            const float tb = ((red[0][3 + c][t] + red[1][3 + c][t]) + red[2][3 + c][t]) + red[3][3 + c][t];
             if (kClosed) {
-                acc.s[6 + c] += (tb == 0.0f) ? 0.0f : jbuf[c][t] * tb;
+                acc.s[6 + c] += (pb[c] == 0.0f) ? 0.0f : J[c] * pb[c];
             } else {
-                float Jc = Jtile[c * kTilePx + t], m = mtile[c * kTilePx + t], v = vtile[c * kTilePx + t];
-                acc.s[6 + c] += (tb == 0.0f) ? 0.0f : Jc * tb;
-                adam_update(Jc, m, v, gscale * ta, co);
-                Jtile[c * kTilePx + t] = Jc; mtile[c * kTilePx + t] = m; vtile[c * kTilePx + t] = v;
+                float Jc = J[c], m = st[(3 + c) * kStripPx], v = st[(6 + c) * kStripPx];
+                acc.s[6 + c] += (pb[c] == 0.0f) ? 0.0f : Jc * pb[c];
+                adam_update(Jc, m, v, gscale * pa[c], co);
+                st[c * kStripPx] = Jc; st[(3 + c) * kStripPx] = m; st[(6 + c) * kStripPx] = v;
             }
         }
-        __syncthreads();
     }
     if (kJOnly) return;
     // workgroup sums: shuffle tree, then the four waves in fixed order
@@ -492,12 +476,10 @@ template <bool kClosed, bool kJOnly, bool kColour>
 static void launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
                                 hipStream_t s) {
     hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
-                       lws + X.off_ext_comp, reinterpret_cast<const uint64_t *>(ws + L.off_tile_off),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_levels), L.n_tiles,
+                       lws + X.off_ext_comp, reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips,
                        reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
-                       reinterpret_cast<float *>(ws + L.off_J), reinterpret_cast<float *>(ws + L.off_m),
-                       reinterpret_cast<float *>(ws + L.off_v), reinterpret_cast<float *>(lws + X.off_partials), co);
+                       reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(lws + X.off_partials), co);
 }
 
 template <bool kClosed, bool kJOnly>

@@ -61,7 +61,7 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.sucre_finalize_matches(ws, 48, 64, 3, float('nan'), None) == -1
     assert lib.sucre_fit_run(ws, 48, 64, 3, 0, -1, 0.05, 0.9, 0.999, 1e-8, 0, None, None) == -2
     assert lib.sucre_fit_run(ws, 48, 64, 3, 0, 1, 0.05, 1.5, 0.999, 1e-8, 0, None, None) == -1
-    assert lib.sucre_fit_run(ws, 48, 64, 3, 0, 1, 0.05, 0.9, 0.999, 1e-8, 8, None, None) == -1 and b'flags' in lib.sucre_last_error()
+    assert lib.sucre_fit_run(ws, 48, 64, 3, 0, 1, 0.05, 0.9, 0.999, 1e-8, 64, None, None) == -1 and b'flags' in lib.sucre_last_error()
     assert lib.sucre_fit_grad(ws, 48, 64, 3, 0, 0.05, 0.9, 0.999, 1e-8, 0, None) == -2
     assert lib.sucre_export_view(ws, 48, 64, 3, 3, ws, None, None) == -2
     assert lib.sucre_export_J(ws, 48, 64, 3, None, None) == -1
