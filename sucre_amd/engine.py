@@ -1,8 +1,9 @@
 """Host driver of the HIP engine: device buffers, launch order, read-back.
 
 PyTorch-ROCm is plumbing here (device memory, streams); every kernel lives in libsucre_hip.so.  One
-``Restoration`` owns the workspace of one target image of size HxW fitted against ``n_views`` views and is
-reused across images of the same geometry.
+``Restoration`` owns the workspace of one target image of size HxW fitted against up to ``n_views`` views (its
+capacity; a target matched against fewer views lays the same buffer out for that number) and is reused across
+images of the same geometry.
 """
 from __future__ import annotations
 
@@ -67,6 +68,9 @@ class DeviceView:
         return s
 
 
+MAX_VIEWS = 4096   # kMaxViews of csrc/layout.h: views of one restoration (after the overlap cull of sfm.Image.match_images)
+
+
 def _stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -94,6 +98,7 @@ class Restoration:
         self._fmt = _lib.OBS_FORMATS[obs_format]
         self._fmt_flag = _lib.FIT_OBS_U16MM if self._fmt == _lib.OBS_U16MM else 0
         self.H, self.W, self.n_views = int(height), int(width), int(n_views)
+        self.capacity = int(n_views)   # the buffers are sized for this many views; match() may use fewer
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.SucreError('the HIP engine needs a GPU device (there is no CPU fallback)')
@@ -126,7 +131,8 @@ class Restoration:
 
     # -- matching (sfm.py:127-138 + loader.py:78-118) ---------------------------------------------------------
     def match(self, target: DeviceView, views: list[DeviceView], min_cover: float = 1e-6) -> None:
-        assert len(views) == self.n_views
+        assert 1 <= len(views) <= self.capacity, (len(views), self.capacity)
+        self.n_views = len(views)   # the workspace layout is a function of (H, W, n_views) and grows with n_views
         tgt = target.to_struct()
         table = (_lib.SucreView * self.n_views)(*[v.to_struct() for v in views])
         host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
@@ -150,7 +156,8 @@ class Restoration:
         """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
         (int16[n], int16[n], float32[n], uint8[n,3]) -- what one group of a reference matches file provides after
         ``cP = unproject_depth(u2, v2, d)`` and ``z = ||cP||`` (loader.py:103-118, sucre.py:53)."""
-        assert len(lists) == self.n_views
+        assert 1 <= len(lists) <= self.capacity, (len(lists), self.capacity)
+        self.n_views = len(lists)
         self._keepalive = [target, lists]
         self._views_dev = None
         ws, H, W, n = self._geom
@@ -373,17 +380,25 @@ _SLOT = 0          # the in-flight slot the calling code is working for (see in_
 
 
 def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
-                        obs_format: str | None = None, float_colour: bool = False) -> Restoration:
-    """Workspace pool: one Restoration per (geometry, device, in-flight slot), reused image after image (the
-    1080p x 65-view workspace is ~2 GB; re-allocating it per image would serialise on the allocator)."""
+                        obs_format: str | None = None, float_colour: bool = False, tag: str = '') -> Restoration:
+    """Workspace pool: one Restoration per (geometry, device, in-flight slot, tag), reused image after image (the
+    1080p x 65-view workspace is ~2 GB; re-allocating it per image would serialise on the allocator) and grown when
+    a target needs more views than it holds.  ``tag`` keeps side uses (``Image.match_two_way``) off the workspace a
+    matches file is attached to."""
     dev = torch.device(device)
     if dev.type == 'cuda' and dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
     if obs_format is None:   # engine knob for the reference-compatible CLI, which has no flag for it
         obs_format = 'f32' if (light or float_colour) else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
-    key = (int(height), int(width), int(n_views), str(dev), bool(light), _SLOT, obs_format, bool(float_colour))
-    if key not in _POOL:
-        _POOL[key] = Restoration(height, width, n_views, device=dev, light=light, obs_format=obs_format,
+    # capacities come in steps, so targets whose surviving view counts differ a little share one workspace
+    n = int(n_views)
+    cap = (n + 7) // 8 * 8 if n <= 64 else (n + 31) // 32 * 32
+    key = (int(height), int(width), str(dev), bool(light), _SLOT, obs_format, bool(float_colour), tag)
+    have = _POOL.get(key)
+    if have is None or have.capacity < n:
+        _POOL.pop(key, None)   # release the smaller workspace before allocating the larger one
+        del have
+        _POOL[key] = Restoration(height, width, cap, device=dev, light=light, obs_format=obs_format,
                                  float_colour=float_colour)
     return _POOL[key]
 

@@ -158,6 +158,30 @@ def prefetch_device_views(images, device, num_workers: int = 0, background: bool
             im.device_view(device)
 
 
+_PLAN_POOL: ThreadPoolExecutor | None = None
+
+
+def prefetch_for_targets(targets, image_list, device, num_workers: int = 0, min_cover: float = 0.0) -> None:
+    """Background decode + upload of what the coming restorations will read, in the order they will read it: every
+    target and the images of ``image_list`` that can overlap it (``sfm.Image.overlapping_views``; all of them when the
+    cull is off).  Returns at once; ``Image.device_view`` blocks only on an image that is still being decoded."""
+    global _PLAN_POOL
+    if _PLAN_POOL is None:
+        _PLAN_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='sucre-plan')
+    cull = min_cover >= 0 and os.environ.get('SUCRE_CULL_VIEWS', '1') != '0'
+    image_list = list(image_list)
+
+    def plan(target):
+        from .sfm import PIXEL_CACHE, _canonical_device
+        if PIXEL_CACHE.full(_canonical_device(device)):
+            return   # a scene larger than the cache budget is decoded on demand instead
+        target.device_view(device)
+        idx = target.overlapping_views(image_list, device) if cull else range(len(image_list))
+        prefetch_device_views([image_list[i] for i in idx], device, num_workers=num_workers, background=True)
+    for target in targets:
+        _PLAN_POOL.submit(plan, target)
+
+
 class ImageDataset(Dataset):
     """Streams ``(idx, rgb)``, ``(idx, depth)`` or ``(idx, rgb, depth)`` like the reference (loader.py:133-153)."""
 

@@ -184,6 +184,61 @@ class Image:
         self._device_view = None
 
     # -- matching ---------------------------------------------------------------------------------------------------
+    def depth_range(self, device) -> tuple[float, float] | None:
+        """(smallest, largest) valid depth of this image, or None when no pixel is valid (cached)."""
+        cached = self.__dict__.get('_depth_range')
+        if cached is None:
+            depth = self.device_view(device).depth
+            valid = depth[depth > 0]
+            cached = (float(valid.min()), float(valid.max())) if valid.numel() else ()
+            self.__dict__['_depth_range'] = cached
+        return cached or None
+
+    def overlapping_views(self, image_list: list['Image'], device: str = 'cuda', margin: float = 2.0) -> list[int]:
+        """Indices of the images of ``image_list`` that CAN hold a match of this image; the others provably have none.
+
+        A match needs a valid pixel of this image whose world point projects inside the other image
+        (``match_one_way``, sfm.py:115-119).  Every such point lies in the convex hull of this camera's view
+        frustum cut at its smallest and largest valid depth (``unproject_depth`` scales the ray by the z-depth,
+        sfm.py:90-93).  The other image accepts a camera-frame point ``c = K (R^T (P - t))`` iff
+        ``-1 < c0/c2 < W`` and ``-1 < c1/c2 < H`` -- four half-spaces meeting in a cone for ``c2 > 0`` and, because
+        the reference never tests ``z > 0``, the mirrored cone for ``c2 < 0``.  If all eight hull corners violate one
+        and the same half-space, the hull misses that cone.  Evaluated in float64 with ``margin`` pixels of slack, far
+        above the float32 rounding of the kernel's own projection, so no view with a match is ever dropped: a dropped
+        view has zero matches and fails ``n / (W H) > min_cover`` for every ``min_cover >= 0`` (sfm.py:136) anyway."""
+        rng = self.depth_range(device)
+        if rng is None or not image_list:
+            return list(range(len(image_list)))
+        W1, H1 = self.camera.width, self.camera.height
+        Kinv = self.camera.K.double().inverse()
+        px = torch.tensor([[0.0, W1, 0.0, W1], [0.0, 0.0, H1, H1], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
+        rays = Kinv @ px                                                        # (3, 4): z component is 1
+        cP = torch.cat([rays * rng[0], rays * rng[1]], dim=1)                   # (3, 8) hull corners, camera frame
+        wP = self.pose.R.double() @ cP + self.pose.t.double()                   # world frame
+        R = torch.stack([im.pose.R for im in image_list]).double()             # (N, 3, 3) world-from-camera
+        t = torch.stack([im.pose.t for im in image_list]).double()             # (N, 3, 1)
+        K = torch.stack([im.camera.K for im in image_list]).double()
+        c = K @ (R.transpose(1, 2) @ (wP.unsqueeze(0) - t))                     # (N, 3, 8)
+        W2 = torch.tensor([im.camera.width for im in image_list], dtype=torch.float64).view(-1, 1)
+        H2 = torch.tensor([im.camera.height for im in image_list], dtype=torch.float64).view(-1, 1)
+        c0, c1, c2 = c[:, 0], c[:, 1], c[:, 2]
+        a = torch.stack([c0 + (1 + margin) * c2, (W2 + margin) * c2 - c0,
+                         c1 + (1 + margin) * c2, (H2 + margin) * c2 - c1], dim=1)      # (N, 4, 8); inside the cone: all > 0
+        misses_cone = (a <= 0).all(dim=2).any(dim=1)      # some half-space excludes every corner
+        misses_mirror = (a >= 0).all(dim=2).any(dim=1)    # inside the mirrored cone: all < 0
+        keep = ~(misses_cone & misses_mirror)
+        return torch.nonzero(keep).flatten().tolist()
+
+    def match_one_way(self, other: 'Image', u1: Tensor, v1: Tensor, wP1: Tensor) -> 'Matches':
+        """Pixels ``(u1, v1)`` of this image (world points ``wP1``) that land inside ``other`` (sfm.py:115-119):
+        the continuous projection is truncated towards zero and tested against ``other``'s sensor; nothing checks
+        that the point is in front of ``other``.  Plain tensor arithmetic on whatever device the inputs are on (the
+        engine's fused kernel never materialises one-way lists; this is the reference's building block, kept for
+        callers that use it)."""
+        q = other.project_to_view(wP1).long()
+        inside = (q[0] >= 0) & (q[0] < other.camera.width) & (q[1] >= 0) & (q[1] < other.camera.height)
+        return Matches(image1=self, image2=other, u1=u1[inside], v1=v1[inside], u2=q[0][inside], v2=q[1][inside])
+
     def match_images(self, image_list: list['Image'], matches_file: 'loader.MatchesFile', min_cover: float = 0.000001,
                      num_workers: int = 0, device: str = 'cuda', light_model: bool = False):
         """Two-way dense matching of this image against every image of ``image_list`` and preparation of the
@@ -192,6 +247,14 @@ class Image:
         disk unless the matches file is asked to persist.  ``light_model`` (not a reference argument) also keeps the
         camera-frame point of every observation, which the artificial-light model needs."""
         from . import engine
+        image_list = list(image_list)
+        if min_cover >= 0 and len(image_list) > 1 and os.environ.get('SUCRE_CULL_VIEWS', '1') != '0':
+            # images whose field of view cannot contain anything this image sees have no match and would be dropped
+            # by the min_cover rule: they are not decoded, uploaded or given workspace (overlapping_views)
+            image_list = [image_list[i] for i in self.overlapping_views(image_list, device)] or image_list[:1]
+        if len(image_list) > engine.MAX_VIEWS:
+            raise RuntimeError(f'{self.name}: {len(image_list)} images can overlap it, more than the {engine.MAX_VIEWS} '
+                               f'views one restoration holds; list images to leave out in --filter-images-path')
         loader.prefetch_device_views(image_list + [self], device, num_workers=num_workers)
         views = [im.device_view(device) for im in image_list]
         target = self.device_view(device)
@@ -205,7 +268,7 @@ class Image:
         resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device, light=light_model,
                                            float_colour=float_colour)
         resto.match(target, views, min_cover=min_cover)
-        matches_file.attach(resto, target_image=self, image_list=list(image_list))
+        matches_file.attach(resto, target_image=self, image_list=image_list)
 
     def match_two_way(self, other: 'Image', device: str = 'cuda', **_unused) -> 'Matches':
         """Mutually consistent matches between this image and ``other`` (sfm.py:121-125) as explicit lists.
@@ -217,7 +280,7 @@ class Image:
         float_colour = views[0].rgb.dtype == torch.float32 or target.rgb.dtype == torch.float32
         if float_colour:
             views, target = [views[0].as_float_colour()], target.as_float_colour()
-        resto = engine.acquire_restoration(self.camera.height, self.camera.width, 1, device, float_colour=float_colour)
+        resto = engine.acquire_restoration(self.camera.height, self.camera.width, 1, device, float_colour=float_colour, tag='pair')
         resto.match(target, views, min_cover=-1.0)
         q = resto.match_map(0)
         v1, u1 = torch.where(q >= 0)

@@ -392,7 +392,7 @@ def parse_args(args: argparse.Namespace):
     image_list = [im for im in colmap_model.images.values() if im.name not in skipped]
     args.output_dir.mkdir(parents=True, exist_ok=True)
     if str(device).startswith('cuda') and images:   # start decoding + uploading the scene now, in the background
-        loader.prefetch_device_views(image_list + images, device, num_workers=args.num_workers, background=True)
+        loader.prefetch_for_targets(images, image_list, device, num_workers=args.num_workers, min_cover=args.min_cover)
     in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
     if len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda'):
         restore_images(images, colmap_model, args.output_dir, in_flight=in_flight, keep_matches=args.keep_matches,

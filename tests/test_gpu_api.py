@@ -360,3 +360,32 @@ def test_cli_image_scale_half(disk_scene, tmp_path):
     assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-6
     got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
     assert np.abs(got - po).max() < 1e-5
+
+
+def test_overlap_cull_sizes_the_workspace_and_changes_nothing(tmp_path, monkeypatch):
+    """The whole COLMAP model is every target's neighbour list (sucre.py:182-183,238-239).  Image.match_images drops
+    the images that cannot overlap the target before anything is decoded or allocated; the restoration must be
+    the same bits as without the cull, on a workspace sized by the survivors."""
+    from sucre_amd import engine, loader, sfm, sucre
+    survey = synth.make_survey(96, 64, 12, 10, seed=5, spacing=0.5)          # 120 images, most of them far away
+    synth.write_to_disk(survey, tmp_path / 's')
+    results = {}
+    for cull in ('0', '1'):
+        monkeypatch.setenv('SUCRE_CULL_VIEWS', cull)
+        engine.release_pool()
+        model = sfm.COLMAPModel(tmp_path / 's' / 'model', tmp_path / 's' / 'images', tmp_path / 's' / 'depth')
+        image_list = list(model.images.values())
+        target = model.images[5 * 12 + 6]
+        mf = loader.MatchesFile(tmp_path / f'm{cull}.h5', colmap_model=model)
+        target.match_images(image_list, mf, device='cuda')
+        mf.check_integrity()
+        md = mf.load_matches()
+        model_ = sucre.SUCRe(target).to('cuda')
+        sucre.adam(model_, md, num_iter=15, device='cuda', verbose=False)
+        decoded = sum(im._device_view is not None for im in image_list)
+        results[cull] = (mf.restoration.n_views, [im.name for im in mf.get_image_list()], len(md),
+                         model_.J.detach().cpu().numpy(), model_.water_vector().cpu().numpy(), decoded)
+    (n0, names0, obs0, J0, p0, dec0), (n1, names1, obs1, J1, p1, dec1) = results['0'], results['1']
+    assert n0 == 120 and n1 < 40 and dec0 == 120 and dec1 == n1          # workspace and decoding follow the survivors
+    assert names0 == names1 and obs0 == obs1 and len(names1) >= 9
+    assert np.array_equal(J0, J1, equal_nan=True) and np.array_equal(p0, p1)

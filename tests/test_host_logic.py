@@ -319,3 +319,64 @@ def test_matches_plot_draws_side_by_side(tmp_path):
     m = sfm.Matches(a, b, u1=torch.tensor([0, 1, 2]), v1=torch.tensor([0, 0, 1]), u2=torch.tensor([3, 4, 5]), v2=torch.tensor([1, 1, 2]))
     pic = m.plot(step=2, color=(255, 0, 0))
     assert pic.size == (16, 6) and (np.asarray(pic) == np.array([255, 0, 0])).all(axis=2).any()
+
+
+def _images_of(scene, sizes=None):
+    """sfm.Image objects (no files) for a synthetic scene; sizes: optional per-view (K, W, H)."""
+    from sucre_amd import sfm
+    out = []
+    for i, v in enumerate(scene.views):
+        K, W, H = sizes[i] if sizes else (scene.K, scene.width, scene.height)
+        out.append(sfm.Image(i + 1, Path(v.name), Path('depth_' + v.name), sfm.Pose(v.R, v.t), sfm.Camera(i + 1, W, H, K)))
+    return out
+
+
+def test_overlap_cull_never_drops_a_view_that_has_matches():
+    """Image.overlapping_views (the pre-pass that sizes the workspace by overlap): over random scenes with far views,
+    strong rotation noise, other sensor sizes and a camera looking away from the seabed, every view the oracle finds a
+    match in survives; the far views are dropped."""
+    import helpers
+    from oracle import oracle
+    from sucre_amd import synth
+    dropped = kept_empty = 0
+    for seed in range(10):
+        a = synth.make_scene(96, 64, 5, seed=seed, far_views=3, rot_sigma=0.12)
+        b = synth.make_scene(128, 80, 5, seed=seed, far_views=0, rot_sigma=0.12)     # same poses, larger sensor
+        tgt = a.views[a.target]
+        flipped = synth.SynthView(name='flip.png', R=(tgt.R @ torch.diag(torch.tensor([1.0, -1.0, -1.0]))).contiguous(),
+                                  t=tgt.t, depth_u16=tgt.depth_u16, rgb_u8=tgt.rgb_u8)
+        views = list(a.views) + list(b.views) + [flipped]
+        sizes = [(a.K, 96, 64)] * len(a.views) + [(b.K, 128, 80)] * len(b.views) + [(a.K, 96, 64)]
+        scene = synth.SynthScene(width=96, height=64, K=a.K, views=views, target=a.target, seed=seed)
+        images = _images_of(scene, sizes)
+        d = tgt.depth_f32()
+        images[a.target].__dict__['_depth_range'] = (float(d[d > 0].min()), float(d[d > 0].max()))
+        keep = set(images[a.target].overlapping_views(images, 'cpu'))
+        cam1 = oracle.make_cam(64, 96, **helpers.cam_matrices(a.K, tgt.R, tgt.t))
+        for k, (v, (K, W, H)) in enumerate(zip(views, sizes)):
+            cam2 = oracle.make_cam(H, W, **helpers.cam_matrices(K, v.R, v.t))
+            n = len(oracle.match_view(d.numpy(), cam1, v.depth_f32().numpy(), cam2))
+            if k not in keep:
+                assert n == 0, (seed, k, n)
+                dropped += 1
+            elif n == 0:
+                kept_empty += 1
+        assert a.target in keep
+    assert dropped >= 25, dropped          # the far views (3 per scene) go
+    assert kept_empty <= 3 * 10            # and few empty ones are kept (the test is conservative, not blind)
+
+
+def test_match_one_way_mirrors_the_reference_semantics():
+    """sfm.Image.match_one_way (sfm.py:115-119): truncation towards zero, bounds test on the other sensor, no
+    in-front-of-camera test; against the oracle's forward half of the two-way matcher on a plane fixture."""
+    from sucre_amd import synth
+    scene = synth.make_scene(64, 48, 2, seed=3)
+    ims = _images_of(scene)
+    t, o = ims[scene.target], ims[0]
+    d = scene.views[scene.target].depth_f32()
+    u1, v1, wP1 = t.unproject_depth_map(d, to_world=True)
+    m = t.match_one_way(o, u1=u1, v1=v1, wP1=wP1)
+    px = o.project_to_view(wP1)
+    ref = (px[0] > -1) & (px[0] < 64) & (px[1] > -1) & (px[1] < 48)      # trunc(x) in [0, W) <=> -1 < x < W
+    assert len(m) == int(ref.sum()) and len(m) > 0
+    assert torch.equal(m.u1, u1[ref]) and torch.equal(m.v2, px[1][ref].long()) and int(m.u2.min()) >= 0
