@@ -217,6 +217,15 @@ int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, cons
 /* Same with float32 colour images: every view's `rgb` points to (H,W,3) float32 instead of uint8 (SUCRE_EXT_COLOUR). */
 int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
                               const sucre_view_t *views_dev, int k0, int k1, void *stream);
+/*
+ * sucre_import_view with extension planes: ext_dev holds three float32 planes [3][n] -- the camera points cP of the
+ * list (loader.py:113; ext_mode SUCRE_EXT_POINTS, rgb_dev required) or its colours I (loader.py:87; SUCRE_EXT_COLOUR,
+ * for colours that are not k/255; rgb_dev may be NULL).  This is how a caller-built MatchesData (loader.py:36-53)
+ * enters the engine; sucre_export_view_ext returns the planes of view k as (3, H, W), zero where nothing was observed.
+ */
+int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
+                          const float *z_dev, const uint8_t *rgb_dev, const float *ext_dev, int64_t n, int ext_mode, void *stream);
+int sucre_export_view_ext(const void *ws, const void *lws, int H, int W, int n_views, int k, float *planes_dev, void *stream);
 int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream);
 int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const uint8_t *rgb1_dev, const float *depth1_dev,
                          const float *params0, const float *J0_dev, void *stream);

@@ -18,6 +18,7 @@ FIT_OBS_U16MM = 2
 FIT_EXT_COLOUR = 4
 FIT_KEEP_J = 8
 OBS_F32, OBS_U16MM = 0, 1
+EXT_POINTS, EXT_COLOUR = 1, 2
 OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)
 
@@ -57,6 +58,8 @@ SIGNATURES = {
     'sucre_light_params_offset': (C.c_int64, [_i, _i, _i]),
     'sucre_match_views_light': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
     'sucre_match_views_fcolour': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_import_view_ext': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _vp]),
+    'sucre_export_view_ext': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'sucre_finalize_matches_light': (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     'sucre_fit_init_light': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_float), _vp, _vp]),
     'sucre_update_J_light': (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -294,6 +294,32 @@ int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, co
                                   light_ext_dense(L, static_cast<uint8_t *>(lws)), SUCRE_EXT_COLOUR), "sucre_match_views_fcolour");
 }
 
+int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
+                          const float *z_dev, const uint8_t *rgb_dev, const float *ext_dev, int64_t n, int ext_mode, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
+    if (n < 0) return fail(SUCRE_ERR_RANGE, "negative observation count %lld", (long long)n);
+    if (ext_mode != SUCRE_EXT_POINTS && ext_mode != SUCRE_EXT_COLOUR) return fail(SUCRE_ERR_ARG, "unknown extension mode %d", ext_mode);
+    if (n > 0 && (!u1_dev || !v1_dev || !z_dev || !ext_dev)) return fail(SUCRE_ERR_ARG, "NULL match list");
+    if (n > 0 && ext_mode == SUCRE_EXT_POINTS && !rgb_dev) return fail(SUCRE_ERR_ARG, "camera-point lists need uint8 colours too");
+    return check_hip(launch_import_view(L, static_cast<uint8_t *>(ws), k, u1_dev, v1_dev, z_dev, rgb_dev, (long long)n,
+                                        static_cast<hipStream_t>(stream), light_ext_dense(L, static_cast<uint8_t *>(lws)), ext_dev),
+                     "sucre_import_view_ext");
+}
+
+int sucre_export_view_ext(const void *ws, const void *lws, int H, int W, int n_views, int k, float *planes_dev, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
+    if (!planes_dev) return fail(SUCRE_ERR_ARG, "planes_dev is NULL");
+    return check_hip(launch_export_view_ext(L, static_cast<const uint8_t *>(ws),
+                                            light_ext_dense(L, const_cast<uint8_t *>(static_cast<const uint8_t *>(lws))), k,
+                                            planes_dev, static_cast<hipStream_t>(stream)), "sucre_export_view_ext");
+}
+
 int sucre_finalize_matches_light(void *ws, void *lws, int H, int W, int n_views, double min_cover, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;

@@ -274,11 +274,13 @@ __global__ __launch_bounds__(256) void clear_view_kernel(uint8_t *__restrict__ o
     if (threadIdx.x == 0) cnt[(size_t)tile * n_views + k] = 0;
 }
 
+// rgb may be NULL (float-colour lists); ext (nullable): three planes [3][n] for the extension store of view k.
 __global__ __launch_bounds__(256) void import_view_kernel(uint8_t *__restrict__ obs, int k, int tiles_x, int H, int W,
                                                           size_t tile_stride, size_t view_stride,
                                                           const int16_t *__restrict__ u1, const int16_t *__restrict__ v1,
                                                           const float *__restrict__ z, const uint8_t *__restrict__ rgb,
-                                                          long long n) {
+                                                          long long n, uint8_t *__restrict__ ext_dense, int n_views,
+                                                          const float *__restrict__ ext) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int u = u1[i], v = v1[i];
@@ -287,9 +289,36 @@ __global__ __launch_bounds__(256) void import_view_kernel(uint8_t *__restrict__ 
     const int slot = (v % kTile) * kTile + (u % kTile);
     uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
     reinterpret_cast<float *>(chunk)[slot] = z[i];
-    chunk[kChunkZ + slot] = rgb[i * 3 + 0];
-    chunk[kChunkZ + kTilePx + slot] = rgb[i * 3 + 1];
-    chunk[kChunkZ + 2 * kTilePx + slot] = rgb[i * 3 + 2];
+    chunk[kChunkZ + slot] = rgb ? rgb[i * 3 + 0] : (uint8_t)0;
+    chunk[kChunkZ + kTilePx + slot] = rgb ? rgb[i * 3 + 1] : (uint8_t)0;
+    chunk[kChunkZ + 2 * kTilePx + slot] = rgb ? rgb[i * 3 + 2] : (uint8_t)0;
+    if (ext) {
+        float *e = reinterpret_cast<float *>(ext_dense + ((size_t)tile * n_views + k) * kExtChunk);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) e[pl * kTilePx + slot] = ext[(size_t)pl * n + i];
+    }
+}
+
+// The extension planes of view k as dense planes (3, H, W): 0 where the view has no observation.
+__global__ __launch_bounds__(256) void export_view_ext_kernel(const uint8_t *__restrict__ obs, const uint16_t *__restrict__ cnt,
+                                                              const uint8_t *__restrict__ ext_dense, int n_views, int k,
+                                                              int tiles_x, int H, int W, float *__restrict__ out,
+                                                              size_t tile_stride, size_t view_stride) {
+    const int tile = blockIdx.x, slot = threadIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int v = ty * kTile + (slot >> 4), u = tx * kTile + (slot & 15);
+    if (v >= H || u >= W) return;
+    float val[3] = {0.f, 0.f, 0.f};
+    if (cnt[(size_t)tile * n_views + k] > 0) {
+        const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[slot];
+        if (z > 0.0f) {
+            const float *e = reinterpret_cast<const float *>(ext_dense + ((size_t)tile * n_views + k) * kExtChunk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) val[pl] = e[pl * kTilePx + slot];
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[((size_t)pl * H + v) * W + u] = val[pl];
 }
 
 __global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
@@ -303,14 +332,21 @@ __global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restri
     if (threadIdx.x == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
 }
 
+hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(export_view_ext_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), ext_dense, L.n_views, k, L.tiles_x, L.H, L.W, out,
+                       L.obs_tile_stride, L.obs_view_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
-                              const uint8_t *rgb, long long n, hipStream_t s) {
+                              const uint8_t *rgb, long long n, hipStream_t s, uint8_t *ext_dense, const float *ext) {
     auto *cnt = reinterpret_cast<uint16_t *>(ws + L.off_cnt);
     hipLaunchKernelGGL(clear_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
                        L.obs_tile_stride, L.obs_view_stride);
     if (n > 0)
         hipLaunchKernelGGL(import_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws + L.off_obs, k,
-                           L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n);
+                           L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n, ext_dense, L.n_views, ext);
     hipLaunchKernelGGL(count_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
                        L.obs_tile_stride, L.obs_view_stride);
     return hipGetLastError();

@@ -155,22 +155,43 @@ class Restoration:
     def import_matches(self, target: DeviceView, lists: list, min_cover: float = -1.0) -> None:
         """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
         (int16[n], int16[n], float32[n], uint8[n,3]) -- what one group of a reference matches file provides after
-        ``cP = unproject_depth(u2, v2, d)`` and ``z = ||cP||`` (loader.py:103-118, sucre.py:53)."""
+        ``cP = unproject_depth(u2, v2, d)`` and ``z = ||cP||`` (loader.py:103-118, sucre.py:53).  A fifth element, a
+        float32 (3, n) tensor, fills the extension planes of a ``light`` restoration (the camera points cP) or of a
+        ``float_colour`` one (the colours I; ``rgb_u8`` may then be None)."""
         assert 1 <= len(lists) <= self.capacity, (len(lists), self.capacity)
         self.n_views = len(lists)
         self._keepalive = [target, lists]
         self._views_dev = None
         ws, H, W, n = self._geom
+        ext_mode = _lib.EXT_COLOUR if self.float_colour else _lib.EXT_POINTS
         with torch.cuda.device(self.device):
-            for k, (u1, v1, z, rgb) in enumerate(lists):
+            for k, item in enumerate(lists):
+                u1, v1, z, rgb = item[:4]
+                ext = item[4] if len(item) > 4 else None
                 u1 = u1.to(self.device, torch.int16).contiguous(); v1 = v1.to(self.device, torch.int16).contiguous()
-                z = z.to(self.device, torch.float32).contiguous(); rgb = rgb.to(self.device, torch.uint8).contiguous()
-                assert rgb.shape == (u1.numel(), 3) and z.numel() == u1.numel() == v1.numel()
+                z = z.to(self.device, torch.float32).contiguous()
+                assert z.numel() == u1.numel() == v1.numel()
+                if rgb is not None:
+                    rgb = rgb.to(self.device, torch.uint8).contiguous()
+                    assert rgb.shape == (u1.numel(), 3)
                 self._keepalive.append((u1, v1, z, rgb))
-                _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
-                                                      C.c_void_p(z.data_ptr()), C.c_void_p(rgb.data_ptr()),
-                                                      u1.numel(), _stream_ptr()))
-            _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
+                rgbp = C.c_void_p(rgb.data_ptr()) if rgb is not None else None
+                if self.lws is not None:
+                    assert ext is not None and ext.shape == (3, u1.numel()), 'this restoration needs the (3, n) extension planes'
+                    ext = ext.to(self.device, torch.float32).contiguous()
+                    self._keepalive.append(ext)
+                    _lib.check(self.lib.sucre_import_view_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, k,
+                                                              C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
+                                                              C.c_void_p(z.data_ptr()), rgbp, C.c_void_p(ext.data_ptr()),
+                                                              u1.numel(), ext_mode, _stream_ptr()))
+                else:
+                    _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
+                                                          C.c_void_p(z.data_ptr()), rgbp, u1.numel(), _stream_ptr()))
+            if self.lws is not None:
+                _lib.check(self.lib.sucre_finalize_matches_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
+                                                                 float(min_cover), _stream_ptr()))
+            else:
+                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
 
     def match_map(self, k: int) -> torch.Tensor:
         """(H,W) int32: linear pixel index v2*W2+u2 in view k matched to every target pixel, -1 = none
@@ -202,6 +223,17 @@ class Restoration:
             _lib.check(self.lib.sucre_export_view(ws, H, W, n, int(k), C.c_void_p(z.data_ptr()),
                                                   C.c_void_p(rgb.data_ptr()), _stream_ptr()))
         return z, rgb
+
+    def export_view_ext(self, k: int) -> torch.Tensor:
+        """(3, H, W) float32: the extension planes of view k (camera points with ``light``, colours with
+        ``float_colour``), zero where the view has no observation."""
+        assert self.lws is not None, 'this restoration keeps no extension planes'
+        out = torch.empty((3, self.H, self.W), dtype=torch.float32, device=self.device)
+        ws, H, W, n = self._geom
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_export_view_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, int(k),
+                                                      C.c_void_p(out.data_ptr()), _stream_ptr()))
+        return out
 
     def check_store(self) -> torch.Tensor:
         """uint32 per view: 0 = sound, bit 0 = non-finite range, bit 1 = negative range, bit 2 = the number of stored

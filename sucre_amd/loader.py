@@ -220,8 +220,9 @@ class MatchesData:
     Two flavours share the interface of the reference's class (loader.py:36-53):
     * engine-backed (``MatchesData(restoration=...)``, what ``MatchesFile.load_matches`` returns): the data are
       the HBM observation store; ``sucre.adam`` hands it to the HIP fit directly.
-    * list-backed (``MatchesData()`` + ``append``): host tensors in the reference's format, e.g. loaded from a
-      foreign source; ``iter`` works, but ``sucre.adam`` refuses it (no CPU fallback).
+    * list-backed (``MatchesData()`` + ``append``, exactly what the reference's ``load_matches`` builds,
+      loader.py:103-118): tensors in the reference's format; ``iter`` works on them as they are, and ``sucre.adam`` /
+      ``SUCRe.update_J`` import them into an engine workspace on first use (``to_engine``).
     """
 
     def __init__(self, restoration=None, image_list=None):
@@ -234,8 +235,11 @@ class MatchesData:
 
     def _materialise(self) -> list[MatchesSample]:
         """Kept views of the observation store in the reference's sample format, groups in name order
-        (h5py iterates groups alphabetically).  ``cP`` is returned as ``(0, 0, z)``: the store keeps the range
-        ``z = ||cP||`` only, which is all ``SUCRe.forward`` reads without the light model (sucre.py:53)."""
+        (h5py iterates groups alphabetically).  ``cP`` is the camera-frame point of loader.py:113: read back from the
+        extension planes when the restoration keeps them (light model), else recomputed exactly as the reference
+        does, ``unproject_depth(u2, v2, depth2[v2, u2])``, from the explicit correspondences (``match_map``) while the
+        matched views are at hand; for a store filled from lists that carried no points, ``(0, 0, ||cP||)`` -- all
+        that ``SUCRe.forward`` reads without the light model (sucre.py:53)."""
         r = self.restoration
         keep = r.view_keep().cpu().numpy().astype(bool)
         order = sorted(range(r.n_views), key=lambda k: self.image_list[k].name if self.image_list else k)
@@ -246,13 +250,56 @@ class MatchesData:
             z, rgb = r.export_view(k)
             v, u = torch.where(z > 0)
             zz = z[v, u]
-            cP = torch.stack([torch.zeros_like(zz), torch.zeros_like(zz), zz])
-            I = (rgb[v, u].to(torch.float64) / 255).to(torch.float32).T.contiguous()
+            if r.light:
+                cP = r.export_view_ext(k)[:, v, u].contiguous()
+            elif r._views_dev is not None and self.image_list:
+                other = self.image_list[k]
+                p2 = r.match_map(k)[v, u].long()
+                W2 = other.camera.width
+                u2, v2 = p2 % W2, torch.div(p2, W2, rounding_mode='floor')
+                cP = other.unproject_depth(u=u2, v=v2, d=other.device_view(r.device).depth[v2, u2])
+            else:
+                cP = torch.stack([torch.zeros_like(zz), torch.zeros_like(zz), zz])
+            if r.float_colour:
+                I = r.export_view_ext(k)[:, v, u].contiguous()
+            else:
+                I = (rgb[v, u].to(torch.float64) / 255).to(torch.float32).T.contiguous()
             out.append(MatchesSample(u=u.short(), v=v.short(), cP=cP, I=I))
         return out
 
+    def to_engine(self, height: int, width: int, device='cuda', light: bool = False):
+        """The engine workspace holding these observations; for a list-backed container the samples are imported
+        once (``sucre_import_view[_ext]``): ranges ``z = ||cP||`` in the match kernel's float32 operation order,
+        colours as uint8 when every ``I * 255`` is an integer (images as stored) and as float32 otherwise (resized
+        images), camera points along when ``light``.  All samples are kept (they passed ``min_cover`` upstream)."""
+        if self.restoration is not None:
+            return self.restoration
+        if not self.data:
+            raise RuntimeError('this MatchesData holds no observation')
+        from . import engine
+        lists, integral = [], True
+        for s in self.data:
+            I = s.I.to(torch.float32)
+            k255 = I.to(torch.float64) * 255
+            integral = integral and bool(((k255 - k255.round()).abs() < 1e-3).all()) and bool(((k255 >= 0) & (k255 <= 255)).all())
+        if light and not integral:
+            raise NotImplementedError('the light model on observations with float32 colours (resized images): both '
+                                      'need the extension planes')
+        for s in self.data:
+            cP = s.cP.to(torch.float32)
+            z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
+            I = s.I.to(torch.float32)
+            rgb = (I.to(torch.float64) * 255).round().to(torch.uint8).T.contiguous() if integral else None
+            ext = cP.contiguous() if light else (None if integral else I.contiguous())
+            lists.append((s.u, s.v, z, rgb) if ext is None else (s.u, s.v, z, rgb, ext))
+        resto = engine.acquire_restoration(height, width, len(lists), device, light=light, float_colour=not integral,
+                                           tag='lists')
+        resto.import_matches(None, lists)
+        self.restoration = resto
+        return resto
+
     def iter(self, batch_size: int = 1, device: str = 'cpu'):
-        data = self.data if self.restoration is None else self._materialise()
+        data = self.data if (self.data or self.restoration is None) else self._materialise()   # appended samples stay as given
         for i in range(0, len(data), batch_size):
             chunk = data[i:i + batch_size]
             yield (torch.hstack([s.u.to(device) for s in chunk]).long(),
@@ -261,7 +308,7 @@ class MatchesData:
                    torch.hstack([s.I.to(device) for s in chunk]))
 
     def __len__(self) -> int:
-        if self.restoration is not None:
+        if self.restoration is not None and not self.data:
             return self.restoration.n_obs()
         return sum(int(s.u.shape[0]) for s in self.data)
 
@@ -276,6 +323,8 @@ class MatchesFile:
     consumes the kept matches instead of re-matching (sucre.py:185).
     """
 
+    _groups = None   # view name -> match lists appended one view at a time (save_matches)
+
     def __init__(self, path: Path, colmap_model=None, overwrite: bool = False):
         self.path = Path(path)
         if overwrite:
@@ -285,6 +334,7 @@ class MatchesFile:
         self.restoration = None
         self.target_image = None
         self.image_list = None
+        self._groups = {}
 
     @property
     def _npz_path(self) -> Path:
@@ -309,16 +359,40 @@ class MatchesFile:
         return sorted([im for im, k in zip(self.image_list, keep) if k], key=lambda im: im.name)
 
     def save_matches(self, matches, d: Tensor):
-        raise NotImplementedError('matches are written by the HIP match kernel (Image.match_images), not one '
-                                  'view at a time from the host')
+        """Appends the matches of one view (loader.py:68-76): ``u1, v1, u2, v2`` as int16, the depths ``d`` of the
+        matched pixels of ``matches.image2``, colours to be filled by ``prepare_matches``.  The groups are kept in
+        memory (``save`` writes them); ``load_matches`` hands them to the engine."""
+        if self.restoration is not None:
+            raise RuntimeError(f'{self.path}: matches of this file already live in the engine (Image.match_images)')
+        if self._groups is None:
+            self._groups = {}
+        self._groups[matches.image2.name] = dict(u1=matches.u1.short().cpu(), v1=matches.v1.short().cpu(),
+                                                 u2=matches.u2.short().cpu(), v2=matches.v2.short().cpu(),
+                                                 d=d.detach().to(torch.float32).cpu(), I=None, image=matches.image2)
 
     def prepare_matches(self, num_workers: int = 0):
-        """Colours were gathered by the match kernel (I = rgb2[v2,u2], loader.py:87): nothing left to do."""
+        """Colours were gathered by the match kernel (I = rgb2[v2,u2], loader.py:87): nothing left to do -- except for
+        groups appended with ``save_matches``, whose colours are gathered here like the reference does."""
+        if self._groups and self.restoration is None:
+            for g in self._groups.values():
+                rgb = g['image'].get_rgb()
+                g['I'] = rgb[g['v2'].long(), g['u2'].long()].T.contiguous()
+            return
         self._need()
 
     def check_integrity(self):
         """Device-side counterpart of loader.py:89-101: every stored range must be finite and >= 0 and the
         per-view totals must add up to n_obs.  One launch checks all views; the verdicts come back in one read."""
+        if self._groups and self.restoration is None:   # host lists: the reference's own checks, loader.py:89-101
+            for name, g in self._groups.items():
+                for key in ('u1', 'v1', 'u2', 'v2', 'd', 'I'):
+                    arr = g[key]
+                    assert arr is not None and not torch.isnan(arr.float()).any(), f'In {self.path}, dataset /{name}/{key} contains NaN(s).'
+                    if key == 'd':
+                        assert bool((arr > 0).all()), f'In {self.path}, dataset /{name}/d contains null of negative depth(s).'
+                    else:
+                        assert bool((arr >= 0).all()), f'In {self.path}, dataset /{name}/{key} contains invalid value(s).'
+            return
         r = self._need()
         state = torch.cat([r.view_keep().to(torch.int64), r.view_counts().to(torch.int64),
                            r.check_store().to(torch.int64)]).cpu().numpy()
@@ -331,6 +405,13 @@ class MatchesFile:
             assert not verdict[k] & 4, f'In {self.path}, view {k} lost observations.'
 
     def load_matches(self, pin_memory: bool = False) -> MatchesData:
+        if self._groups and self.restoration is None:   # appended view by view: the reference's own loop, loader.py:103-118
+            md = MatchesData()
+            for name in sorted(self._groups):
+                g = self._groups[name]
+                assert g['I'] is not None, 'call prepare_matches() first'
+                md.append(u=g['u1'], v=g['v1'], cP=g['image'].unproject_depth(u=g['u2'], v=g['v2'], d=g['d']), I=g['I'])
+            return md
         return MatchesData(restoration=self._need(), image_list=self.image_list)
 
     def save(self) -> Path:
@@ -391,7 +472,9 @@ class MatchesFile:
         self.attach(resto, target_image=target_image, image_list=images)
 
     def __len__(self) -> int:
-        return self.restoration.n_obs() if self.restoration is not None else 0
+        if self.restoration is not None:
+            return self.restoration.n_obs()
+        return sum(int(g['u1'].shape[0]) for g in (self._groups or {}).values())
 
     def __repr__(self) -> str:
         return f'MatchesFile(path={self.path}, {len(self)} observations)'

@@ -163,14 +163,24 @@ class Image:
                 PIXEL_CACHE.touch(self)
                 return cached[1]
             PIXEL_CACHE.forget(self)
-            rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
-            if rgb is None:   # --image-scale: colours resized in float64 like the reference -> float32 observations
-                rgb = self.get_rgb()
-            mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
-            if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
-                depth = self.get_depth_map().to(dev).contiguous()
+            if type(self).get_rgb is not Image.get_rgb or type(self).get_depth_map is not Image.get_depth_map:
+                # a subclass supplies the pixels itself (the documented way to feed images that are not files): take
+                # them through the same accessors the reference calls (sfm.py:109-113)
+                rgb = self.get_rgb().to(torch.float32)
+                k255 = rgb.to(torch.float64) * 255
+                if bool(((k255 - k255.round()).abs() < 1e-3).all()):
+                    rgb = k255.round().to(torch.uint8)          # images as stored: exactly k/255
+                depth = self.get_depth_map().to(torch.float32).to(dev).contiguous()
+                mm = None
             else:
-                depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
+                rgb = loader.load_rgb_u8(self.rgb_path, width=self.camera.width, height=self.camera.height)
+                if rgb is None:   # --image-scale: colours resized in float64 like the reference -> float32 observations
+                    rgb = self.get_rgb()
+                mm = loader.load_depth_raw(self.depth_map_path, width=self.camera.width, height=self.camera.height)
+                if mm is None or dev.type != 'cuda':   # not a 16-bit file: host conversion as the reference does it
+                    depth = self.get_depth_map().to(dev).contiguous()
+                else:
+                    depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
             view = engine.DeviceView(depth=depth, rgb=rgb.to(dev).contiguous(),
                                      K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
             if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):

@@ -76,7 +76,7 @@ class SUCRe(torch.nn.Module):
         """Closed-form J from the current water parameters (sucre.py:66-77), computed by the engine."""
         if not (self.use_closed_form or force_update):
             return
-        resto = _restoration_of(matches_data)
+        resto = _restoration_of(matches_data, self)
         resto.params().copy_(self.water_vector().to(resto.device))
         resto.update_J()
         self.J = resto.J().to(self.B.device)
@@ -164,11 +164,19 @@ class SUCRe(torch.nn.Module):
             self.plot_l().save(Path(save_dir) / f'{stem}_vignetting{tag}.png', compress_level=level)
 
 
-def _restoration_of(matches_data: loader.MatchesData):
+def _restoration_of(matches_data: loader.MatchesData, sucre: 'SUCRe | None' = None):
+    """The engine workspace behind ``matches_data``: the one ``Image.match_images`` filled, or -- for a container built
+    with ``append`` like the reference's ``load_matches`` does (loader.py:103-118) -- one the samples are imported
+    into on first use.  There is no CPU path for the fit."""
     resto = getattr(matches_data, 'restoration', None)
+    if resto is None and sucre is not None and getattr(matches_data, 'data', None):
+        dev = sucre.B.device
+        if dev.type != 'cuda':
+            raise RuntimeError('the fit runs on the GPU engine: move the model to a cuda device (SUCRe(...).to("cuda"))')
+        resto = matches_data.to_engine(sucre.image.camera.height, sucre.image.camera.width, dev, light=sucre.light_model)
     if resto is None:
-        raise RuntimeError('this MatchesData is not backed by the HIP engine (build it with Image.match_images + '
-                           'MatchesFile.load_matches); there is no CPU fallback for the fit')
+        raise RuntimeError('this MatchesData holds no observations the engine can use (build it with Image.match_images + '
+                           'MatchesFile.load_matches, or append samples to it); there is no CPU fallback for the fit')
     return resto
 
 
@@ -232,7 +240,7 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
 
 
 def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData):
-    resto = _restoration_of(matches_data)
+    resto = _restoration_of(matches_data, sucre)
     if sucre.light_model and not resto.light:
         raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
                            'needs were not kept (call Image.match_images(..., light_model=True))')

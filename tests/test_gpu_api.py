@@ -13,6 +13,13 @@ from sucre_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+def _same_points(a, b):
+    """Camera points K^-1 (d [u+.5, v+.5, 1]) formed by a torch matmul: which FMA order the (3,3)@(3,n) product takes
+    depends on the BLAS path of the machine (host CPU features, GPU library), so they agree to a rounding, not to
+    the bit, across machines (the engine's own ranges are formed in a fixed order and are compared bit for bit)."""
+    return a.shape == b.shape and np.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
 def write_scene(scene, root: Path):
     """Synthetic scene -> image files + COLMAP text model, as a user of the reference would have them."""
     from PIL import Image as PILImage
@@ -117,8 +124,7 @@ def test_match_two_way_and_matches_data_compat(disk_scene):
     assert len(got) == len(samples)
     for (u, v, cP, I), (su, sv, scP, sI) in zip(got, samples):
         assert np.array_equal(u.numpy(), su) and np.array_equal(v.numpy(), sv) and np.array_equal(I.numpy(), sI)
-        z = np.sqrt((scP[0] * scP[0] + scP[1] * scP[1]) + scP[2] * scP[2], dtype=np.float32)
-        assert np.array_equal(cP.norm(dim=0).numpy(), z)
+        assert _same_points(cP.numpy(), scP)     # the camera points of loader.py:113 themselves
 
 
 def test_shared_water_split_path_vs_oracle():
@@ -389,3 +395,78 @@ def test_overlap_cull_sizes_the_workspace_and_changes_nothing(tmp_path, monkeypa
     assert n0 == 120 and n1 < 40 and dec0 == 120 and dec1 == n1          # workspace and decoding follow the survivors
     assert names0 == names1 and obs0 == obs1 and len(names1) >= 9
     assert np.array_equal(J0, J1, equal_nan=True) and np.array_equal(p0, p1)
+
+
+class SynthImage:
+    """sfm.Image whose pixels come from a synthetic view instead of files (what tests/golden/ref_harness.py does to
+    the reference's class)."""
+
+    def __new__(cls, idx, view, K, W, H):
+        from sucre_amd import sfm
+
+        class _Image(sfm.Image):
+            def get_rgb(self):
+                return view.rgb_f32()
+
+            def get_depth_map(self):
+                return view.depth_f32()
+        return _Image(idx, Path(view.name), Path('depth_' + view.name), sfm.Pose(view.R, view.t), sfm.Camera(1, W, H, K))
+
+
+def test_reference_call_sequence_with_hand_built_matches_data(golden, tmp_path):
+    """restore_image's own statements (sucre.py:179-215) with the matches appended one view at a time the way the
+    reference's match_images does (sfm.py:127-138: match_two_way, min_cover rule, save_matches), then
+    prepare / check / load_matches -> a list-backed MatchesData (loader.py:103-118) -> SUCRe -> adam.  Must land on
+    the reference's own result for that sequence (golden J_param_5) and on its update_J (golden J_closed_init)."""
+    from sucre_amd import loader, sucre
+    sc = golden.scene
+    images = [SynthImage(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)]
+    target = images[sc.target]
+    matches_file = loader.MatchesFile(tmp_path / 'm.h5', colmap_model=None)
+    u1, v1, wP1 = target.unproject_depth_map(target.get_depth_map().cuda(), to_world=True)
+    for other in images:
+        other_depth = other.get_depth_map().cuda()
+        u2, v2, wP2 = other.unproject_depth_map(other_depth, to_world=True)
+        m = target.match_two_way(other, u1=u1, v1=v1, wP1=wP1, u2=u2, v2=v2, wP2=wP2)
+        if len(m) / (sc.width * sc.height) > 1e-6:
+            matches_file.save_matches(matches=m, d=other_depth[m.v2, m.u2])
+    matches_file.prepare_matches()
+    matches_file.check_integrity()
+    md = matches_file.load_matches()
+    assert md.restoration is None and len(md) == int(golden['n_obs']) == len(matches_file)
+    # the samples are the reference's: same order (name order), same camera points and colours
+    _, samples = helpers.oracle_scene_samples(sc)
+    assert len(md.data) == len(samples)
+    for s, (su, sv, scP, sI) in zip(md.data, samples):
+        assert np.array_equal(s.u.numpy(), su) and np.array_equal(s.v.numpy(), sv)
+        assert _same_points(s.cP.numpy(), scP) and np.array_equal(s.I.numpy(), sI)
+    model = sucre.SUCRe(image=target).to('cuda')
+    sucre.adam(sucre=model, matches_data=md, lr=0.05, num_iter=5, batch_size=5, device='cuda')
+    J = model.J.detach().cpu().numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(golden['J_param_5']))
+    assert helpers.rms_per_channel(J, golden['J_param_5']).max() < 1e-6
+    got = model.water_vector().cpu().numpy()
+    assert np.abs(got - golden['trace_param'][4, 1:]).max() < 1e-6
+    assert md.restoration is not None                       # imported once, reused
+    closed = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
+    closed.update_J(md)
+    assert helpers.rms_per_channel(closed.J.cpu().numpy(), golden['J_closed_init']).max() < 1e-6
+    # and the reference-format iterator gives the true camera points back
+    for (u, v, cP, I), (su, sv, scP, sI) in zip(md.iter(batch_size=1, device='cpu'), samples):
+        assert _same_points(cP.numpy(), scP) and np.array_equal(I.numpy(), sI)
+
+
+def test_engine_backed_matches_data_iterates_true_camera_points(golden):
+    """MatchesData.iter on the HBM store yields cP = unproject_depth(u2, v2, d) (loader.py:113), not a stand-in, with
+    and without the light model's extension planes."""
+    from sucre_amd import loader
+    sc = golden.scene
+    images = [SynthImage(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)]
+    _, samples = helpers.oracle_scene_samples(sc)
+    for light in (False, True):
+        mf = loader.MatchesFile(Path('/tmp/unused.h5'), colmap_model=None)
+        images[sc.target].match_images(images, mf, device='cuda', light_model=light)
+        got = list(mf.load_matches().iter(batch_size=1, device='cpu'))
+        assert len(got) == len(samples)
+        for (u, v, cP, I), (su, sv, scP, sI) in zip(got, samples):
+            assert np.array_equal(u.numpy(), su) and _same_points(cP.numpy(), scP) and np.array_equal(I.numpy(), sI)
