@@ -186,6 +186,17 @@ int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void
 int sucre_export_J(const void *ws, int H, int W, int n_views, float *J_dev, void *stream);
 
 /*
+ * Output stage, SUCRe.plot_J (sucre.py:84-95): exact order statistics of the restored image without moving it.  For
+ * every channel of J_dev ((H,W,3) float32) the values at the given 0-based ranks among the VALID pixels (no NaN in any
+ * channel, sucre.py:87), ascending: out_dev[c * n_ranks + r].  `ranks` is a host array of n_ranks <= 8 entries, each
+ * below the number of valid pixels; scratch_dev: sucre_select_scratch_bytes() bytes, 8-byte aligned.  numpy's percentile
+ * is a linear interpolation between two such values; the caller does that part (in numpy's arithmetic).
+ */
+size_t sucre_select_scratch_bytes(void);
+int sucre_select_ranks(const float *J_dev, int H, int W, int n_ranks, const uint64_t *ranks, float *out_dev, void *scratch_dev,
+                       void *stream);
+
+/*
  * MatchesFile.check_integrity (loader.py:89-101) over the whole store in one launch: verdict_dev[k] (uint32, one per
  * view) gets bit 0 if a stored range of view k is not finite, bit 1 if one is negative, bit 2 if the number of
  * stored ranges > 0 differs from the view's match count; 0 = sound.  scratch_dev: n_views uint64 of scratch.

@@ -250,6 +250,18 @@ int sucre_check_store(const void *ws, int H, int W, int n_views, uint32_t *verdi
                                         static_cast<hipStream_t>(stream)), "sucre_check_store");
 }
 
+size_t sucre_select_scratch_bytes(void) { return select_scratch_bytes(); }
+
+int sucre_select_ranks(const float *J_dev, int H, int W, int n_ranks, const uint64_t *ranks, float *out_dev, void *scratch_dev,
+                       void *stream) {
+    if (H <= 0 || W <= 0) return fail(SUCRE_ERR_ARG, "invalid image size %dx%d", W, H);
+    if (!J_dev || !ranks || !out_dev || !scratch_dev) return fail(SUCRE_ERR_ARG, "J_dev / ranks / out_dev / scratch_dev is NULL");
+    if (n_ranks < 1 || n_ranks > 8) return fail(SUCRE_ERR_RANGE, "n_ranks=%d outside [1,8]", n_ranks);
+    if (!aligned(scratch_dev, 8) || !aligned(J_dev, 4) || !aligned(out_dev, 4)) return fail(SUCRE_ERR_ARG, "misaligned pointer");
+    return check_hip(launch_select_ranks(J_dev, H, W, n_ranks, ranks, out_dev, scratch_dev, static_cast<hipStream_t>(stream)),
+                     "sucre_select_ranks");
+}
+
 /* ---- artificial-light model (--light-model) ------------------------------------------------------------------ */
 
 size_t sucre_light_workspace_bytes(int H, int W, int n_views) {

@@ -52,6 +52,11 @@ hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s);
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
 hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
 
+// output stage (plot.hip)
+size_t select_scratch_bytes();
+hipError_t launch_select_ranks(const float *J, int H, int W, int n_ranks, const uint64_t *ranks, float *out, void *scratch,
+                               hipStream_t s);
+
 // artificial-light model (light.hip)
 size_t light_workspace_bytes(const Layout &L);
 int64_t light_params_offset(const Layout &L);

@@ -328,6 +328,22 @@ class Restoration:
         return out
 
 
+def select_ranks(J: torch.Tensor, ranks: list[int]) -> torch.Tensor:
+    """(3, len(ranks)) float32: per channel of the (H,W,3) float32 device image ``J``, the values at the given 0-based
+    ranks among the valid pixels (no NaN in any channel), ascending -- exact order statistics by radix select on the
+    device (csrc/plot.hip); the image does not move."""
+    lib = _lib.load()
+    assert J.is_cuda and J.dtype == torch.float32 and J.is_contiguous() and J.dim() == 3 and J.shape[2] == 3
+    assert 1 <= len(ranks) <= 8
+    out = torch.empty((3, len(ranks)), dtype=torch.float32, device=J.device)
+    scratch = torch.empty(lib.sucre_select_scratch_bytes(), dtype=torch.uint8, device=J.device)
+    arr = (C.c_uint64 * len(ranks))(*[int(r) for r in ranks])
+    with torch.cuda.device(J.device):
+        _lib.check(lib.sucre_select_ranks(C.c_void_p(J.data_ptr()), J.shape[0], J.shape[1], len(ranks), arr,
+                                          C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), _stream_ptr()))
+    return out
+
+
 def device_views_from_scene(scene, device='cuda') -> list[DeviceView]:
     """Uploads a synthetic scene (sucre_amd.synth) the way the loaders would: float32 depth, uint8 colour."""
     out = []

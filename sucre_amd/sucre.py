@@ -110,16 +110,21 @@ class SUCRe(torch.nn.Module):
         return PILImage.fromarray(np.uint8(J * 255))
 
     def _plot_J_device(self) -> Tensor:
-        """The same stretch with J left on the GPU (uint8 (H,W,3) out).  Only the two percentiles are taken on the
-        host, by numpy itself on the valid pixels of one channel at a time, so they are the very numbers the
-        reference computes; clip, min, max, the two float32 divisions' worth of arithmetic and the uint8 cast are
-        IEEE-exact elementwise operations and give the same bits on either side (tested against the host path)."""
-        J = self.J.detach()
+        """The same stretch with J left on the GPU (uint8 (H,W,3) out).  The two percentiles of every channel are
+        numpy's linear interpolation between two order statistics of the valid pixels: the engine finds those four
+        values per channel by radix select on the device (``sucre_select_ranks``), the ranks and the interpolation
+        are numpy's own float32 arithmetic (``percentile_plan`` / ``percentile_lerp``), so the percentiles are the
+        very numbers ``np.percentile`` returns for the whole array; clip, min, max, the divisions and the uint8 cast
+        are IEEE-exact elementwise operations and give the same bits on either side."""
+        from . import engine
+        J = self.J.detach().contiguous()
         ok = ~torch.isnan(J).any(dim=2)
+        n = int(ok.sum())
+        plan = [percentile_plan(n, q) for q in (1, 99)]
+        stats = engine.select_ranks(J, [plan[0][0], plan[0][1], plan[1][0], plan[1][1]]).cpu().numpy()   # (3, 4)
+        lo = np.array([percentile_lerp(stats[c, 0], stats[c, 1], plan[0][2]) for c in range(3)], np.float32)
+        hi = np.array([percentile_lerp(stats[c, 2], stats[c, 3], plan[1][2]) for c in range(3)], np.float32)
         vals = J[ok]                                              # (n, 3)
-        host = vals.T.contiguous().cpu().numpy()                  # (3, n): one contiguous row per channel
-        lo = np.stack([np.percentile(host[c], 1) for c in range(3)]).astype(np.float32)
-        hi = np.stack([np.percentile(host[c], 99) for c in range(3)]).astype(np.float32)
         vals = torch.clamp(vals, torch.from_numpy(lo).to(J.device), torch.from_numpy(hi).to(J.device))
         vals = vals - vals.amin(dim=0)
         vals = vals / vals.amax(dim=0)
@@ -162,6 +167,33 @@ class SUCRe(torch.nn.Module):
         self.plot_reconstruction().save(Path(save_dir) / f'{stem}_reconstruction{tag}.png', compress_level=level)
         if self.light_model:
             self.plot_l().save(Path(save_dir) / f'{stem}_vignetting{tag}.png', compress_level=level)
+
+
+def percentile_plan(n: int, q: float) -> tuple[int, int, np.floating]:
+    """(rank below, rank above, weight) of ``np.percentile(a, q)`` (method 'linear') for a float32 array of ``n``
+    values, in numpy's own arithmetic: the quantile ``q / 100`` and the virtual index ``(n - 1) q'`` are formed in
+    the array's dtype, float32 (numpy/lib/_function_base_impl.py: percentile, _QuantileMethods['linear'],
+    _get_indexes, _get_gamma)."""
+    quant = np.asanyarray(np.true_divide(q, np.float32(100)))
+    virtual = np.asanyarray((n - 1) * quant)
+    below = np.floor(virtual)
+    above = below + 1
+    if virtual >= n - 1:
+        below = above = np.float32(n - 1)
+    if virtual < 0:
+        below = above = np.float32(0)
+    gamma = np.asanyarray(virtual - below, dtype=virtual.dtype)
+    return int(below), int(above), gamma[()]
+
+
+def percentile_lerp(a, b, t):
+    """numpy's ``_lerp``: ``a + (b - a) t``, formed from the upper end when ``t >= 0.5``."""
+    a, b = np.float32(a), np.float32(b)
+    diff = np.subtract(b, a)
+    out = np.add(a, diff * t)
+    if t >= 0.5:
+        out = np.subtract(b, diff * (1 - t))
+    return out
 
 
 def _restoration_of(matches_data: loader.MatchesData, sucre: 'SUCRe | None' = None):

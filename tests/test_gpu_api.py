@@ -470,3 +470,35 @@ def test_engine_backed_matches_data_iterates_true_camera_points(golden):
         assert len(got) == len(samples)
         for (u, v, cP, I), (su, sv, scP, sI) in zip(got, samples):
             assert np.array_equal(u.numpy(), su) and _same_points(cP.numpy(), scP) and np.array_equal(I.numpy(), sI)
+
+
+def test_select_ranks_is_an_exact_order_statistic():
+    """csrc/plot.hip: radix select on the float bit pattern against a full sort, with NaN pixels, negative values,
+    zeros of both signs, duplicates and the extreme ranks."""
+    from sucre_amd import engine
+    g = torch.Generator().manual_seed(5)
+    for H, W in ((7, 5), (64, 48), (333, 517)):
+        J = torch.randn((H, W, 3), generator=g) * torch.tensor([1.0, 1e-3, 40.0])
+        J[torch.rand((H, W), generator=g) < 0.1] = float('nan')            # invalid pixels: all channels
+        J[0, 0, 1] = float('nan')                                          # ... or one channel only (sucre.py:87)
+        J[1, 1] = torch.tensor([0.0, -0.0, 0.0]); J[2, 2] = J[2, 1]       # signed zeros, duplicates
+        ok = ~torch.isnan(J).any(dim=2)
+        n = int(ok.sum())
+        ranks = sorted({0, 1, n // 100, n // 2, n - 2, n - 1} & set(range(n)))
+        got = engine.select_ranks(J.cuda().contiguous(), ranks).cpu().numpy()
+        ref = np.sort(J[ok].numpy(), axis=0)[ranks].T
+        assert np.array_equal(got, ref)
+
+
+def test_plot_J_on_the_device_is_the_reference_picture(golden):
+    """SUCRe.plot_J with J resident on the GPU (percentiles by device-side select, nothing but 12 floats comes back)
+    against the picture the reference itself made from the same J (golden plot_J_200), not against our host path."""
+    from sucre_amd import sucre
+    sc = golden.scene
+    image = SynthImage(1, sc.views[sc.target], sc.K, sc.width, sc.height)
+    model = sucre.SUCRe(image=image).to('cuda')
+    with torch.no_grad():
+        model.J.copy_(torch.tensor(golden['J_param_200']))
+    assert model.J.is_cuda
+    assert np.array_equal(np.asarray(model.plot_J()), golden['plot_J_200'])
+    assert np.array_equal(np.asarray(model.cpu().plot_J()), golden['plot_J_200'])    # and the host path

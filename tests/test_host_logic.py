@@ -380,3 +380,22 @@ def test_match_one_way_mirrors_the_reference_semantics():
     ref = (px[0] > -1) & (px[0] < 64) & (px[1] > -1) & (px[1] < 48)      # trunc(x) in [0, W) <=> -1 < x < W
     assert len(m) == int(ref.sum()) and len(m) > 0
     assert torch.equal(m.u1, u1[ref]) and torch.equal(m.v2, px[1][ref].long()) and int(m.u2.min()) >= 0
+
+
+def test_percentile_plan_and_lerp_are_numpys_percentile():
+    """plot_J's percentiles on the device = two exact order statistics (GPU) + numpy's interpolation restated on the
+    host: ranks, weight and lerp must reproduce np.percentile of a float32 array bit for bit (and its dtype)."""
+    from sucre_amd.sucre import percentile_lerp, percentile_plan
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        n = int(rng.integers(1, 5000)) if trial < 110 else int(rng.integers(1_000_000, 2_500_000))
+        a = (rng.random(n) * float(rng.choice([1, 1e-3, 50])) - 0.2).astype(np.float32)
+        s = np.sort(a)
+        for q in (1, 99, 50, 0, 100):
+            lo, hi, g = percentile_plan(n, q)
+            got, ref = percentile_lerp(s[lo], s[hi], g), np.percentile(a, q)
+            assert got == ref and got.dtype == ref.dtype == np.float32, (n, q, got, ref)
+    b = np.stack([a, a[::-1], a * np.float32(0.5)], 1)          # the reference's call shape: (n, 3), axis=0
+    lo, hi, g = percentile_plan(len(a), 99)
+    got = np.array([percentile_lerp(np.sort(b[:, c])[lo], np.sort(b[:, c])[hi], g) for c in range(3)])
+    assert np.array_equal(got, np.percentile(b, 99, axis=0))
