@@ -184,11 +184,8 @@ def main():
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        group = engine.HipWaterGroup([engine.HipWaterBackend(r, use_closed_form=args.use_closed_form) for r in group_restos])
+        group = engine.HipWaterGroup(group_restos, use_closed_form=args.use_closed_form)
         sdist.fit_shared_water(group, T)
-        if args.use_closed_form:
-            for r in group_restos:
-                r.update_J()
         if record:
             e1.record()
             fit_events.append((e0, e1))
@@ -210,10 +207,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()   # torch's current stream == the stream handed to the C ABI
         if args.shared_water:
-            be = engine.HipWaterBackend(resto, use_closed_form=args.use_closed_form)
-            sdist.fit_shared_water(be, T)
-            if args.use_closed_form:
-                resto.update_J()
+            sdist.fit_shared_water(engine.HipWaterGroup([resto], use_closed_form=args.use_closed_form), T)
         else:
             resto.fit(T, use_closed_form=args.use_closed_form, record_trace=True)
         if record:
@@ -278,7 +272,7 @@ def main():
                 restos[0].fit_init(tgt)
                 f0.record()
                 if args.shared_water:
-                    sdist.fit_shared_water(engine.HipWaterBackend(restos[0], use_closed_form=args.use_closed_form), T)
+                    sdist.fit_shared_water(engine.HipWaterGroup([restos[0]], use_closed_form=args.use_closed_form), T)
                 else:
                     restos[0].fit(T, use_closed_form=args.use_closed_form, record_trace=True)
                 f1.record()

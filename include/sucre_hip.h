@@ -178,6 +178,31 @@ int sucre_fit_step(void *ws, int H, int W, int n_views, int step, double lr, dou
 /* Overrides the observation count used in the 1/(3 n_obs) gradient scale (sum over ranks). */
 int sucre_set_n_obs_total(void *ws, int H, int W, int n_views, uint64_t n_obs_total, void *stream);
 
+/*
+ * Shared water parameters over SEVERAL images (all the images of one rank; BASELINE config 4): one launch and one
+ * collective per iteration.  `group_dev`: sucre_group_bytes(n_images) bytes of device memory, 256-byte aligned, set
+ * up once by sucre_group_init from the images' workspaces (each matched, finalised and fit_init-ed; `images` is a host
+ * array) and the nine start parameters.  sucre_group_iter(step), step = 1, 2, ...: first takes the Adam step on B,
+ * beta, gamma that the sums left by the previous call -- all-reduced over the ranks by the host in between -- call
+ * for (and logs it in row step-2 of trace_dev, T x 10 float64, nullable), then runs the gradient pass of iteration
+ * `step` over every image (J steps stay local, sucre.py:142-148) and leaves this rank's ten float64 sums at
+ * sucre_group_sums_offset() inside the buffer.  sucre_group_finish(step) takes the last pending step and copies the
+ * final parameters into every image's workspace (SUCRE_WS_PARAMS).  n_obs_total: observations over all images of all
+ * ranks, the n_obs of the 1/(3 n_obs) scale.
+ */
+typedef struct sucre_group_image {
+    void *ws;              /* the image's workspace */
+    int32_t H, W, n_views; /* its geometry */
+    int32_t reserved;
+} sucre_group_image_t;
+size_t sucre_group_bytes(int n_images);
+int64_t sucre_group_sums_offset(void);
+int sucre_group_init(void *group_dev, int n_images, const sucre_group_image_t *images, const float *params0, void *stream);
+int sucre_group_iter(void *group_dev, int n_images, int step, double lr, double beta1, double beta2, double eps, unsigned flags,
+                     uint64_t n_obs_total, double *trace_dev, void *stream);
+int sucre_group_finish(void *group_dev, int n_images, int step, double lr, double beta1, double beta2, double eps,
+                       uint64_t n_obs_total, double *trace_dev, void *stream);
+
 /* SUCRe.update_J(force_update=True) (sucre.py:66-77): closed-form J from the current parameters. */
 int sucre_update_J(void *ws, int H, int W, int n_views, void *stream);
 int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream);

@@ -32,6 +32,11 @@ class SucreView(C.Structure):
 
 assert C.sizeof(SucreView) == 192
 
+
+class GroupImage(C.Structure):
+    """sucre_group_image_t"""
+    _fields_ = [('ws', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('n_views', C.c_int32), ('reserved', C.c_int32)]
+
 # name -> (restype, argtypes); mirrors include/sucre_hip.h one to one (tests/test_abi.py checks both ways)
 _i, _vp, _d, _u64 = C.c_int, C.c_void_p, C.c_double, C.c_uint64
 SIGNATURES = {
@@ -49,6 +54,11 @@ SIGNATURES = {
     'sucre_fit_grad': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, C.c_uint, _vp]),
     'sucre_fit_step': (_i, [_vp, _i, _i, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     'sucre_set_n_obs_total': (_i, [_vp, _i, _i, _i, _u64, _vp]),
+    'sucre_group_bytes': (C.c_size_t, [_i]),
+    'sucre_group_sums_offset': (C.c_int64, []),
+    'sucre_group_init': (_i, [_vp, _i, C.POINTER(GroupImage), C.POINTER(C.c_float), _vp]),
+    'sucre_group_iter': (_i, [_vp, _i, _i, _d, _d, _d, _d, C.c_uint, _u64, _vp, _vp]),
+    'sucre_group_finish': (_i, [_vp, _i, _i, _d, _d, _d, _d, _u64, _vp, _vp]),
     'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
     'sucre_update_J_fmt': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),

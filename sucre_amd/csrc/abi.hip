@@ -250,6 +250,49 @@ int sucre_check_store(const void *ws, int H, int W, int n_views, uint32_t *verdi
                                         static_cast<hipStream_t>(stream)), "sucre_check_store");
 }
 
+/* ---- shared water parameters over the images of a rank: one launch + one collective per iteration -------------- */
+
+size_t sucre_group_bytes(int n_images) { return n_images > 0 ? group_bytes(n_images) : 0; }
+
+int64_t sucre_group_sums_offset(void) { return group_sums_offset(); }
+
+int sucre_group_init(void *group_dev, int n_images, const sucre_group_image_t *images, const float *params0, void *stream) {
+    if (!group_dev || !aligned(group_dev, 256)) return fail(SUCRE_ERR_ARG, "group buffer is NULL or not 256-byte aligned");
+    if (n_images < 1 || !images || !params0) return fail(SUCRE_ERR_ARG, "need at least one image and params0");
+    auto s = static_cast<hipStream_t>(stream);
+    if (int rc = check_hip(launch_group_init(group_dev, params0, s), "sucre_group_init")) return rc;
+    for (int i = 0; i < n_images; ++i) {
+        Layout L;
+        if (int rc = check_ws(images[i].ws, images[i].H, images[i].W, images[i].n_views, &L)) return rc;
+        if (int rc = check_hip(launch_group_set_image(group_dev, i, L, static_cast<uint8_t *>(images[i].ws), s), "sucre_group_init")) return rc;
+    }
+    return SUCRE_OK;
+}
+
+int sucre_group_iter(void *group_dev, int n_images, int step, double lr, double beta1, double beta2, double eps, unsigned flags,
+                     uint64_t n_obs_total, double *trace_dev, void *stream) {
+    if (!group_dev || n_images < 1) return fail(SUCRE_ERR_ARG, "group buffer is NULL / no image");
+    if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (n_obs_total == 0) return fail(SUCRE_ERR_RANGE, "n_obs_total must be > 0");
+    if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
+    const AdamCoef co_prev = adam_coef(step > 1 ? step - 1 : 1, lr, beta1, beta2, eps);
+    double *row = (trace_dev && step > 1) ? trace_dev + (size_t)(step - 2) * 10 : nullptr;
+    return check_hip(launch_group_iter(group_dev, n_images, step, co_prev, adam_coef(step, lr, beta1, beta2, eps), flags, n_obs_total,
+                                       row, static_cast<hipStream_t>(stream)), "sucre_group_iter");
+}
+
+int sucre_group_finish(void *group_dev, int n_images, int step, double lr, double beta1, double beta2, double eps,
+                       uint64_t n_obs_total, double *trace_dev, void *stream) {
+    if (!group_dev || n_images < 1) return fail(SUCRE_ERR_ARG, "group buffer is NULL / no image");
+    if (step < 0) return fail(SUCRE_ERR_RANGE, "step=%d must be >= 0", step);
+    if (step >= 1) if (int rc = check_adam(step, lr, beta1, beta2, eps)) return rc;
+    if (n_obs_total == 0) return fail(SUCRE_ERR_RANGE, "n_obs_total must be > 0");
+    double *row = (trace_dev && step >= 1) ? trace_dev + (size_t)(step - 1) * 10 : nullptr;
+    return check_hip(launch_group_finish(group_dev, n_images, step, adam_coef(step >= 1 ? step : 1, lr, beta1, beta2, eps), n_obs_total,
+                                         row, static_cast<hipStream_t>(stream)), "sucre_group_finish");
+}
+
 size_t sucre_select_scratch_bytes(void) { return select_scratch_bytes(); }
 
 int sucre_select_ranks(const float *J_dev, int H, int W, int n_ranks, const uint64_t *ranks, float *out_dev, void *scratch_dev,

@@ -22,6 +22,8 @@
 // With L = sum r^2 / (3 n_obs) and s = (1/3)/n_obs (sucre.py:145):
 //   dL/dJ[p]  = -2 s sum_k r a          dL/dB     = -2 s sum r (1 - g)
 //   dL/dbeta  = +2 s sum_p J sum_k r a z    dL/dgamma = -2 s B sum r g z        (per channel)
+#include <cstddef>
+
 #include "fit_math.h"
 
 namespace sucre {
@@ -343,10 +345,31 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
 
 __device__ __forceinline__ uint32_t item_kind(uint32_t bits) { return (bits >> 16) & 7u; }
 
-// Issues item `it` into `slot` (LDS byte address).
-__device__ __forceinline__ void issue_item(const PlanItem &it, const uint8_t *__restrict__ ws, uint32_t slot, uint32_t lane) {
-    const uint8_t *src = ws + ((uint64_t)it.src64 << 6);
-    dma_item(src, slot, lane, it.bits & 127u, (it.bits >> 8) & 127u);
+// Plan items are read through the constant address space: for it the compiler emits scalar loads (s_load) whenever the
+// address is wave-uniform and tracks their completion itself.  A vector load here would count in vmcnt and be waited
+// for with vmcnt(0), draining the ring.  (A hand-issued s_load in inline asm with the wait in a second statement is
+// NOT safe: the compiler may copy the destination registers between the two -- e.g. at the unrolled loop's back
+// edge -- before the data has landed; seen as strips ended twice or never once two processes shared the GPU.)
+typedef uint32_t ItemRegs __attribute__((ext_vector_type(4)));   // src64, bits, strip, pad
+typedef const __attribute__((address_space(4))) ItemRegs *ConstItems;
+
+// A wave-uniform pointer that the compiler may hold in vector registers -> scalar registers.
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
+}
+
+
+__device__ __forceinline__ ConstItems const_items(const PlanItem *p) {
+    return (ConstItems)(reinterpret_cast<uintptr_t>(uniform_ptr(p)));
+}
+
+// Issues the item described by `it` into `slot` (LDS byte address).
+__device__ __forceinline__ void issue_item(const ItemRegs &it, const uint8_t *__restrict__ ws, uint32_t slot, uint32_t lane) {
+    const uint8_t *src = ws + ((uint64_t)it.x << 6);
+    dma_item(src, slot, lane, it.y & 127u, (it.y >> 8) & 127u);
 }
 
 // A full chunk in a ring slot -> this lane's four ranges and three colour dwords.
@@ -387,9 +410,10 @@ __device__ __forceinline__ void stream_items(FitLds &lds, const PlanItem *__rest
     if (n == 0) return;
     const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
     // descriptors of the items in flight: d[S] describes the item that lives in ring slot S
-    PlanItem d[kRing];
+    const ConstItems items = const_items(plan);
+    ItemRegs d[kRing];
 #pragma unroll
-    for (int S = 0; S < kRing; ++S) d[S] = plan[(uint32_t)S < n ? S : 0];
+    for (int S = 0; S < kRing; ++S) d[S] = items[(uint32_t)S < n ? S : 0];
 #pragma unroll
     for (int S = 0; S < kAhead; ++S)
         if ((uint32_t)S < n) issue_item(d[S], ws, ring0 + (uint32_t)S * kSlot, lane);
@@ -403,9 +427,9 @@ __device__ __forceinline__ void stream_items(FitLds &lds, const PlanItem *__rest
         for (int S = 0; S < kRing; ++S) {
             if (more) {
                 const int Sin = (S + kAhead) % kRing;
-                if (i + (uint32_t)kAhead < n) issue_item(d[Sin], ws, ring0 + (uint32_t)Sin * kSlot, lane);
-                const uint32_t bits = d[S].bits, strip = d[S].strip;
-                if (i + (uint32_t)kRing < n) d[S] = plan[i + (uint32_t)kRing];
+                if (i + (uint32_t)kAhead < n) issue_item(d[Sin], ws, ring0 + (uint32_t)Sin * kSlot, lane);   // loaded one step ago
+                const uint32_t bits = d[S].y, strip = d[S].z;
+                if (i + (uint32_t)kRing < n) d[S] = items[i + (uint32_t)kRing];
                 const uint32_t vm = (bits >> 24) & 31u;
                 if (vm == 2u * kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead) : "memory");  // the steady state
                 else wait_vm(vm);
@@ -458,29 +482,32 @@ __device__ __forceinline__ void reduce_total(const double *gpart, int n_groups, 
             x += __hip_atomic_load(gpart + (size_t)q * n_groups + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = wave_sum_fixed(x);
         if (lane == 0) {
-            sums[q] = x;  // global copy: read by the host all-reduce in shared-water runs
+            __hip_atomic_store(sums + q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global copy: read by the host all-reduce
             stot[q] = x;  // LDS copy: read by water_step of the same workgroup
         }
     }
     __syncthreads();
 }
 
-// Arrival on a counter (relaxed agent-scope fetch_add by one lane behind the wave's drained stores); returns
-// true in the workgroup that arrived last, which has then done its agent acquire and re-armed the counter.
+// Arrival on a counter: EVERY wave of the workgroup drains its own hand-off stores (vmcnt is per wave; reduce_group's
+// results are stored by all four waves), the workgroup meets, and only then one lane signals with a relaxed
+// agent-scope fetch_add.  Returns true in the workgroup that arrived last, which has then done its agent acquire and
+// re-armed the counter.  (Until round 2 only the signalling wave drained: the other waves' group sums could still be
+// in flight when the top-level last arriver read them -- seen as run-to-run differences of the beta gradient, the
+// last values each wave stores, once two processes shared the GPU.)
 __device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned expected, int *flag) {
     const int t = threadIdx.x;
-    if (t < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (t == 0) {
-            const unsigned got = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (got == expected - 1u) ? 1 : 0;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-            }
-            *flag = last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        const unsigned got = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (got == expected - 1u) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
         }
+        *flag = last;
     }
     __syncthreads();
     return *flag != 0;
@@ -519,7 +546,7 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
 
 // End of a fit launch: the lanes' ten sums -> one float32 partial per workgroup -> (fused form) two-level
 // last-arriver reduction in float64 and the Adam step on B, beta, gamma by the workgroup that arrives last.
-template <bool kFused>
+template <bool kFused, bool kStep = kFused>
 __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums], float *partials, const AdamCoef &co,
                                               unsigned *ticket, double *gpart, int n_groups, double *sums,
                                               float *pstate, const uint64_t *__restrict__ n_obs_total,
@@ -559,45 +586,21 @@ __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums],
             if (arrive_last(ticket, (unsigned)n_groups, &lds.is_last_total)) {
                 reduce_total(gpart, n_groups, lds.stot, sums);
                 // every other workgroup has finished (it arrived after its last use of the parameters)
-                if (t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);
+                if (kStep && t < 64) water_step(lds.stot, pstate, n_obs_total, co, trace_row);
             }
         }
     }
 }
 
-// J-parameter iteration (sucre.py:142-148 with J among the parameters).
-template <bool kFused, int kFmt>
-__global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t *__restrict__ ws,
-                                                       const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
-                                                       float *pstate, const uint64_t *__restrict__ n_obs_total,
-                                                       float *__restrict__ state, float *partials, const AdamCoef co,
-                                                       unsigned *ticket, double *gpart, int n_groups, double *sums,
-                                                       double *trace_row, const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLds lds;  // 21.9 KB
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(pstate);
-    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
-#ifdef SUCRE_EXP_CLOCK  // experiment build only: shader clock held during the launch (MI355X_MICROARCH.md, DVFS item 6)
-    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    // a store compacted in the other format is not read at all; the logged cost turns NaN instead
-    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
-    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t n_items = fmt_ok ? plan_count[wid] : 0u;
-
-    // The lane's shares of the global sums keep accumulating across its strips; the per-pixel sums restart with
-    // every strip.
-    Acc acc;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { acc.pa[c] = 0.f; acc.pb[c] = 0.f; acc.sB[c] = 0.f; acc.sGZ[c] = 0.f; }
-    acc.cost = fmt_ok ? 0.f : __builtin_nanf("");
-    float sBeta[3] = {0.f, 0.f, 0.f};
+// One wave's share of a J-parameter iteration on one image (sucre.py:142-148 with J among the parameters): streams
+// the wave's items, steps J of every strip, and keeps adding the lane's shares of the global sums to acc / sBeta.
+template <int kFmt>
+__device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n_items,
+                                          const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
+                                          const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3]) {
     float J[3] = {0.f, 0.f, 0.f};
-
     stream_items<kFmt>(
-        lds, plan + (size_t)wid * plan_stride, n_items, ws, wave, lane,
+        lds, plan, n_items, ws, wave, lane,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -632,6 +635,43 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
                 st[(6 + c) * kStripPx + lane] = v;
             }
         });
+}
+
+__device__ __forceinline__ void zero_acc(Acc &acc) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { acc.pa[c] = 0.f; acc.pb[c] = 0.f; acc.sB[c] = 0.f; acc.sGZ[c] = 0.f; }
+    acc.cost = 0.f;
+}
+
+// J-parameter iteration of one image: one launch.
+template <bool kFused, int kFmt>
+__global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t *__restrict__ ws,
+                                                       const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
+                                                       float *pstate, const uint64_t *__restrict__ n_obs_total,
+                                                       float *__restrict__ state, float *partials, const AdamCoef co,
+                                                       unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                                       double *trace_row, const uint32_t *__restrict__ obs_format) {
+    __shared__ FitLds lds;  // 21.9 KB
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(pstate);
+    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
+#ifdef SUCRE_EXP_CLOCK  // experiment build only: shader clock held during the launch (MI355X_MICROARCH.md, DVFS item 6)
+    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // a store compacted in the other format is not read at all; the logged cost turns NaN instead
+    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t n_items = fmt_ok ? plan_count[wid] : 0u;
+
+    // The lane's shares of the global sums keep accumulating across its strips; the per-pixel sums restart with
+    // every strip.
+    Acc acc;
+    zero_acc(acc);
+    if (!fmt_ok) acc.cost = __builtin_nanf("");
+    float sBeta[3] = {0.f, 0.f, 0.f};
+    grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, n_items, ws, state, wave, lane, w, gscale, co, acc, sBeta);
 
 #ifdef SUCRE_EXP_CLOCK
     if (t == 0 && blockIdx.x == 7) {   // stamps go to the two padding slots of `sums`, which nothing reads
@@ -648,32 +688,18 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
 }
 
-// Closed-form mode, one observation pass per iteration (see AccOne); kJOnly: SUCRe.update_J alone (sucre.py:66-77,
-// 156): J = sum (I - b) a / sum a^2 from the current parameters, nothing else.
-template <bool kFused, int kFmt, bool kJOnly>
-__global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uint8_t *__restrict__ ws,
-                                                         const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
-                                                         float *pstate, const uint64_t *__restrict__ n_obs_total,
-                                                         float *__restrict__ state, float *partials, const AdamCoef co,
-                                                         unsigned *ticket, double *gpart, int n_groups, double *sums,
-                                                         double *trace_row, const uint32_t *__restrict__ obs_format) {
-    __shared__ FitLds lds;
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(pstate);
-    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
-    // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
-    // plan was written for the store's format, so the items themselves are sound)
-    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t n_items = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;
-    float sB[3] = {0.f, 0.f, 0.f}, sGZ[3] = {0.f, 0.f, 0.f}, sBeta[3] = {0.f, 0.f, 0.f};
-    float cost = fmt_ok ? 0.f : __builtin_nanf("");
+// One wave's share of a closed-form iteration on one image, one observation pass (see AccOne); kJOnly:
+// SUCRe.update_J alone (sucre.py:66-77, 156): J = sum (I - b) a / sum a^2 from the current parameters, nothing else.
+struct ClosedSums { float sB[3], sGZ[3], sBeta[3], cost; };
+
+template <int kFmt, bool kJOnly>
+__device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n_items,
+                                            const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
+                                            const Water &w, bool fmt_ok, ClosedSums &cs) {
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
-
     stream_items<kFmt>(
-        lds, plan + (size_t)wid * plan_stride, n_items, ws, wave, lane,
+        lds, plan, n_items, ws, wave, lane,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -711,16 +737,176 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
                 const float Jc = fmt_ok ? Jp[c] + dJ : __builtin_nanf("");   // = sum y a / sum a^2
                 st[c * kStripPx + lane] = Jc;
                 if (!kJOnly && D != 0.0f) {
-                    sB[c] += __builtin_fmaf(-dJ, acc.q[3][c], acc.q[2][c]);
-                    sBeta[c] += Jc * __builtin_fmaf(-dJ, acc.q[5][c], acc.q[4][c]);
-                    sGZ[c] += __builtin_fmaf(-dJ, acc.q[7][c], acc.q[6][c]);
-                    cost += __builtin_fmaf(-dJ, N, acc.q[8][c]);
+                    cs.sB[c] += __builtin_fmaf(-dJ, acc.q[3][c], acc.q[2][c]);
+                    cs.sBeta[c] += Jc * __builtin_fmaf(-dJ, acc.q[5][c], acc.q[4][c]);
+                    cs.sGZ[c] += __builtin_fmaf(-dJ, acc.q[7][c], acc.q[6][c]);
+                    cs.cost += __builtin_fmaf(-dJ, N, acc.q[8][c]);
                 }
             }
         });
+}
+
+template <bool kFused, int kFmt, bool kJOnly>
+__global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uint8_t *__restrict__ ws,
+                                                         const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
+                                                         float *pstate, const uint64_t *__restrict__ n_obs_total,
+                                                         float *__restrict__ state, float *partials, const AdamCoef co,
+                                                         unsigned *ticket, double *gpart, int n_groups, double *sums,
+                                                         double *trace_row, const uint32_t *__restrict__ obs_format) {
+    __shared__ FitLds lds;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const Water w = load_water(pstate);
+    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
+    // plan was written for the store's format, so the items themselves are sound)
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t n_items = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;
+    ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
+    closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, n_items, ws, state, wave, lane, w, fmt_ok, cs);
     if (kJOnly) return;
-    float s[kNumSums] = {sB[0], sB[1], sB[2], sGZ[0], sGZ[1], sGZ[2], sBeta[0], sBeta[1], sBeta[2], cost};
+    float s[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
+}
+
+struct Params9 { float v[9]; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shared water parameters (north-star extension): every image of this rank -- and, through one
+// all-reduce of the ten sums, of every other rank -- steps B, beta, gamma together.  One iteration is ONE launch and
+// one collective: the launch walks all the rank's images (every wave streams its item list of image 0, then of
+// image 1, ...; the lanes' shares of the sums simply keep accumulating), leaves the rank's reduced sums in the group
+// buffer for the host's all-reduce, and the Adam step on the nine parameters that those all-reduced sums call for
+// is taken in the PROLOGUE of the next launch, by every workgroup for itself from the same inputs (workgroup 0
+// records it).  The water state is double-buffered so that late workgroups never read a stepped state.
+// ---------------------------------------------------------------------------------------------------------------
+struct GroupImage {
+    uint8_t *ws;
+    uint64_t off_plan[2], off_count[2], off_state, off_format, off_params;
+    uint32_t stride[2], n_waves[2];
+};
+
+struct GroupHeader {
+    float pstate[2][32];                 // [k & 1] = B, beta, gamma + moments after k steps (27 floats used)
+    double sums[kSumsPad];               // this rank's sums of the last pass; all-reduced in place by the host
+    unsigned ticket[(1 + (kFitGrid + kGroup - 1) / kGroup) * kTicketStride];
+    double gpart[kNumSums * ((kFitGrid + kGroup - 1) / kGroup)];
+    float partials[kNumSums * kFitGrid];
+};
+
+__host__ __device__ __forceinline__ GroupImage *group_images(GroupHeader *g) {
+    return reinterpret_cast<GroupImage *>(reinterpret_cast<uint8_t *>(g) + align_up(sizeof(GroupHeader), 256));
+}
+
+// The step that the all-reduced sums call for (water_step's arithmetic), from state `in`; lanes 0..8 of wave 0 return
+// the stepped (p, m, v); all 64 lanes must call it.
+// Agent-scope (sc1) accesses for everything the group launches hand to each other or receive from the host between
+// launches: the water state, written early in a launch by workgroup 0 and read by every workgroup of the next one,
+// and the sums, written by the last arriver and by the host's all-reduce.  (Measured with two processes sharing the
+// GPU: with plain loads some workgroups of a launch stepped from a stale copy -- non-deterministic trajectories.)
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void group_water_step(const double *__restrict__ sums, const float *__restrict__ in,
+                                                 uint64_t n_obs_total, const AdamCoef &co, bool apply, float &p, float &m, float &v) {
+    const int q = threadIdx.x & 63;
+    p = m = v = 0.f;
+    if (q < 9) {
+        p = ld_agent(in + q); m = ld_agent(in + 9 + q); v = ld_agent(in + 18 + q);
+        if (apply) {
+            const float scale = (1.0f / 3.0f) / (float)n_obs_total;
+            const int c = q % 3;
+            double g;
+            if (q < 3) g = -2.0 * (double)scale * ld_agent(sums + c);
+            else if (q < 6) g = 2.0 * (double)scale * ld_agent(sums + 6 + c);
+            else g = -2.0 * (double)scale * (double)ld_agent(in + c) * ld_agent(sums + 3 + c);
+            adam_update(p, m, v, (float)g, co);
+        }
+    }
+}
+
+template <int kMode, int kFmt>
+__global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_iter_kernel(GroupHeader *g, int n_images, uint64_t n_obs_total,
+                                                                                           const AdamCoef co_prev, const AdamCoef co, int apply,
+                                                                                           int in, int out, double *trace_prev, int n_groups,
+                                                                                           const GroupImage *__restrict__ images) {
+    __shared__ FitLds lds;
+    __shared__ float wpar[9];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if (t < 64) {
+        float p, m, v;
+        group_water_step(g->sums, g->pstate[in], n_obs_total, co_prev, apply != 0, p, m, v);
+        if (lane < 9) wpar[lane] = p;
+        if (blockIdx.x == 0 && apply) {   // every workgroup computes the same step; workgroup 0 records it
+            if (lane < 9) {
+                st_agent(&g->pstate[out][lane], p); st_agent(&g->pstate[out][9 + lane], m); st_agent(&g->pstate[out][18 + lane], v);
+                if (trace_prev) trace_prev[1 + lane] = (double)p;
+            }
+            if (lane == 9 && trace_prev) trace_prev[0] = ld_agent(&g->sums[9]);
+        }
+    }
+    __syncthreads();
+    const Water w = load_water(wpar);
+    const float gscale = -2.0f * ((1.0f / 3.0f) / (float)n_obs_total);
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    Acc acc;
+    zero_acc(acc);
+    float sBeta[3] = {0.f, 0.f, 0.f};
+    ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+    for (int i = 0; i < n_images; ++i) {
+        const GroupImage im = images[i];
+        uint8_t *ws = uniform_ptr(im.ws);   // between images nothing is in flight: ordinary loads are harmless here
+        const bool fmt_ok = *reinterpret_cast<const uint32_t *>(ws + im.off_format) == (uint32_t)kFmt;
+        if (!fmt_ok) { acc.cost = __builtin_nanf(""); cs.cost = __builtin_nanf(""); continue; }
+        if (wid >= im.n_waves[kMode]) continue;
+        const uint32_t n_items = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
+        const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + im.off_plan[kMode]) + (size_t)wid * im.stride[kMode]);
+        float *state = reinterpret_cast<float *>(ws + im.off_state);
+        if (kMode == 0) grad_pass<kFmt>(lds, plan, n_items, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+        else closed_pass<kFmt, false>(lds, plan, n_items, ws, state, wave, lane, w, true, cs);
+    }
+    float s[kNumSums];
+    if (kMode == 0) {
+        const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
+#pragma unroll
+        for (int i = 0; i < kNumSums; ++i) s[i] = q[i];
+    } else {
+        const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
+#pragma unroll
+        for (int i = 0; i < kNumSums; ++i) s[i] = q[i];
+    }
+    finish_launch<true, false>(lds, s, g->partials, co, g->ticket, g->gpart, n_groups, g->sums, nullptr, nullptr, nullptr);
+}
+
+// The last pending step; the final parameters also go to every image's own workspace (Restoration.params()).
+__global__ __launch_bounds__(64) void group_finish_kernel(GroupHeader *g, int n_images, uint64_t n_obs_total, const AdamCoef co_prev,
+                                                          int apply, int in, int out, double *trace_prev) {
+    float p, m, v;
+    const int lane = threadIdx.x;
+    group_water_step(g->sums, g->pstate[in], n_obs_total, co_prev, apply != 0, p, m, v);
+    if (lane < 9) {
+        st_agent(&g->pstate[out][lane], p); st_agent(&g->pstate[out][9 + lane], m); st_agent(&g->pstate[out][18 + lane], v);
+        if (apply && trace_prev) trace_prev[1 + lane] = (double)p;
+        const GroupImage *images = group_images(g);
+        for (int i = 0; i < n_images; ++i) {
+            float *ps = reinterpret_cast<float *>(images[i].ws + images[i].off_params);
+            ps[lane] = p; ps[9 + lane] = m; ps[18 + lane] = v;
+        }
+    }
+    if (lane == 9 && apply && trace_prev) trace_prev[0] = ld_agent(&g->sums[9]);
+}
+
+__global__ void group_set_image_kernel(GroupHeader *g, int i, const GroupImage im) { group_images(g)[i] = im; }
+
+__global__ __launch_bounds__(64) void group_init_kernel(GroupHeader *g, const Params9 p0) {
+    const int t = threadIdx.x;
+    if (t < 32) { g->pstate[0][t] = t < 9 ? p0.v[t] : 0.f; g->pstate[1][t] = 0.f; }
+    if (t < kSumsPad) g->sums[t] = 0.0;
+    for (int i = t; i < (int)(sizeof(g->ticket) / sizeof(unsigned)); i += 64) g->ticket[i] = 0u;
 }
 
 __global__ __launch_bounds__(256) void reduce_groups_kernel(const float *partials, int n_blocks, double *gpart,
@@ -738,8 +924,6 @@ __global__ __launch_bounds__(64) void param_step_kernel(const double *__restrict
                                                         double *__restrict__ trace_row) {
     water_step(sums, pstate, n_obs_total, co, trace_row);
 }
-
-struct Params9 { float v[9]; };
 
 // SUCRe.__init__ (sucre.py:36-50) in the sorted pixel order: one workgroup per sorted tile = four strips.
 __global__ __launch_bounds__(256) void fit_init_kernel(const uint8_t *__restrict__ rgb1,
@@ -876,6 +1060,60 @@ hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStre
     hipLaunchKernelGGL(export_J_kernel, dim3(L.n_tiles), dim3(256), 0, s,
                        reinterpret_cast<const float *>(ws + L.off_state), L.H, L.W, L.tiles_x,
                        reinterpret_cast<const uint32_t *>(ws + L.off_invperm), J);
+    return hipGetLastError();
+}
+
+size_t group_bytes(int n_images) { return align_up(sizeof(GroupHeader), 256) + (size_t)n_images * sizeof(GroupImage); }
+
+int64_t group_sums_offset() { return (int64_t)offsetof(GroupHeader, sums); }
+
+hipError_t launch_group_init(void *group, const float *params0, hipStream_t s) {
+    Params9 p0;
+    for (int i = 0; i < 9; ++i) p0.v[i] = params0[i];
+    hipLaunchKernelGGL(group_init_kernel, dim3(1), dim3(64), 0, s, static_cast<GroupHeader *>(group), p0);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_set_image(void *group, int i, const Layout &L, uint8_t *ws, hipStream_t s) {
+    GroupImage im;
+    im.ws = ws;
+    for (int m = 0; m < 2; ++m) {
+        im.off_plan[m] = L.off_plan[m]; im.off_count[m] = L.off_plan_count[m];
+        im.stride[m] = (uint32_t)L.plan_stride[m]; im.n_waves[m] = (uint32_t)L.fit_blocks[m] * 4u;
+    }
+    im.off_state = L.off_state;
+    im.off_format = L.off_total_chunks + sizeof(uint64_t);
+    im.off_params = L.off_params;
+    hipLaunchKernelGGL(group_set_image_kernel, dim3(1), dim3(1), 0, s, static_cast<GroupHeader *>(group), i, im);
+    return hipGetLastError();
+}
+
+// step >= 1: the pass of iteration `step`; first applies the pending step of iteration step - 1 (if any).
+hipError_t launch_group_iter(void *group, int n_images, int step, const AdamCoef &co_prev, const AdamCoef &co, unsigned flags,
+                             uint64_t n_obs_total, double *trace_prev, hipStream_t s) {
+    auto *g = static_cast<GroupHeader *>(group);
+    const int apply = step > 1 ? 1 : 0;
+    const int in = apply ? (step - 2) & 1 : 0, out = apply ? (step - 1) & 1 : 0;
+    const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
+    if (flags & SUCRE_FIT_CLOSED_FORM) {
+        const int ng = (kClosedGrid + kGroup - 1) / kGroup;
+        if (u16) hipLaunchKernelGGL((group_iter_kernel<1, 1>), dim3(kClosedGrid), dim3(256), 0, s, g, n_images, n_obs_total, co_prev, co, apply, in, out, trace_prev, ng, group_images(g));
+        else hipLaunchKernelGGL((group_iter_kernel<1, 0>), dim3(kClosedGrid), dim3(256), 0, s, g, n_images, n_obs_total, co_prev, co, apply, in, out, trace_prev, ng, group_images(g));
+    } else {
+        const int ng = (kFitGrid + kGroup - 1) / kGroup;
+        if (u16) hipLaunchKernelGGL((group_iter_kernel<0, 1>), dim3(kFitGrid), dim3(256), 0, s, g, n_images, n_obs_total, co_prev, co, apply, in, out, trace_prev, ng, group_images(g));
+        else hipLaunchKernelGGL((group_iter_kernel<0, 0>), dim3(kFitGrid), dim3(256), 0, s, g, n_images, n_obs_total, co_prev, co, apply, in, out, trace_prev, ng, group_images(g));
+    }
+    return hipGetLastError();
+}
+
+// after the pass of iteration `step` (and its all-reduce): applies that last step
+hipError_t launch_group_finish(void *group, int n_images, int step, const AdamCoef &co_prev, uint64_t n_obs_total,
+                               double *trace_prev, hipStream_t s) {
+    const int apply = step >= 1 ? 1 : 0;
+    const int in = apply ? (step - 1) & 1 : 0, out = apply ? step & 1 : 0;
+    hipLaunchKernelGGL(group_finish_kernel, dim3(1), dim3(64), 0, s, static_cast<GroupHeader *>(group), n_images, n_obs_total, co_prev,
+                       apply, in, out, trace_prev);
     return hipGetLastError();
 }
 

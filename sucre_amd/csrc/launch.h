@@ -51,6 +51,15 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s)
 hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s);
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
 hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
+// shared water parameters over several images: one launch + one collective per iteration (fit.hip)
+size_t group_bytes(int n_images);
+int64_t group_sums_offset();
+hipError_t launch_group_init(void *group, const float *params0, hipStream_t s);
+hipError_t launch_group_set_image(void *group, int i, const Layout &L, uint8_t *ws, hipStream_t s);
+hipError_t launch_group_iter(void *group, int n_images, int step, const AdamCoef &co_prev, const AdamCoef &co, unsigned flags,
+                             uint64_t n_obs_total, double *trace_prev, hipStream_t s);
+hipError_t launch_group_finish(void *group, int n_images, int step, const AdamCoef &co_prev, uint64_t n_obs_total,
+                               double *trace_prev, hipStream_t s);
 
 // output stage (plot.hip)
 size_t select_scratch_bytes();

@@ -94,7 +94,7 @@ struct Layout {
     size_t total;
 };
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline bool make_layout(int H, int W, int n_views, Layout *L) {
     if (H <= 0 || W <= 0 || n_views <= 0 || n_views > kMaxViews || H > 32767 || W > 32767) return false;

@@ -80,3 +80,5 @@ def fit_shared_water(backend: WaterBackend, num_iter: int, group=None) -> None:
         sums = backend.grad(it)
         all_reduce_sum(sums, group)
         backend.step(it)
+    if hasattr(backend, 'finish'):
+        backend.finish()     # a backend that defers its parameter step to the next launch takes the last one here

@@ -392,34 +392,73 @@ class HipWaterBackend:
 
 
 class HipWaterGroup:
-    """dist.WaterBackend over SEVERAL restorations of this rank (BASELINE config 4: a 512-image scene, 64 images per
-    GPU, all sharing B, beta, gamma): the images' gradient sums are added on the device before the one all-reduce of
-    the iteration, and every image then applies the same reduced sums."""
+    """dist.WaterBackend over ALL the restorations of this rank (BASELINE config 4: a 512-image scene, 64 images per
+    GPU, all sharing B, beta, gamma) with one launch and one collective per iteration: ``grad`` runs the gradient pass
+    of every image in a single launch (csrc/fit.hip, group_iter_kernel) and returns the rank's ten sums for the
+    all-reduce; the Adam step those sums call for is taken in the prologue of the next ``grad`` launch (``step`` only
+    notes it) and ``finish`` takes the last one.  ``trace``: optional (T, 10) float64 device tensor."""
 
-    def __init__(self, backends: list[HipWaterBackend]):
-        assert backends, 'need at least one image'
-        self.backends = list(backends)
-        self._total = torch.zeros(12, dtype=torch.float64, device=backends[0].r.device)
+    def __init__(self, restorations: list, lr: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
+                 use_closed_form: bool = False, trace: torch.Tensor | None = None, params0=None):
+        rs = [getattr(r, 'r', r) for r in restorations]      # Restoration objects (or HipWaterBackend wrappers)
+        assert rs, 'need at least one image'
+        if any(r.light or r.float_colour for r in rs):
+            raise NotImplementedError('shared water parameters run on the plain water model with uint8 colours')
+        assert len({(r.obs_format, str(r.device)) for r in rs}) == 1, 'one device and one observation format per group'
+        self.rs = rs
+        self.lib = rs[0].lib
+        self.device = rs[0].device
+        self.hyper = (float(lr), float(betas[0]), float(betas[1]), float(eps))
+        self.closed = bool(use_closed_form)
+        self.flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | rs[0]._fmt_flag
+        self.trace = trace
+        self.total = None
+        self.steps_done = 0
+        n = len(rs)
+        self.buf = torch.empty(self.lib.sucre_group_bytes(n), dtype=torch.uint8, device=self.device)
+        assert self.buf.data_ptr() % 256 == 0
+        table = (_lib.GroupImage * n)(*[_lib.GroupImage(r.ws.data_ptr(), r.H, r.W, r.n_views, 0) for r in rs])
+        p0 = np.full(9, 0.1, np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(9)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_group_init(C.c_void_p(self.buf.data_ptr()), n, table, (C.c_float * 9)(*p0.tolist()),
+                                                 _stream_ptr()))
+        off = self.lib.sucre_group_sums_offset()
+        self._sums = self.buf[off:off + 96].view(torch.float64)
 
     def grad_device(self):
-        return self.backends[0].r.device
+        return self.device
 
     def n_obs(self) -> int:
-        return sum(b.n_obs() for b in self.backends)
+        return sum(r.n_obs() for r in self.rs)
 
     def set_n_obs_total(self, n: int) -> None:
-        for b in self.backends:
-            b.set_n_obs_total(n)
+        self.total = int(n)
+
+    def _trace_ptr(self):
+        return C.c_void_p(self.trace.data_ptr()) if self.trace is not None else None
 
     def grad(self, step: int) -> torch.Tensor:
-        sums = [b.grad(step) for b in self.backends]
-        torch.sum(torch.stack(sums), dim=0, out=self._total)   # fixed order: image 0, 1, ... (float64)
-        return self._total
+        assert self.total, 'set_n_obs_total() first'
+        with torch.cuda.device(self.device):
+            if self.closed and step == 1:   # start the one-pass closed-form kernel from a solved J (see sucre_fit_run)
+                for r in self.rs:
+                    r.update_J()
+            _lib.check(self.lib.sucre_group_iter(C.c_void_p(self.buf.data_ptr()), len(self.rs), int(step), *self.hyper,
+                                                 self.flags, self.total, self._trace_ptr(), _stream_ptr()))
+        return self._sums
 
     def step(self, step: int) -> None:
-        for b in self.backends:
-            b._sums.copy_(self._total)
-            b.step(step)
+        self.steps_done = int(step)    # taken in the prologue of the next grad launch, or by finish()
+        for r in self.rs:
+            r.steps_done = int(step)
+
+    def finish(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sucre_group_finish(C.c_void_p(self.buf.data_ptr()), len(self.rs), self.steps_done, *self.hyper,
+                                                   self.total, self._trace_ptr(), _stream_ptr()))
+            if self.closed:
+                for r in self.rs:
+                    r.update_J()     # the final update_J of sucre.py:156 from the final parameters
 
 
 _POOL: dict = {}

@@ -1,4 +1,4 @@
-"""One rank of the two-process shared-water GPU test (tests/test_gpu_dist.py): the real HipWaterBackend driven by
+"""One rank of the two-process shared-water GPU test (tests/test_gpu_dist.py): the real single-launch HipWaterGroup driven by
 dist.fit_shared_water over a gloo process group, both ranks on the box's one GPU."""
 import sys
 from pathlib import Path
@@ -24,7 +24,7 @@ def main(out_dir: str, fixture: str, T: int) -> None:
     r.match(views[tgt], views)
     r.fit_init(views[tgt])
     trace = torch.zeros((T, 10), dtype=torch.float64, device=dev)
-    be = engine.HipWaterBackend(r, trace=trace)
+    be = engine.HipWaterGroup([r], trace=trace)
     sdist.fit_shared_water(be, T)
     torch.cuda.synchronize()
     import torch.distributed as dist

@@ -127,35 +127,64 @@ def test_match_two_way_and_matches_data_compat(disk_scene):
         assert _same_points(cP.numpy(), scP)     # the camera points of loader.py:113 themselves
 
 
-def test_shared_water_split_path_vs_oracle():
-    """Two images share B, beta, gamma (the N>1 exchange, emulated in one process: the all-reduce is a sum)."""
+def test_shared_water_group_vs_oracle():
+    """Two images share B, beta, gamma (the N>1 exchange, emulated in one process: the all-reduce is a sum): the
+    single-launch group path (engine.HipWaterGroup: one launch per iteration over both images, parameter step in the
+    next launch's prologue) against the oracle, J-parameter and closed-form."""
+    from sucre_amd import dist as sdist
     from sucre_amd import engine
     T = 15
-    backends, oimgs = [], []
-    for seed in (10, 11):
-        scene = synth.make_scene(48, 32, 3, seed=seed)
-        views = engine.device_views_from_scene(scene, 'cuda')
-        r = engine.Restoration(32, 48, len(views))
-        r.match(views[scene.target], views)
-        r.fit_init(views[scene.target])
-        backends.append(engine.HipWaterBackend(r))
-        _, samples = helpers.oracle_scene_samples(scene)
-        tgt = scene.views[scene.target]
-        oimgs.append(oracle.SharedWaterImage(32, 48, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
-    total = sum(b.n_obs() for b in backends)
-    assert total == sum(o.n_obs for o in oimgs)
-    # several images of one rank: engine.HipWaterGroup adds their sums before the (here absent) all-reduce
+    for closed in (False, True):
+        rs, oimgs, scenes = [], [], []
+        for seed in (10, 11):
+            scene = synth.make_scene(48, 32, 3, seed=seed)
+            views = engine.device_views_from_scene(scene, 'cuda')
+            r = engine.Restoration(32, 48, len(views))
+            r.match(views[scene.target], views)
+            r.fit_init(views[scene.target])
+            rs.append(r)
+            _, samples = helpers.oracle_scene_samples(scene)
+            tgt = scene.views[scene.target]
+            oimgs.append(oracle.SharedWaterImage(32, 48, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
+        total = sum(r.n_obs() for r in rs)
+        assert total == sum(o.n_obs for o in oimgs)
+        trace = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
+        group = engine.HipWaterGroup(rs, use_closed_form=closed, trace=trace)
+        sdist.fit_shared_water(group, T)
+        p0, p1 = rs[0].params().cpu().numpy(), rs[1].params().cpu().numpy()
+        assert np.array_equal(p0, p1) and np.array_equal(p0, trace[-1, 1:].cpu().numpy().astype(np.float32))
+        assert np.all(np.isfinite(trace.cpu().numpy())) and float(trace[-1, 0]) < float(trace[0, 0])
+        if closed:
+            continue   # the oracle's lock-step helper is J-parameter only; closed form is held to the single-image path below
+        pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
+        for it in range(1, T + 1):
+            acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
+            oracle.shared_step(pstate, acc, it, total)
+        assert np.abs(p0 - pstate[:9]).max() < 1e-5
+        for r, o in zip(rs, oimgs):
+            assert helpers.rms_per_channel(r.J().cpu().numpy(), o.J).max() < 1e-5
+
+
+@pytest.mark.parametrize('closed', [False, True])
+def test_shared_water_group_of_one_equals_the_fused_fit(golden, closed):
+    """A group of one image on one rank is the reference algorithm: the single-launch group path must reproduce
+    sucre_fit_run bit for bit (same kernels' arithmetic, same reduction tree; only where the parameter step is taken
+    differs)."""
     from sucre_amd import dist as sdist
-    sdist.fit_shared_water(engine.HipWaterGroup(backends), T)
-    pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
-    for it in range(1, T + 1):
-        acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
-        oracle.shared_step(pstate, acc, it, total)
-    p0, p1 = backends[0].r.params().cpu().numpy(), backends[1].r.params().cpu().numpy()
-    assert np.array_equal(p0, p1)
-    assert np.abs(p0 - pstate[:9]).max() < 1e-5
-    for b, o in zip(backends, oimgs):
-        assert helpers.rms_per_channel(b.r.J().cpu().numpy(), o.J).max() < 1e-5
+    from sucre_amd import engine
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    T = 12
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views)
+    r.fit_init(views[sc.target])
+    t1 = r.fit(T, use_closed_form=closed).cpu().numpy()
+    J1, p1 = r.J().cpu().numpy(), r.params().cpu().numpy()
+    r.fit_init(views[sc.target])
+    trace = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
+    sdist.fit_shared_water(engine.HipWaterGroup([r], use_closed_form=closed, trace=trace), T)
+    assert np.array_equal(trace.cpu().numpy(), t1)
+    assert np.array_equal(r.J().cpu().numpy(), J1, equal_nan=True) and np.array_equal(r.params().cpu().numpy(), p1)
 
 
 def test_shared_water_vs_tied_reference_modules(golden):
