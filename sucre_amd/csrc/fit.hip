@@ -427,6 +427,11 @@ __device__ __forceinline__ void stream_items(FitLds &lds, const PlanItem *__rest
         for (int S = 0; S < kRing; ++S) {
             if (more) {
                 const int Sin = (S + kAhead) % kRing;
+                // Slot Sin held item i - 1.  Its LDS reads must have RETURNED before the DMA below may overwrite it:
+                // a chunk's reads have (the arithmetic consumed them), but a J plane is read into registers that are
+                // first used one step later -- without this wait the DMA raced those reads (rare, and only under load:
+                // wrong J, first channel first, seen when other work shared the GPU).
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (i + (uint32_t)kAhead < n) issue_item(d[Sin], ws, ring0 + (uint32_t)Sin * kSlot, lane);   // loaded one step ago
                 const uint32_t bits = d[S].y, strip = d[S].z;
                 if (i + (uint32_t)kRing < n) d[S] = items[i + (uint32_t)kRing];
@@ -630,9 +635,15 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
                 sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
                 adam_update(Jc, m, v, gscale * acc.pa[c], co);
+#ifdef SUCRE_STATE_SC1
+                __hip_atomic_store(st + c * kStripPx + lane, Jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(st + (3 + c) * kStripPx + lane, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(st + (6 + c) * kStripPx + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 st[c * kStripPx + lane] = Jc;
                 st[(3 + c) * kStripPx + lane] = m;
                 st[(6 + c) * kStripPx + lane] = v;
+#endif
             }
         });
 }

@@ -39,12 +39,13 @@ constexpr int kSumsPad = 12;
 constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)
 constexpr int kTicketStride = 16;    // uint32 words between tickets: every counter on its own 64-byte line
 #ifndef SUCRE_FIT_WAVES
-#define SUCRE_FIT_WAVES 6
+#define SUCRE_FIT_WAVES 5   // 82-94 VGPRs: at 6 waves (80) the kernels spill, and scratch traffic both counts in the
+                            // hand-counted vmcnt waits and made results depend on what else ran on the GPU (round 2)
 #endif
 #ifndef SUCRE_CLOSED_WAVES
 #define SUCRE_CLOSED_WAVES 4
 #endif
-constexpr int kFitWaves = SUCRE_FIT_WAVES;        // waves per SIMD of fit_grad_kernel (80 VGPRs)
+constexpr int kFitWaves = SUCRE_FIT_WAVES;        // waves per SIMD of fit_grad_kernel / group_iter_kernel (<= 96 VGPRs)
 constexpr int kClosedWaves = SUCRE_CLOSED_WAVES;  // ... of fit_closed_kernel (27 accumulators per lane: 118 VGPRs)
 constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (kFitWaves per CU x 256 CUs: all resident
                                      // at once); constants, so the reduction order -- hence every result bit -- does

@@ -87,3 +87,55 @@ def test_results_do_not_depend_on_who_else_uses_the_gpu(golden):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
         assert digests(so) == [ref[0]] * reps
+
+
+@pytest.mark.timeout(900)
+def test_images_in_flight_equal_one_by_one_under_load():
+    """Different images of a survey restored on two and three HIP streams at once (engine.in_flight_slot's use), with a
+    second thread keeping the GPU busy with unrelated work, against the same images restored one by one: same bits,
+    every time.  Full size on purpose: the races this guards against (an LDS-DMA overwriting a ring slot whose reads
+    had not returned; hand-offs read before they had drained) only showed under load."""
+    import threading
+    import torch
+    from sucre_amd import engine, synth
+    W, H = 1920, 1080
+    survey = synth.make_survey(W, H, 6, 4, seed=3, device='cuda')
+    views = engine.device_views_from_scene(survey, 'cuda')
+    jobs = [(views[t], [views[q] for q in survey.neighbours(t, 12 + (t % 5))]) for t in (7, 8, 9, 10, 13, 14)]
+    cap = max(len(v) for _, v in jobs)
+    T = 120
+    ref = []
+    r = engine.Restoration(H, W, cap)
+    for tgt, vs in jobs:
+        r.match(tgt, vs); r.fit_init(tgt); t = r.fit(T); torch.cuda.synchronize()
+        ref.append((r.J().clone(), t.clone()))
+    del r
+    stop = []
+
+    def noise():
+        g = torch.Generator(device='cuda'); g.manual_seed(1)
+        while not stop:
+            x = torch.rand((1_000_000, 3), device='cuda', generator=g)
+            y = x[x[:, 0] > 0.5]
+            float(torch.sort(y[:, 1]).values.exp().sum())
+    th = threading.Thread(target=noise)
+    th.start()
+    try:
+        for ns in (2, 3):
+            restos = [engine.Restoration(H, W, cap) for _ in range(ns)]
+            streams = [torch.cuda.Stream() for _ in range(ns)]
+            outs = []
+            for rep in range(2):
+                for i, (tgt, vs) in enumerate(jobs):
+                    with torch.cuda.stream(streams[i % ns]):
+                        rr = restos[i % ns]
+                        rr.match(tgt, vs); rr.fit_init(tgt)
+                        outs.append((i, rr.fit(T), rr.J()))
+            torch.cuda.synchronize()
+            for i, t, J in outs:
+                assert torch.equal(t, ref[i][1]), (ns, i)
+                assert torch.equal(torch.nan_to_num(J), torch.nan_to_num(ref[i][0])), (ns, i)
+            del restos
+    finally:
+        stop.append(1)
+        th.join()
