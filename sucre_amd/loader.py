@@ -117,9 +117,9 @@ def load_depth_raw(depth_map_path: Path, width: int, height: int) -> Tensor | No
 
 
 def decode_threads(num_workers: int = 0) -> int:
-    """Threads used to decode image files: ``--num-workers`` when given, else SUCRE_DECODE_THREADS (default 8).
+    """Threads used to decode image files: ``--num-workers`` when given, else SUCRE_DECODE_THREADS (default min(16, cores)).
     PNG/JPEG decoding releases the GIL, and the result does not depend on who decoded it."""
-    return int(num_workers) if num_workers else max(1, int(os.environ.get('SUCRE_DECODE_THREADS', '8')))
+    return int(num_workers) if num_workers else max(1, int(os.environ.get('SUCRE_DECODE_THREADS', min(16, os.cpu_count() or 1))))
 
 
 _PREFETCH_POOL: ThreadPoolExecutor | None = None

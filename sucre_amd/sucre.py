@@ -380,19 +380,19 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
 def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, output_dir: Path, in_flight: int = 2,
                    keep_matches: bool = False, device: str = 'cuda', **kw) -> None:
     """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot)
-    and the output files written by background threads (SUCRE_WRITER_THREADS, default min(16, cores)).  While image i iterates,
+    and the output files written by background threads (SUCRE_WRITER_THREADS, default min(32, cores)).  While image i iterates,
     image i+1 is matched and submitted and the plots of images < i are encoded, so neither the tails of the fit
     launches nor the PNG encoding leave the GPU idle.  Per-image results are the same bits as ``restore_image``
     (each image has its own workspace and stream; nothing is shared)."""
     from . import engine
     pending: list[tuple[int, _Job]] = []
     written = []
-    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(16, os.cpu_count() or 1)))),
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(32, os.cpu_count() or 1)))),
                             thread_name_prefix='sucre-write') as writers:
         def finish(slot, job):
             with engine.in_flight_slot(slot, device):
                 written.append(_restore_finish(job, keep_matches, writers))
-            while len(written) > 4 * in_flight:       # bound the host memory held by queued outputs
+            while len(written) > 64:                  # bound the host memory held by queued outputs (~50 MB each)
                 written.pop(0).result()
 
         for i, image in enumerate(images):
