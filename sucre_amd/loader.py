@@ -63,10 +63,57 @@ def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor | None:
     return torch.from_numpy(np.array(rgb, dtype=np.uint8, order="C"))
 
 
+def _area_taps(ssize: int, dsize: int) -> tuple[np.ndarray, np.ndarray]:
+    """Source indices and weights of OpenCV's INTER_AREA along one axis for a non-integer shrink factor (its
+    ``computeResizeAreaTab``): destination cell ``d`` covers ``[d*scale, (d+1)*scale)`` of the source, whole source
+    cells weigh ``1/cell``, the two partly covered ones their covered fraction (dropped below 1e-3), the weights are
+    rounded to float32 as OpenCV stores them.  Returns ``(index, weight)`` of shape (dsize, taps), padded with weight 0."""
+    scale = 1.0 / (dsize / ssize)
+    rows = []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+        s2 = min(s2, ssize - 1)
+        s1 = min(s1, s2)
+        taps = []
+        if s1 - f1 > 1e-3:
+            taps.append((s1 - 1, np.float32((s1 - f1) / cell)))
+        taps += [(sx, np.float32(1.0 / cell)) for sx in range(s1, s2)]
+        if f2 - s2 > 1e-3:
+            taps.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+        rows.append(taps)
+    n = max(len(t) for t in rows)
+    idx = np.zeros((dsize, n), np.int64)
+    wgt = np.zeros((dsize, n), np.float64)
+    for d, taps in enumerate(rows):
+        for k, (sx, a) in enumerate(taps):
+            idx[d, k], wgt[d, k] = sx, float(a)
+    return idx, wgt
+
+
+def _resize_area(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
+    """INTER_AREA of a float64 image for any shrink factor: columns reduced first, then rows, every sum taken in
+    source order in float64 -- the order of OpenCV's ``ResizeArea_Invoker`` for a double image."""
+    ix, wx = _area_taps(rgb.shape[1], width)
+    iy, wy = _area_taps(rgb.shape[0], height)
+    cols = np.zeros((rgb.shape[0], width, rgb.shape[2]), np.float64)
+    for k in range(ix.shape[1]):
+        cols += rgb[:, ix[:, k]] * wx[None, :, k, None]
+    out = np.zeros((height, width, rgb.shape[2]), np.float64)
+    for k in range(iy.shape[1]):
+        out += cols[iy[:, k]] * wy[:, k, None, None]
+    return out
+
+
 def _resize_rgb(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
     """The reference's resize of the float64 colour image (loader.py:158-162): OpenCV INTER_AREA when shrinking,
-    INTER_CUBIC otherwise.  Without OpenCV, shrinking by integer factors -- what --image-scale 0.5 / 0.25 do -- is
-    done here the way INTER_AREA does it in that case: the block's pixels summed in row-major order, times 1/area."""
+    INTER_CUBIC otherwise.  OpenCV is used when it is installed.  Without it, shrinking is restated here from
+    OpenCV's published algorithm: integer factors (--image-scale 0.5 / 0.25) the way its fast path does them (the
+    block's pixels summed in row-major order, times 1/area), any other factor by `_resize_area`.  The restatement
+    could not be checked against OpenCV in the build image (no cv2 there): install opencv-python where bit-identical
+    --image-scale output matters.  Enlarging (INTER_CUBIC) needs OpenCV."""
     try:
         import cv2
         return cv2.resize(rgb, (width, height), interpolation=cv2.INTER_AREA if width < rgb.shape[1] else cv2.INTER_CUBIC)
@@ -79,9 +126,11 @@ def _resize_rgb(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
         for dy in range(fy):
             for dx in range(fx):
                 acc += rgb[dy::fy, dx::fx]
-        return acc * (1.0 / (fx * fy))
-    raise NotImplementedError(f'resizing {W0}x{H0} to {width}x{height} (not an integer shrink factor) needs OpenCV, '
-                              f'which is not installed: its INTER_AREA / INTER_CUBIC kernels are not restated here')
+        return acc * float(np.float32(1.0) / np.float32(fx * fy))   # OpenCV keeps 1/area in float32
+    if width < W0 and height <= H0:
+        return _resize_area(rgb, width, height)
+    raise NotImplementedError(f'resizing {W0}x{H0} to {width}x{height} (enlarging: INTER_CUBIC) needs OpenCV, which is '
+                              f'not installed')
 
 
 def load_rgb(rgb_path: Path, width: int, height: int) -> Tensor:

@@ -351,8 +351,16 @@ _COLMAP_NUM_PARAMS = {0: 3, 1: 4, 2: 4, 3: 5, 4: 8, 5: 8, 6: 12, 7: 5, 8: 4, 9: 
 
 
 def quat_to_rotmat(qw: float, qx: float, qy: float, qz: float) -> np.ndarray:
-    """Unit quaternion -> 3x3 rotation, float64, same operation order as Eigen's ``toRotationMatrix`` (what
-    pycolmap's ``Rigid3d.rotation.matrix()`` evaluates)."""
+    """Quaternion (COLMAP order: w first) -> 3x3 rotation in float64.  COLMAP normalises the quaternion when it reads
+    ``images.txt`` / ``images.bin`` (a zero quaternion becomes the identity), so the input need not be a unit one;
+    the matrix is then built in the operation order of Eigen's ``toRotationMatrix``, which is what pycolmap's
+    ``cam_from_world.rotation.matrix()`` evaluates (sfm.py:221).  Pinned against scipy's
+    ``Rotation.from_quat([x, y, z, w])`` in tests/test_host_logic.py."""
+    n = float(np.sqrt(qw * qw + qx * qx + qy * qy + qz * qz))
+    if n == 0.0:
+        qw, qx, qy, qz = 1.0, 0.0, 0.0, 0.0
+    else:
+        qw, qx, qy, qz = qw / n, qx / n, qy / n, qz / n
     tx, ty, tz = 2.0 * qx, 2.0 * qy, 2.0 * qz
     twx, twy, twz = tx * qw, ty * qw, tz * qw
     txx, txy, txz = tx * qx, ty * qx, tz * qx
@@ -402,16 +410,21 @@ def _read_images(model_dir: Path) -> dict[int, tuple[tuple[float, ...], tuple[fl
             off += 8 + 24 * n2d
             images[image_id] = (q, t, cam_id, name)
     else:
-        lines = [ln for ln in (model_dir / 'images.txt').read_text().splitlines() if not ln.lstrip().startswith('#')]
+        # COLMAP's text reader: blank lines and lines starting with '#' are skipped wherever a header line is expected;
+        # the line after a header is that image's POINTS2D list (taken as it is, even when empty); the name is the rest
+        # of the header line after the ninth blank, so it may contain blanks itself
+        lines = (model_dir / 'images.txt').read_text().splitlines()
         i = 0
         while i < len(lines):
-            if not lines[i].strip():
-                i += 1
+            head = lines[i].strip()
+            i += 1
+            if not head or head.startswith('#'):
                 continue
-            tok = lines[i].split()
+            tok = head.split(' ', 9)
+            assert len(tok) == 10, f'images.txt: malformed image line {head!r}'
             images[int(tok[0])] = (tuple(float(x) for x in tok[1:5]), tuple(float(x) for x in tok[5:8]), int(tok[8]),
-                                   ' '.join(tok[9:]))
-            i += 2  # the following line lists the 2-D points (possibly empty)
+                                   tok[9].strip())
+            i += 1  # the POINTS2D line
     return images
 
 

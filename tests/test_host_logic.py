@@ -151,7 +151,8 @@ def test_pixel_loaders_reproduce_reference_quantisation(tmp_path):
     dh = loader.load_depth_map(tmp_path / 'depth_a.png', width=4, height=3)
     assert np.array_equal(dh.numpy(), (depth[0::2, 0::2].astype(np.float64) / 1000).astype(np.float32))
     with pytest.raises(NotImplementedError, match='OpenCV'):
-        loader.load_rgb(tmp_path / 'a.png', width=5, height=4)
+        loader.load_rgb(tmp_path / 'a.png', width=16, height=12)   # enlarging is INTER_CUBIC: not restated
+    assert loader.load_rgb(tmp_path / 'a.png', width=5, height=4).shape == (4, 5, 3)
 
 
 def test_list_backed_matches_data_keeps_reference_semantics():
@@ -399,3 +400,91 @@ def test_percentile_plan_and_lerp_are_numpys_percentile():
     lo, hi, g = percentile_plan(len(a), 99)
     got = np.array([percentile_lerp(np.sort(b[:, c])[lo], np.sort(b[:, c])[hi], g) for c in range(3)])
     assert np.array_equal(got, np.percentile(b, 99, axis=0))
+
+
+def test_quat_to_rotmat_equals_scipy_also_for_non_unit_input():
+    """pycolmap's `cam_from_world.rotation.matrix()` (sfm.py:221) = normalise, then Eigen's toRotationMatrix; scipy's
+    Rotation.from_quat (scalar LAST) normalises too and is the independent check available here."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(1)
+    qs = [rng.normal(size=4) * s for s in (1.0, 1.0, 1e-3, 7.5, 1.0) for _ in range(8)]
+    qs += [np.array(q, float) for q in ([1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [-1, 0, 0, 0],
+                                         [0.5, 0.5, 0.5, 0.5], [2, 0, 0, 0], [1, 1e-9, 0, 0], [-0.3, 0.1, -0.9, 0.2])]
+    for q in qs:
+        R = sfm.quat_to_rotmat(*q)
+        Rs = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+        assert np.abs(R - Rs).max() < 1e-15, (q, np.abs(R - Rs).max())
+        assert np.array_equal(R, sfm.quat_to_rotmat(*(-q)))   # q and -q are the same rotation
+    assert np.array_equal(sfm.quat_to_rotmat(0, 0, 0, 0), np.eye(3))   # COLMAP's NormalizeQvec on a zero quaternion
+
+
+def test_images_txt_as_colmap_writes_it(tmp_path):
+    """images.txt cases of a real COLMAP export: populated POINTS2D lines, several cameras, blank lines and comments
+    between records, names with blanks and sub-folders; ids need not be contiguous (sfm.py:186-226)."""
+    (tmp_path / 'cameras.txt').write_text(
+        '# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n# Number of cameras: 2\n'
+        '7 PINHOLE 640 480 500.5 501.25 320.0 240.5\n'
+        '2 PINHOLE 1280 720 900 905 640.25 360\n')
+    (tmp_path / 'images.txt').write_text(
+        '# Image list with two lines of data per image:\n'
+        '#   IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n#   POINTS2D[] as (X, Y, POINT3D_ID)\n'
+        '# Number of images: 3, mean observations per image: 2\n'
+        '12 0.9 0.1 -0.2 0.3 1.5 -2.5 3.25 7 dive 1/frame 0001.png\n'
+        '10.5 20.25 -1 300.0 200.0 17 5 6 99\n'
+        '\n'
+        '3 1 0 0 0 0 0 0 2 b.jpg\n'
+        '\n'
+        '# a comment between records\n'
+        '40 0.0 0.0 2.0 0.0 -1 -2 -3 7 c.JPG\n'
+        '1 2 3\n')
+    model = sfm.COLMAPModel(tmp_path, tmp_path / 'img', tmp_path / 'dep', image_scale=0.5)
+    assert sorted(model.images) == [3, 12, 40] and sorted(model.cameras) == [2, 7]
+    a, b, c = model.images[12], model.images[3], model.images[40]
+    # Image.name is the file's base name (sfm.py:84), which is also what COLMAPModel[...] looks up (sfm.py:226)
+    assert a.name == 'frame 0001.png' and model['frame 0001.png'] is a
+    assert a.rgb_path == tmp_path / 'img' / 'dive 1' / 'frame 0001.png'
+    assert a.depth_map_path == tmp_path / 'dep' / 'dive 1' / 'depth_frame 0001.png'
+    assert c.depth_map_path.name == 'depth_c.png'
+    assert a.camera is model.cameras[7] and c.camera is model.cameras[7] and b.camera is model.cameras[2]
+    assert (a.camera.width, a.camera.height) == (320, 240) and (b.camera.width, b.camera.height) == (640, 360)
+    assert torch.equal(b.camera.K, torch.tensor([[450.0, 0, 320.125], [0, 452.5, 180.0], [0, 0, 1]]))
+    # poses: world-from-camera = inverse of the (normalised) cam_from_world of the file
+    from scipy.spatial.transform import Rotation
+    Rcw = Rotation.from_quat([0.1, -0.2, 0.3, 0.9]).as_matrix()
+    assert torch.allclose(a.pose.R, torch.tensor(Rcw.T, dtype=torch.float32), atol=1e-7)
+    assert torch.allclose(a.pose.t, torch.tensor(-Rcw.T @ np.array([1.5, -2.5, 3.25]), dtype=torch.float32).view(3, 1), atol=1e-6)
+    assert torch.equal(b.pose.R, torch.eye(3)) and torch.equal(b.pose.t, torch.zeros(3, 1))
+    assert torch.allclose(c.pose.R, torch.diag(torch.tensor([-1.0, 1.0, -1.0])))   # (0,0,2,0) -> half turn about y
+
+
+def test_area_resize_without_opencv():
+    """INTER_AREA restated (loader._resize_rgb) when cv2 is absent: exact block means for integer factors, the area
+    integral of the piecewise-constant image for any other factor, weights that sum to one."""
+    try:
+        import cv2  # noqa: F401
+        pytest.skip('cv2 is installed: the product path uses it')
+    except ImportError:
+        pass
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(36, 60, 3)).astype(np.float64) / 255
+    half = loader._resize_rgb(img, 30, 18)
+    assert np.array_equal(half, (img[0::2, 0::2] + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2]) * 0.25)
+    for (w, h) in ((45, 27), (42, 25), (17, 11), (59, 35)):
+        out = loader._resize_rgb(img, w, h)
+        assert out.shape == (h, w, 3)
+        # brute force: integrate the source over each destination cell
+        sx, sy = 60 / w, 36 / h
+        ref = np.zeros_like(out)
+        for y in range(h):
+            for x in range(w):
+                acc = 0.0
+                for yy in range(int(np.floor(y * sy)), min(36, int(np.ceil((y + 1) * sy)))):
+                    wy = min(yy + 1, (y + 1) * sy) - max(yy, y * sy)
+                    for xx in range(int(np.floor(x * sx)), min(60, int(np.ceil((x + 1) * sx)))):
+                        wx = min(xx + 1, (x + 1) * sx) - max(xx, x * sx)
+                        acc = acc + img[yy, xx] * (wx * wy)
+                ref[y, x] = acc / (sx * sy)
+        assert np.abs(out - ref).max() < 2e-3   # OpenCV drops slivers below 1e-3 of a pixel and keeps float32 weights
+        assert np.abs(loader._resize_rgb(np.ones((36, 60, 3)), w, h) - 1).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        loader._resize_rgb(img, 120, 72)

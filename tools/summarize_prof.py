@@ -35,7 +35,7 @@ for d in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
             cnt[k][r['Counter_Name']] += 1
         print(f'== {d}: per-dispatch averages')
         for k in acc:
-            if not any(s in k for s in ('fit_grad', 'fit_closed', 'light_grad', 'match_kernel', 'update_J', 'gather_kernel', 'scatter_kernel')):
+            if not any(s in k for s in ('fit_grad', 'fit_closed', 'light_grad', 'match_kernel', 'update_J', 'scatter_kernel', 'plan_kernel', 'group_iter', 'select_')):
                 continue
             print(' ', k)
             for c in sorted(acc[k]):
@@ -68,5 +68,13 @@ if fetch is not None and write is not None:
             if kernel in r['Name']:
                 rec['rocprofv3_avg_ns'] = float(r['AverageNs'])
                 break
+    import re
+    try:   # the workload the numbers belong to: bench.py prints n_obs in its JSON line
+        rec['n_obs'] = int(re.search(r'"n_obs": (\d+)', open(f'{out}/bench_trace.log').read()).group(1))
+    except (OSError, AttributeError):
+        pass
+    rec['_comment'] = ('HBM traffic of the dominant kernel from rocprofv3 PMC passes (tools/profile.sh; separate --pmc runs, never '
+                       'combined with tracing). FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of wide '
+                       'streaming reads at 64 B); WRITE_SIZE is exact. Workload: bench.py default, --images-in-flight 1.')
     json.dump(rec, open(f'{out}/traffic.json', 'w'), indent=1)
     print('== traffic', json.dumps(rec))
