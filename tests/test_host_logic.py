@@ -488,3 +488,22 @@ def test_area_resize_without_opencv():
         assert np.abs(loader._resize_rgb(np.ones((36, 60, 3)), w, h) - 1).max() < 1e-6
     with pytest.raises(NotImplementedError):
         loader._resize_rgb(img, 120, 72)
+
+
+def test_png_writer_keeps_every_pixel(tmp_path, monkeypatch):
+    """sucre._save_png (the CLI's output files, sucre.py:116-121): lossless for RGB through the zlib writer, PIL for
+    other modes and on request; a decoder must give back the very pixels."""
+    from PIL import Image as PILImage
+    rng = np.random.default_rng(7)
+    for shape in ((37, 53, 3), (1, 1, 3), (2, 300, 3)):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        sucre._save_png(PILImage.fromarray(a), tmp_path / 'a.png')
+        with PILImage.open(tmp_path / 'a.png') as im:
+            assert im.mode == 'RGB' and np.array_equal(np.array(im), a)
+        monkeypatch.setenv('SUCRE_PNG_WRITER', 'pil')
+        sucre._save_png(PILImage.fromarray(a), tmp_path / 'b.png')
+        monkeypatch.delenv('SUCRE_PNG_WRITER')
+        assert np.array_equal(np.array(PILImage.open(tmp_path / 'b.png')), a)
+    g = rng.integers(0, 256, size=(9, 11), dtype=np.uint8)
+    sucre._save_png(PILImage.fromarray(g), tmp_path / 'g.png')
+    assert np.array_equal(np.array(PILImage.open(tmp_path / 'g.png')), g)

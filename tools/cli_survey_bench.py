@@ -4,6 +4,7 @@ depth maps, COLMAP text model): where does a user's wall time go once the GPU pa
 usage (GPU box): python3 tools/cli_survey_bench.py [width height grid_x grid_y n_restore]"""
 import cProfile
 import io
+import os
 import pstats
 import sys
 import tempfile
@@ -30,13 +31,18 @@ def main():
         first = 1 if n >= gx * gy else gx * (gy // 2) + 1
         argv = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
                 '--output-dir', str(root / 'out'), '--image-ids', str(first), str(first + n)]
+        profile = os.environ.get('SUCRE_CLI_PROFILE', '0') != '0'   # cProfile slows the main thread by ~25 %
         pr = cProfile.Profile()
         t0 = time.perf_counter()
-        pr.enable()
+        if profile:
+            pr.enable()
         sucre.main(argv)
-        pr.disable()
+        if profile:
+            pr.disable()
         dt = time.perf_counter() - t0
-        print(f'CLI: {n} images in {dt:.2f}s = {dt / n * 1e3:.0f} ms/image', flush=True)
+        print(f'CLI: {n} images in {dt:.2f}s = {dt / n * 1e3:.0f} ms/image' + (' (under cProfile)' if profile else ''), flush=True)
+        if not profile:
+            return
         s = io.StringIO()
         pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(35)
         print(s.getvalue()[:6000])
