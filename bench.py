@@ -66,6 +66,8 @@ def cpu_baseline(scene, n_obs_full, n_views_full, num_iter, sample_views, sample
     import copy
     import helpers
     from oracle import oracle
+    from sucre_amd.loader import effective_cpus
+    oracle.set_num_threads(effective_cpus())   # the cgroup quota, not the machine core count (256 logical CPUs, quota 16)
     sub = copy.copy(scene)
     order = sorted(range(len(scene.views)), key=lambda i: abs(i - scene.target))[:sample_views]
     order.sort()

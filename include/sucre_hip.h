@@ -221,6 +221,18 @@ size_t sucre_select_scratch_bytes(void);
 int sucre_select_ranks(const float *J_dev, int H, int W, int n_ranks, const uint64_t *ranks, float *out_dev, void *scratch_dev,
                        void *stream);
 
+/* Number of valid pixels of J_dev (no NaN in any channel: `valid`, sucre.py:86-87) -> *count_dev (uint64, device). */
+int sucre_count_valid(const float *J_dev, int H, int W, uint64_t *count_dev, void *stream);
+
+/*
+ * The remainder of SUCRe.plot_J (sucre.py:88-94) in one pass over J_dev: clip every channel to [lo[c], hi[c]] (the
+ * two percentiles; host arrays of 3), subtract the minimum, divide by the maximum, multiply by 255 and truncate to
+ * uint8 -> out_dev ((H,W,3) uint8); pixels with a NaN come out black.  After the clip the minimum is lo[c] and the
+ * maximum of the shifted values is the float32 difference hi[c] - lo[c], so no reduction is involved and the result
+ * equals numpy's bit for bit.
+ */
+int sucre_plot_stretch(const float *J_dev, int H, int W, const float *lo, const float *hi, uint8_t *out_dev, void *stream);
+
 /*
  * MatchesFile.check_integrity (loader.py:89-101) over the whole store in one launch: verdict_dev[k] (uint32, one per
  * view) gets bit 0 if a stored range of view k is not finite, bit 1 if one is negative, bit 2 if the number of

@@ -38,7 +38,33 @@ def lib() -> C.CDLL:
         _lib.oracle_match_view.restype = C.c_int64
         _lib.oracle_fit.restype = C.c_int
         _lib.oracle_update_J.restype = C.c_int
+        _lib.oracle_set_num_threads(_usable_cpus())
     return _lib
+
+
+def _usable_cpus() -> int:
+    """OpenMP's default is one thread per CPU of the machine; inside a container with a CPU quota (16 of 256 on the GPU
+    boxes) that many threads only get the process throttled.  Scheduler affinity capped by the cgroup quota."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path, split in (('/sys/fs/cgroup/cpu.max', True), ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', False)):
+        try:
+            if split:
+                quota, period = Path(path).read_text().split()[:2]
+                if quota != 'max':
+                    n = min(n, max(1, int(quota) // int(period)))
+            else:
+                quota = int(Path(path).read_text())
+                period = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read_text())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
 
 
 def num_threads() -> int:

@@ -64,6 +64,8 @@ SIGNATURES = {
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'sucre_select_scratch_bytes': (C.c_size_t, []),
     'sucre_select_ranks': (_i, [_vp, _i, _i, _i, C.POINTER(C.c_uint64), _vp, _vp, _vp]),
+    'sucre_count_valid': (_i, [_vp, _i, _i, _vp, _vp]),
+    'sucre_plot_stretch': (_i, [_vp, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
     'sucre_check_store': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'sucre_export_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sucre_light_workspace_bytes': (C.c_size_t, [_i, _i, _i]),

@@ -305,6 +305,20 @@ int sucre_select_ranks(const float *J_dev, int H, int W, int n_ranks, const uint
                      "sucre_select_ranks");
 }
 
+int sucre_count_valid(const float *J_dev, int H, int W, uint64_t *count_dev, void *stream) {
+    if (H <= 0 || W <= 0) return fail(SUCRE_ERR_ARG, "invalid image size %dx%d", W, H);
+    if (!J_dev || !count_dev) return fail(SUCRE_ERR_ARG, "J_dev / count_dev is NULL");
+    if (!aligned(J_dev, 4) || !aligned(count_dev, 8)) return fail(SUCRE_ERR_ARG, "misaligned pointer");
+    return check_hip(launch_count_valid(J_dev, H, W, count_dev, static_cast<hipStream_t>(stream)), "sucre_count_valid");
+}
+
+int sucre_plot_stretch(const float *J_dev, int H, int W, const float *lo, const float *hi, uint8_t *out_dev, void *stream) {
+    if (H <= 0 || W <= 0) return fail(SUCRE_ERR_ARG, "invalid image size %dx%d", W, H);
+    if (!J_dev || !lo || !hi || !out_dev) return fail(SUCRE_ERR_ARG, "J_dev / lo / hi / out_dev is NULL");
+    if (!aligned(J_dev, 4)) return fail(SUCRE_ERR_ARG, "misaligned pointer");
+    return check_hip(launch_plot_stretch(J_dev, H, W, lo, hi, out_dev, static_cast<hipStream_t>(stream)), "sucre_plot_stretch");
+}
+
 /* ---- artificial-light model (--light-model) ------------------------------------------------------------------ */
 
 size_t sucre_light_workspace_bytes(int H, int W, int n_views) {

@@ -65,6 +65,8 @@ hipError_t launch_group_finish(void *group, int n_images, int step, const AdamCo
 size_t select_scratch_bytes();
 hipError_t launch_select_ranks(const float *J, int H, int W, int n_ranks, const uint64_t *ranks, float *out, void *scratch,
                                hipStream_t s);
+hipError_t launch_plot_stretch(const float *J, int H, int W, const float *lo, const float *hi, uint8_t *out, hipStream_t s);
+hipError_t launch_count_valid(const float *J, int H, int W, uint64_t *count, hipStream_t s);
 
 // artificial-light model (light.hip)
 size_t light_workspace_bytes(const Layout &L);

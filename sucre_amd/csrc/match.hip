@@ -240,21 +240,32 @@ __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restr
 
 // MatchesFile.check_integrity (loader.py:89-101) for every view in one launch: per view, bit 0 = a stored range is not
 // finite, bit 1 = a stored range is negative, and the number of ranges > 0 (compared with the view's match count by
-// the second kernel -> bit 2).  One workgroup per tile walks the views whose chunk was written.
+// the second kernel -> bit 2).  Workgroup (k, j) walks view k's chunks of the tiles j, j + gridDim.y, ... and reports
+// once.  (The first version, one workgroup per tile reporting per (tile, view, wave), queued 1.5 M atomics on 48
+// addresses: 3.8 ms per 1080p image.)
 __global__ __launch_bounds__(256) void integrity_scan_kernel(const uint8_t *__restrict__ obs,
-                                                             const uint16_t *__restrict__ cnt, int n_views,
+                                                             const uint16_t *__restrict__ cnt, int n_views, int n_tiles,
                                                              size_t tile_stride, size_t view_stride,
                                                              uint32_t *__restrict__ verdict,
                                                              unsigned long long *__restrict__ positives) {
-    const int tile = blockIdx.x, slot = threadIdx.x;
-    for (int k = 0; k < n_views; ++k) {
+    const int k = blockIdx.x, slot = threadIdx.x;
+    __shared__ unsigned long long s_pos;
+    __shared__ uint32_t s_bad;
+    if (slot == 0) { s_pos = 0ull; s_bad = 0u; }
+    __syncthreads();
+    uint32_t bad = 0u, pos = 0u;
+    for (int tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         if (cnt[(size_t)tile * n_views + k] == 0) continue;   // workgroup-uniform: the chunk was never written
         const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[slot];
-        const uint32_t bad = (__builtin_isfinite(z) ? 0u : 1u) | (z < 0.0f ? 2u : 0u);
-        const unsigned long long pos = __ballot(z > 0.0f);
-        const unsigned long long any_bad = __ballot(bad != 0u);
-        if (any_bad != 0ull && bad != 0u) atomicOr(verdict + k, bad);
-        if ((slot & 63) == 0 && pos != 0ull) atomicAdd(positives + k, (unsigned long long)__popcll(pos));
+        bad |= (__builtin_isfinite(z) ? 0u : 1u) | (z < 0.0f ? 2u : 0u);
+        pos += z > 0.0f ? 1u : 0u;
+    }
+    if (pos != 0u) atomicAdd(&s_pos, (unsigned long long)pos);
+    if (bad != 0u) atomicOr(&s_bad, bad);
+    __syncthreads();
+    if (slot == 0) {
+        if (s_pos != 0ull) atomicAdd(positives + k, s_pos);
+        if (s_bad != 0u) atomicOr(verdict + k, s_bad);
     }
 }
 
@@ -394,8 +405,10 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
 hipError_t launch_check_store(const Layout &L, const uint8_t *ws, uint32_t *verdict, uint64_t *scratch, hipStream_t s) {
     if (hipError_t e = hipMemsetAsync(verdict, 0, sizeof(uint32_t) * L.n_views, s); e != hipSuccess) return e;
     if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint64_t) * L.n_views, s); e != hipSuccess) return e;
-    hipLaunchKernelGGL(integrity_scan_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs,
-                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, L.obs_tile_stride,
+    int per_view = 4096 / L.n_views;   // ~4096 workgroups in all
+    per_view = per_view < 1 ? 1 : (per_view > L.n_tiles ? L.n_tiles : per_view);
+    hipLaunchKernelGGL(integrity_scan_kernel, dim3(L.n_views, per_view), dim3(256), 0, s, ws + L.off_obs,
+                       reinterpret_cast<const uint16_t *>(ws + L.off_cnt), L.n_views, L.n_tiles, L.obs_tile_stride,
                        L.obs_view_stride, verdict, reinterpret_cast<unsigned long long *>(scratch));
     hipLaunchKernelGGL(integrity_verdict_kernel, dim3((L.n_views + 255) / 256), dim3(256), 0, s,
                        reinterpret_cast<const unsigned long long *>(scratch),

@@ -110,4 +110,56 @@ hipError_t launch_select_ranks(const float *J, int H, int W, int n_ranks, const 
     return hipGetLastError();
 }
 
+// The rest of plot_J (sucre.py:88-94) in one pass: clip to [lo, hi], shift, scale, times 255, truncate to uint8; pixels
+// with a NaN in any channel come out black.  After the clip the smallest value IS lo and the largest IS hi (a
+// percentile lies between the extreme order statistics, and np.clip returns the bound itself), so np.min of the clipped
+// values is lo, np.max of the shifted ones is the float32 difference hi - lo: no reduction is needed, and every
+// operation below is the same IEEE float32 operation numpy performs (this file is built without contraction).
+__global__ __launch_bounds__(256) void plot_stretch_kernel(const float *__restrict__ J, long long n_px, float lo0, float lo1,
+                                                           float lo2, float hi0, float hi1, float hi2,
+                                                           uint8_t *__restrict__ out) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_px) return;
+    const float v[3] = {J[p * 3], J[p * 3 + 1], J[p * 3 + 2]};
+    const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const bool valid = !(__builtin_isnan(v[0]) || __builtin_isnan(v[1]) || __builtin_isnan(v[2]));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float x = v[c];
+        x = x < lo[c] ? lo[c] : x;          // np.clip = minimum(maximum(x, lo), hi)
+        x = x > hi[c] ? hi[c] : x;
+        x = (x - lo[c]) / (hi[c] - lo[c]);
+        out[p * 3 + c] = valid ? (uint8_t)(x * 255.0f) : (uint8_t)0;
+    }
+}
+
+// Number of valid pixels (no NaN in any channel, sucre.py:87) -> *count (uint64, zeroed here).
+__global__ __launch_bounds__(256) void count_valid_kernel(const float *__restrict__ J, long long n_px,
+                                                          unsigned long long *__restrict__ count) {
+    unsigned int mine = 0;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n_px; p += (long long)gridDim.x * 256)
+        mine += !(__builtin_isnan(J[p * 3]) || __builtin_isnan(J[p * 3 + 1]) || __builtin_isnan(J[p * 3 + 2]));
+    __shared__ unsigned int total;
+    if (threadIdx.x == 0) total = 0u;
+    __syncthreads();
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && total) atomicAdd(count, (unsigned long long)total);
+}
+
+hipError_t launch_plot_stretch(const float *J, int H, int W, const float *lo, const float *hi, uint8_t *out, hipStream_t s) {
+    const long long n_px = (long long)H * W;
+    hipLaunchKernelGGL(plot_stretch_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, s, J, n_px, lo[0], lo[1], lo[2],
+                       hi[0], hi[1], hi[2], out);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_valid(const float *J, int H, int W, uint64_t *count, hipStream_t s) {
+    const long long n_px = (long long)H * W;
+    if (hipError_t e = hipMemsetAsync(count, 0, sizeof(uint64_t), s); e != hipSuccess) return e;
+    const int grid = (int)((n_px + 255) / 256 < 1024 ? (n_px + 255) / 256 : 1024);
+    hipLaunchKernelGGL(count_valid_kernel, dim3(grid), dim3(256), 0, s, J, n_px, reinterpret_cast<unsigned long long *>(count));
+    return hipGetLastError();
+}
+
 }  // namespace sucre

@@ -113,6 +113,10 @@ class Restoration:
             self.lws = torch.empty(lbytes, dtype=torch.uint8, device=self.device)
             assert self.lws.data_ptr() % 256 == 0
         self._views_dev = None
+        # the view table goes through a pinned staging buffer: a copy from pageable memory makes the host wait
+        self._views_host = torch.empty(self.capacity * C.sizeof(_lib.SucreView), dtype=torch.uint8).pin_memory()
+        self._views_buf = torch.empty(self.capacity * C.sizeof(_lib.SucreView), dtype=torch.uint8, device=self.device)
+        self._views_copied = None
         self._keepalive = []
         self.trace = None
         self.steps_done = 0
@@ -135,8 +139,15 @@ class Restoration:
         self.n_views = len(views)   # the workspace layout is a function of (H, W, n_views) and grows with n_views
         tgt = target.to_struct()
         table = (_lib.SucreView * self.n_views)(*[v.to_struct() for v in views])
-        host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
-        self._views_dev = host.to(self.device)
+        nbytes = C.sizeof(table)
+        if self._views_copied is not None:
+            self._views_copied.synchronize()   # the previous table has left the staging buffer (it was the first thing
+        self._views_host[:nbytes].copy_(torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8))   # of that image)
+        self._views_dev = self._views_buf[:nbytes]
+        with torch.cuda.device(self.device):
+            self._views_dev.copy_(self._views_host[:nbytes], non_blocking=True)
+            self._views_copied = torch.cuda.Event()
+            self._views_copied.record()
         self._keepalive = [target, views]
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
@@ -211,8 +222,11 @@ class Restoration:
     def view_keep(self) -> torch.Tensor:
         return self._region(_lib.WS_VIEW_KEEP, torch.int32, self.n_views)
 
+    def n_obs_device(self) -> torch.Tensor:
+        return self._region(_lib.WS_N_OBS, torch.int64, 1)
+
     def n_obs(self) -> int:
-        return int(self._region(_lib.WS_N_OBS, torch.int64, 1).item())
+        return int(self.n_obs_device().item())
 
     def export_view(self, k: int):
         """Dense (z (H,W) float32, rgb (H,W,3) uint8) planes of view k's matches."""
@@ -341,6 +355,31 @@ def select_ranks(J: torch.Tensor, ranks: list[int]) -> torch.Tensor:
     with torch.cuda.device(J.device):
         _lib.check(lib.sucre_select_ranks(C.c_void_p(J.data_ptr()), J.shape[0], J.shape[1], len(ranks), arr,
                                           C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()), _stream_ptr()))
+    return out
+
+
+def count_valid(J: torch.Tensor) -> int:
+    """Pixels of the (H,W,3) float32 device image ``J`` without a NaN in any channel (``valid``, sucre.py:86-87)."""
+    lib = _lib.load()
+    assert J.is_cuda and J.dtype == torch.float32 and J.is_contiguous() and J.dim() == 3 and J.shape[2] == 3
+    count = torch.empty(1, dtype=torch.int64, device=J.device)
+    with torch.cuda.device(J.device):
+        _lib.check(lib.sucre_count_valid(C.c_void_p(J.data_ptr()), J.shape[0], J.shape[1], C.c_void_p(count.data_ptr()),
+                                         _stream_ptr()))
+    return int(count.item())
+
+
+def plot_stretch(J: torch.Tensor, lo, hi) -> torch.Tensor:
+    """(H,W,3) uint8: SUCRe.plot_J's clip / shift / scale / x255 / truncate (sucre.py:88-94) of the device image ``J``
+    between the per-channel percentiles ``lo`` and ``hi`` (3 float32 each); invalid pixels black."""
+    lib = _lib.load()
+    assert J.is_cuda and J.dtype == torch.float32 and J.is_contiguous() and J.dim() == 3 and J.shape[2] == 3
+    out = torch.empty(J.shape, dtype=torch.uint8, device=J.device)
+    lo_c = (C.c_float * 3)(*[float(x) for x in lo])
+    hi_c = (C.c_float * 3)(*[float(x) for x in hi])
+    with torch.cuda.device(J.device):
+        _lib.check(lib.sucre_plot_stretch(C.c_void_p(J.data_ptr()), J.shape[0], J.shape[1], lo_c, hi_c,
+                                          C.c_void_p(out.data_ptr()), _stream_ptr()))
     return out
 
 
@@ -491,13 +530,17 @@ def acquire_restoration(height: int, width: int, n_views: int, device='cuda', li
 
 
 @contextlib.contextmanager
-def in_flight_slot(index: int, device='cuda'):
+def in_flight_slot(index: int, device='cuda', wait_for_caller: bool = True):
     """Several images in flight on one GPU.  Code inside the block enqueues on slot ``index``'s own HIP stream and
     ``acquire_restoration`` hands out that slot's own workspace, so image i+1 (slot 1) can be submitted while image
     i (slot 0) is still iterating: the 200 launches of one fit depend on each other, and each ends in a short
     tail where a single workgroup reduces and steps the parameters -- a second image's kernels fill those tails
     (+13 % images/s at 1080p x 65 views, tools/dual_stream_probe.py).  Results of a slot must be read inside a
-    block of the same slot (its stream is then the current one, so ``.cpu()`` waits for the right work)."""
+    block of the same slot (its stream is then the current one, so ``.cpu()`` waits for the right work).
+    ``wait_for_caller=False``: the slot's stream does not wait for what the caller's stream holds -- for callers whose
+    inputs are complete when they are handed over (``sfm.Image.device_view`` publishes a view only once its upload has
+    landed); recording that dependency on the default stream costs the host up to 10 ms per image when other threads
+    keep that stream busy with blocking copies (measured in the CLI, tools/cli_timeline.py)."""
     global _SLOT
     dev = torch.device(device)
     if dev.index is None:
@@ -506,7 +549,8 @@ def in_flight_slot(index: int, device='cuda'):
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(dev)
     stream = _STREAMS[key]
-    stream.wait_stream(torch.cuda.current_stream(dev))   # inputs uploaded / allocations freed on the caller's stream
+    if wait_for_caller:
+        stream.wait_stream(torch.cuda.current_stream(dev))   # inputs uploaded / allocations freed on the caller's stream
     prev, _SLOT = _SLOT, int(index)
     try:
         with torch.cuda.stream(stream):

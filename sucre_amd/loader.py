@@ -21,37 +21,29 @@ import torch
 from torch import Tensor
 from torch.utils.data import DataLoader, Dataset
 
-from . import h5bridge
+from . import _pixelio, h5bridge
 
 MatchesSample = namedtuple('MatchesSample', ['u', 'v', 'cP', 'I'])
 
 
 # ---- pixel loaders ----------------------------------------------------------------------------------------------------
 
+def _decode_pool():
+    """The worker processes, if image files are to be decoded there (SUCRE_DECODE_IN_WORKERS=1).  Off by default: PIL's
+    decoder scales to only ~4 threads' worth over 16 threads, but on the 48-image test survey starting enough workers
+    cost more at start-up (first image submitted after 1.4 s instead of 0.5 s) than their throughput gave back."""
+    return _pixelio.POOL if os.environ.get('SUCRE_DECODE_IN_WORKERS', '0') != '0' else None
+
+
 def _imread_rgb_u8(path: Path) -> np.ndarray:
-    try:
-        import cv2
-        bgr = cv2.imread(str(path))
-        if bgr is None:
-            raise FileNotFoundError(path)
-        return cv2.cvtColor(bgr, cv2.COLOR_BGR2RGB)
-    except ImportError:
-        from PIL import Image as PILImage
-        with PILImage.open(path) as im:
-            return np.asarray(im.convert('RGB'))
+    """The colour image as stored (loader.py:157)."""
+    pool = _decode_pool()
+    return pool.read(path) if pool is not None else _pixelio.imread_rgb_u8(path)
 
 
 def _imread_depth_u16(path: Path) -> np.ndarray:
-    try:
-        import cv2
-        d = cv2.imread(str(path), cv2.IMREAD_UNCHANGED)
-        if d is None:
-            raise FileNotFoundError(path)
-        return d
-    except ImportError:
-        from PIL import Image as PILImage
-        with PILImage.open(path) as im:
-            return np.asarray(im)
+    pool = _decode_pool()
+    return pool.read(path, depth=True) if pool is not None else _pixelio.imread_depth_u16(path)
 
 
 def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor | None:
@@ -165,10 +157,35 @@ def load_depth_raw(depth_map_path: Path, width: int, height: int) -> Tensor | No
     return torch.from_numpy(depth.astype(np.int32))
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity capped by the cgroup CPU quota.  In a container
+    ``os.cpu_count()`` reports the machine (256 on the MI355X boxes) while the quota may be 16 CPUs; thread pools sized
+    by the former get the whole process throttled -- the thread that feeds the GPU included (measured: the CLI's
+    per-image rate fell from 22 to 35 ms with 32 PNG-encoding threads under a 16-CPU quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:   # cgroup v2
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            quota = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read_text())
+            period = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read_text())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def decode_threads(num_workers: int = 0) -> int:
-    """Threads used to decode image files: ``--num-workers`` when given, else SUCRE_DECODE_THREADS (default min(16, cores)).
-    PNG/JPEG decoding releases the GIL, and the result does not depend on who decoded it."""
-    return int(num_workers) if num_workers else max(1, int(os.environ.get('SUCRE_DECODE_THREADS', min(16, os.cpu_count() or 1))))
+    """Threads used to decode image files: ``--num-workers`` when given, else SUCRE_DECODE_THREADS (default: the
+    CPUs this process may use, at most 16).  PNG/JPEG decoding releases the GIL, and the result does not depend on
+    who decoded it."""
+    return int(num_workers) if num_workers else max(1, int(os.environ.get('SUCRE_DECODE_THREADS', min(16, effective_cpus()))))
 
 
 _PREFETCH_POOL: ThreadPoolExecutor | None = None
@@ -373,6 +390,7 @@ class MatchesFile:
     """
 
     _groups = None   # view name -> match lists appended one view at a time (save_matches)
+    _pending_check = None   # (device verdicts, n_views) between check_integrity(defer=True) and finish_integrity
 
     def __init__(self, path: Path, colmap_model=None, overwrite: bool = False):
         self.path = Path(path)
@@ -429,9 +447,12 @@ class MatchesFile:
             return
         self._need()
 
-    def check_integrity(self):
+    def check_integrity(self, defer: bool = False):
         """Device-side counterpart of loader.py:89-101: every stored range must be finite and >= 0 and the
-        per-view totals must add up to n_obs.  One launch checks all views; the verdicts come back in one read."""
+        per-view totals must add up to n_obs.  One launch checks all views; the verdicts come back in one read.
+        ``defer=True`` (not a reference argument) only enqueues the check and leaves its verdicts on the device:
+        ``finish_integrity`` reads them later, so a pipeline can enqueue the fit behind the matching without waiting
+        for either (sucre.restore_images)."""
         if self._groups and self.restoration is None:   # host lists: the reference's own checks, loader.py:89-101
             for name, g in self._groups.items():
                 for key in ('u1', 'v1', 'u2', 'v2', 'd', 'I'):
@@ -443,15 +464,25 @@ class MatchesFile:
                         assert bool((arr >= 0).all()), f'In {self.path}, dataset /{name}/{key} contains invalid value(s).'
             return
         r = self._need()
-        state = torch.cat([r.view_keep().to(torch.int64), r.view_counts().to(torch.int64),
-                           r.check_store().to(torch.int64)]).cpu().numpy()
-        n = r.n_views
-        keep, counts, verdict = state[:n].astype(bool), state[n:2 * n], state[2 * n:]
-        assert int(counts[keep].sum()) == r.n_obs(), f'In {self.path}, observation count mismatch.'
+        self._pending_check = (torch.cat([r.view_keep().to(torch.int64), r.view_counts().to(torch.int64),
+                                          r.check_store().to(torch.int64), r.n_obs_device()]), r.n_views)
+        if not defer:
+            self.finish_integrity()
+
+    def finish_integrity(self) -> int:
+        """Reads the verdicts ``check_integrity`` left on the device, raises like it, and returns n_obs."""
+        if self._pending_check is None:   # host lists: checked on the spot by check_integrity
+            return sum(len(g['u1']) for g in (self._groups or {}).values())
+        state, n = self._pending_check
+        self._pending_check = None
+        state = state.cpu().numpy()
+        keep, counts, verdict, n_obs = state[:n].astype(bool), state[n:2 * n], state[2 * n:3 * n], int(state[3 * n])
+        assert int(counts[keep].sum()) == n_obs, f'In {self.path}, observation count mismatch.'
         for k in np.nonzero(keep)[0]:
             assert not verdict[k] & 1, f'In {self.path}, view {k} contains NaN(s).'
             assert not verdict[k] & 2, f'In {self.path}, view {k} contains null of negative depth(s).'
             assert not verdict[k] & 4, f'In {self.path}, view {k} lost observations.'
+        return n_obs
 
     def load_matches(self, pin_memory: bool = False) -> MatchesData:
         if self._groups and self.restoration is None:   # appended view by view: the reference's own loop, loader.py:103-118

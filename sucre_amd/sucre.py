@@ -23,7 +23,7 @@ import torch
 from PIL import Image as PILImage
 from torch import Tensor
 
-from . import dist as sdist
+from . import _pixelio, dist as sdist
 from . import loader, se3, sfm
 
 
@@ -34,7 +34,11 @@ class SUCRe(torch.nn.Module):
     image itself with NaN where the depth map is invalid, or -- with ``use_closed_form`` -- a plain attribute
     recomputed from the observations."""
 
-    def __init__(self, image: sfm.Image, light_model: bool = False, use_closed_form: bool = False):
+    def __init__(self, image: sfm.Image, light_model: bool = False, use_closed_form: bool = False,
+                 _J_by_engine: bool = False):
+        """``_J_by_engine`` (engine-internal): leave ``J`` uninitialised on the device -- the fit's first kernel
+        (``sucre_fit_init``) writes the very same start values, ``float32(float64(k)/255)`` with NaN where the depth is
+        invalid, and ``adam`` copies the fitted J back; saves the pipeline five torch launches and a host wait per image."""
         super().__init__()
         self.image = image
         self.light_model = light_model
@@ -47,7 +51,10 @@ class SUCRe(torch.nn.Module):
             self.sigma = torch.nn.Parameter(torch.eye(2))
         if not use_closed_form:
             cached = getattr(image, '_device_view', None)
-            if cached is not None and cached[0].type == 'cuda':
+            if _J_by_engine and cached is not None and cached[0].type == 'cuda':
+                J = torch.empty(cached[1].rgb.shape, dtype=torch.float32, device=cached[1].rgb.device)
+                self._J_unset = True
+            elif cached is not None and cached[0].type == 'cuda':
                 # the pixels are already resident for the engine: same values as get_rgb() / get_depth_map()
                 # (float32(float64(k)/255), loader.py:157-163) without decoding the files a second time
                 view = cached[1]
@@ -114,23 +121,19 @@ class SUCRe(torch.nn.Module):
         numpy's linear interpolation between two order statistics of the valid pixels: the engine finds those four
         values per channel by radix select on the device (``sucre_select_ranks``), the ranks and the interpolation
         are numpy's own float32 arithmetic (``percentile_plan`` / ``percentile_lerp``), so the percentiles are the
-        very numbers ``np.percentile`` returns for the whole array; clip, min, max, the divisions and the uint8 cast
-        are IEEE-exact elementwise operations and give the same bits on either side."""
+        very numbers ``np.percentile`` returns for the whole array.  After the clip the minimum is the lower
+        percentile itself and the maximum of the shifted values the float32 difference of the two, so what remains is
+        one elementwise pass of IEEE-exact operations (``sucre_plot_stretch``): the same bits as the host path."""
         from . import engine
         J = self.J.detach().contiguous()
-        ok = ~torch.isnan(J).any(dim=2)
-        n = int(ok.sum())
+        n = engine.count_valid(J)
+        if n == 0:
+            return torch.zeros(J.shape, dtype=torch.uint8, device=J.device)   # (numpy raises on an empty percentile)
         plan = [percentile_plan(n, q) for q in (1, 99)]
         stats = engine.select_ranks(J, [plan[0][0], plan[0][1], plan[1][0], plan[1][1]]).cpu().numpy()   # (3, 4)
         lo = np.array([percentile_lerp(stats[c, 0], stats[c, 1], plan[0][2]) for c in range(3)], np.float32)
         hi = np.array([percentile_lerp(stats[c, 2], stats[c, 3], plan[1][2]) for c in range(3)], np.float32)
-        vals = J[ok]                                              # (n, 3)
-        vals = torch.clamp(vals, torch.from_numpy(lo).to(J.device), torch.from_numpy(hi).to(J.device))
-        vals = vals - vals.amin(dim=0)
-        vals = vals / vals.amax(dim=0)
-        out = torch.zeros_like(J)
-        out[ok] = vals
-        return (out * 255).to(torch.uint8)
+        return engine.plot_stretch(J, lo, hi)
 
     @torch.no_grad()
     def plot_reconstruction(self) -> PILImage.Image:
@@ -172,28 +175,22 @@ class SUCRe(torch.nn.Module):
 
 def _save_png(img: PILImage.Image, path: Path) -> None:
     """Writes ``img`` as a PNG holding exactly its pixels.  PNG is lossless, so only the encoding effort is a choice:
-    8-bit RGB images go through one ``zlib.compress`` call at SUCRE_PNG_COMPRESS_LEVEL (default 1) over Sub-filtered
-    rows -- 2.5x faster than PIL's encoder at the same level and it holds the GIL for none of that time, which is
-    what the CLI's writer threads need; anything else, or SUCRE_PNG_WRITER=pil, is saved by PIL (level 6 is PIL's
-    default and what the reference writes)."""
-    level = int(os.environ.get('SUCRE_PNG_COMPRESS_LEVEL', '1'))
+    8-bit RGB images go through ``_pixelio.encode_rgb`` (Sub-filtered rows, one zlib stream at SUCRE_PNG_COMPRESS_LEVEL,
+    default 1: 2.5-4x faster than PIL's encoder at the same level), in a worker process when the CLI has started some;
+    anything else, or SUCRE_PNG_WRITER=pil, is saved by PIL (level 6 is PIL's default and what the reference writes)."""
+    from . import _pixelio
+    level = _pixelio.default_level()
     if img.mode != 'RGB' or os.environ.get('SUCRE_PNG_WRITER', 'zlib') == 'pil':
         img.save(path, compress_level=level)
-        return
-    import struct
-    import zlib
-    px = np.asarray(img)
-    H, W, _ = px.shape
-    rows = np.empty((H, 1 + 3 * W), np.uint8)
-    rows[:, 0] = 1                                   # filter type 1 (Sub): every byte minus the same channel one pixel left
-    flat = px.reshape(H, 3 * W)
-    rows[:, 1:4] = flat[:, :3]
-    np.subtract(flat[:, 3:], flat[:, :-3], out=rows[:, 4:])
-
-    def chunk(tag: bytes, data: bytes) -> bytes:
-        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', zlib.crc32(tag + data) & 0xffffffff)
-    Path(path).write_bytes(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 2, 0, 0, 0))
-                           + chunk(b'IDAT', zlib.compress(rows.tobytes(), level)) + chunk(b'IEND', b''))
+    else:
+        pool = _pixelio.POOL
+        if pool is not None:
+            try:
+                pool.write(path, np.asarray(img), level)
+                return
+            except _pixelio.WorkerLost as e:
+                print(f'warning: {e}; writing {path} in-process')
+        _pixelio.write_rgb(str(path), np.asarray(img), level)
 
 
 def percentile_plan(n: int, q: float) -> tuple[int, int, np.floating]:
@@ -253,6 +250,7 @@ def _pull_results(sucre: SUCRe, resto) -> None:
             sucre.J = J
         else:
             sucre.J.copy_(J)
+            sucre._J_unset = False
 
 
 def _format_trace(trace: np.ndarray, first_iteration: int) -> str:
@@ -298,7 +296,9 @@ def adam(sucre: SUCRe, matches_data: loader.MatchesData, lr: float = 0.05, num_i
     return sucre
 
 
-def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData):
+def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData, params0: np.ndarray | None = None):
+    """``params0``: the model's water (and light) parameters when the caller already has them on the host; reading
+    them from the module costs a device-to-host copy, i.e. a wait for everything enqueued on the stream."""
     resto = _restoration_of(matches_data, sucre)
     if sucre.light_model and not resto.light:
         raise RuntimeError('these matches were computed without light_model=True: the camera points the light model '
@@ -306,8 +306,10 @@ def _adam_begin(sucre: SUCRe, matches_data: loader.MatchesData):
     target = sucre.image.device_view(resto.device)
     if resto.float_colour:
         target = target.as_float_colour()
-    J0 = None if sucre.use_closed_form else sucre.J.detach()
-    resto.fit_init(target, params0=sucre.water_vector().detach().cpu().numpy(), J0=J0)
+    J0 = None if (sucre.use_closed_form or getattr(sucre, '_J_unset', False)) else sucre.J.detach()
+    if params0 is None:
+        params0 = sucre.water_vector().detach().cpu().numpy()
+    resto.fit_init(target, params0=params0, J0=J0)
     return resto
 
 
@@ -320,14 +322,30 @@ class _Job:
 
 def _restore_submit(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: Path, light_model: bool,
                     use_closed_form: bool, min_cover: float, image_list: list[sfm.Image], lr: float, num_iter: int,
-                    params_path: Path, force_compute_matches: bool, num_workers: int, device: str) -> _Job:
-    """Stages of sucre.py:160-210 up to and including the enqueued fit; the trace and J stay on the device."""
+                    params_path: Path, force_compute_matches: bool, num_workers: int, device: str,
+                    defer_checks: bool = False) -> _Job:
+    """Stages of sucre.py:160-210 up to and including the enqueued fit; the trace and J stay on the device.
+    ``defer_checks``: the integrity verdicts and the observation count stay on the device until ``_restore_finish``
+    reads them with the results -- waiting for them here would make the host wait for the matching, which shares the
+    GPU with the previous image's fit, before it can enqueue this image's fit (measured: 7-37 ms per image)."""
     print(f'Restore {image.name}.')
     output_dir = Path(output_dir)
     matches_path = (output_dir / image.name).with_suffix('.h5')
     matches_file = loader.MatchesFile(matches_path, colmap_model=colmap_model, overwrite=force_compute_matches)
     if image_list is None:
         image_list = list(colmap_model.images.values())
+
+    # The model is built before the matching is enqueued (the reference builds it after, sucre.py:199; the two do not
+    # depend on each other): moving its parameters to the device is a host-to-device copy, which the host waits for,
+    # and behind the matching on the same stream that wait would last until the matching is done.
+    if str(device).startswith('cuda'):
+        image.device_view(device)   # J starts from the resident pixels (SUCRe.__init__)
+    sucre = SUCRe(image=image, light_model=light_model, use_closed_form=use_closed_form,
+                  _J_by_engine=defer_checks and params_path is None)
+    if params_path is not None:
+        sucre.load_state_dict(torch.load(params_path), strict=False)
+    params0 = sucre.water_vector().detach().cpu().numpy()   # still on the host: no wait
+    sucre = sucre.to(device)
 
     if force_compute_matches or light_model or not matches_file.on_disk():
         print(f'Compute {image.name} matches.')
@@ -338,24 +356,27 @@ def _restore_submit(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir:
     else:  # a kept matches file (ours or the reference's): consumed as is, like sucre.py:185
         matches_file.load_file(image, device=device)
     print('Check matches integrity.')
-    matches_file.check_integrity()
+    matches_file.check_integrity(defer=defer_checks)
     print('Load matches.')
     matches_data = matches_file.load_matches(pin_memory=False)
-    print(f'Total of {len(matches_data)} observations.')
-    if len(matches_data) == 0:
-        raise RuntimeError(f'{image.name}: no observation survived matching; nothing to fit')
+    if not defer_checks:
+        _report_observations(image, len(matches_data))
 
-    sucre = SUCRe(image=image, light_model=light_model, use_closed_form=use_closed_form).to(device)
-    if params_path is not None:
-        sucre.load_state_dict(torch.load(params_path), strict=False)
     return _Job(image=image, sucre=sucre, matches_file=matches_file, matches_data=matches_data,
-                matches_path=matches_path, output_dir=output_dir, lr=lr, num_iter=num_iter, trace=None)
+                matches_path=matches_path, output_dir=output_dir, lr=lr, num_iter=num_iter, trace=None,
+                deferred_checks=defer_checks, params0=params0)
+
+
+def _report_observations(image: sfm.Image, n_obs: int) -> None:
+    print(f'Total of {n_obs} observations.')
+    if n_obs == 0:
+        raise RuntimeError(f'{image.name}: no observation survived matching; nothing to fit')
 
 
 def _restore_enqueue_fit(job: _Job) -> None:
     """The whole fit of sucre.py:138-156 enqueued in one go (no intermediate plots): no host synchronisation."""
     print(f'Solve least squares with Adam optimizer ({job.num_iter} iterations).')
-    resto = _adam_begin(job.sucre, job.matches_data)
+    resto = _adam_begin(job.sucre, job.matches_data, params0=job.params0)
     job.trace = resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
 
 
@@ -364,6 +385,8 @@ def _restore_finish(job: _Job, keep_matches: bool, writers: ThreadPoolExecutor |
     ``writers`` pool the files are written in the background -- percentile stretch, PNG encoding and the .pt take
     ~1 s of host time per 1080p image, 30x the GPU time -- and the future is returned instead of the model."""
     sucre = job.sucre
+    if job.deferred_checks:   # raises what check_integrity / the empty-list test would have raised before the fit
+        _report_observations(job.image, job.matches_file.finish_integrity())
     if job.trace is not None:
         job.trace = job.trace.cpu().numpy()
         if writers is None:
@@ -407,17 +430,23 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
 def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, output_dir: Path, in_flight: int = 2,
                    keep_matches: bool = False, device: str = 'cuda', **kw) -> None:
     """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot)
-    and the output files written by background threads (SUCRE_WRITER_THREADS, default min(32, cores)).  While image i iterates,
+    and the output files written by background threads (SUCRE_WRITER_THREADS).  While image i iterates,
     image i+1 is matched and submitted and the plots of images < i are encoded, so neither the tails of the fit
     launches nor the PNG encoding leave the GPU idle.  Per-image results are the same bits as ``restore_image``
     (each image has its own workspace and stream; nothing is shared)."""
     from . import engine
     pending: list[tuple[int, _Job]] = []
     written = []
-    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(32, os.cpu_count() or 1)))),
+    _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw)
+
+
+def _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw) -> None:
+    from . import engine
+    # writer threads: the CPUs this process may use minus two (this thread and the HIP runtime's), at most 32
+    with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(32, loader.effective_cpus() - 2)))),
                             thread_name_prefix='sucre-write') as writers:
         def finish(slot, job):
-            with engine.in_flight_slot(slot, device):
+            with engine.in_flight_slot(slot, device, wait_for_caller=False):
                 written.append(_restore_finish(job, keep_matches, writers))
             while len(written) > 64:                  # bound the host memory held by queued outputs (~50 MB each)
                 written.pop(0).result()
@@ -426,8 +455,8 @@ def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, outpu
             slot = i % in_flight
             while pending and (len(pending) >= in_flight or pending[0][0] == slot):
                 finish(*pending.pop(0))
-            with engine.in_flight_slot(slot, device):
-                job = _restore_submit(image, colmap_model, output_dir, device=device, **kw)
+            with engine.in_flight_slot(slot, device, wait_for_caller=False):   # inputs: Image.device_view, complete
+                job = _restore_submit(image, colmap_model, output_dir, device=device, defer_checks=True, **kw)
                 _restore_enqueue_fit(job)
             pending.append((slot, job))
         for slot, job in pending:
@@ -458,10 +487,24 @@ def parse_args(args: argparse.Namespace):
     skipped = set(args.filter_images_path.read_text().splitlines()) if args.filter_images_path else set()
     image_list = [im for im in colmap_model.images.values() if im.name not in skipped]
     args.output_dir.mkdir(parents=True, exist_ok=True)
+    in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
+    survey = len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda')
+    if survey:
+        # the result pictures are encoded by child processes (_pixelio.WorkerPool: CPU work in the process that drives
+        # the GPU slows its launches down); SUCRE_IO_PROCESSES=0 keeps the encoding in this process's writer threads
+        n_io = int(os.environ.get('SUCRE_IO_PROCESSES', min(8, max(1, loader.effective_cpus() // 2))))
+        if n_io > 0:
+            _pixelio.start_pool(n_io)
+    try:
+        _run_request(args, images, image_list, colmap_model, device, survey, in_flight)
+    finally:
+        _pixelio.stop_pool()
+
+
+def _run_request(args, images, image_list, colmap_model, device, survey: bool, in_flight: int) -> None:
     if str(device).startswith('cuda') and images:   # start decoding + uploading the scene now, in the background
         loader.prefetch_for_targets(images, image_list, device, num_workers=args.num_workers, min_cover=args.min_cover)
-    in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
-    if len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda'):
+    if survey:
         restore_images(images, colmap_model, args.output_dir, in_flight=in_flight, keep_matches=args.keep_matches,
                        device=device, light_model=args.light_model, use_closed_form=args.use_closed_form,
                        min_cover=args.min_cover, image_list=image_list, lr=args.learning_rate, num_iter=args.num_iter,

@@ -320,14 +320,19 @@ def test_cli_images_in_flight_equal_one_by_one(disk_scene, tmp_path, monkeypatch
 
 
 def test_plot_J_on_the_device_equals_the_host_path():
-    """SUCRe.plot_J with J on the GPU (percentiles by numpy on the host, everything else on the device) must give
-    the same image as the host path, which tests/test_host_logic.py pins to reference-made images."""
+    """SUCRe.plot_J with J on the GPU (order statistics by radix select, one stretch kernel: sucre_select_ranks,
+    sucre_plot_stretch) must give the same image as the host path, which tests/test_host_logic.py pins to
+    reference-made images -- also when a NaN sits in one channel only, when values repeat, and for negative values."""
     from sucre_amd import sucre
     g = torch.Generator().manual_seed(5)
-    for H, W in ((97, 131), (480, 640)):
+    for H, W in ((97, 131), (480, 640), (33, 1)):
         J = torch.rand((H, W, 3), generator=g) ** 2 * 1.3 - 0.1
         J[torch.rand((H, W), generator=g) < 0.03] = float('nan')
         J[0, :7] = float('nan')
+        J[H // 2, 0, 1] = float('nan')                      # one channel only: the whole pixel is invalid
+        if W > 100:
+            J[5:9, 10:90] = J[5, 10].clone()                # runs of equal values around the order statistics
+            J[20:30, :, 2] = torch.round(J[20:30, :, 2] * 8) / 8
         m = sucre.SUCRe.__new__(sucre.SUCRe)
         torch.nn.Module.__init__(m)
         m.J = J.clone()

@@ -507,3 +507,52 @@ def test_png_writer_keeps_every_pixel(tmp_path, monkeypatch):
     g = rng.integers(0, 256, size=(9, 11), dtype=np.uint8)
     sucre._save_png(PILImage.fromarray(g), tmp_path / 'g.png')
     assert np.array_equal(np.array(PILImage.open(tmp_path / 'g.png')), g)
+
+
+def test_png_writer_processes(tmp_path, monkeypatch):
+    """_png.WriterPool (the CLI's PNG encoding, moved out of the process that drives the GPU): files written by the
+    child processes decode to the very pixels, errors come back as exceptions, workers start on demand."""
+    import threading
+    from PIL import Image as PILImage
+    from sucre_amd import _pixelio as _png
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, size=(40 + i, 64, 3), dtype=np.uint8) for i in range(6)]
+    pool = _png.WorkerPool(2)
+    try:
+        assert pool._procs == []
+        threads = [threading.Thread(target=pool.write, args=(tmp_path / f'{i}.png', a)) for i, a in enumerate(imgs)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert 1 <= len(pool._procs) <= 2
+        for i, a in enumerate(imgs):
+            assert np.array_equal(np.array(PILImage.open(tmp_path / f'{i}.png')), a)
+        with pytest.raises(FileNotFoundError, match='No such file'):
+            pool.write(tmp_path / 'missing' / 'x.png', imgs[0])
+        pool.write(tmp_path / 'again.png', imgs[1])      # the worker survives a failed write
+        assert np.array_equal(np.array(PILImage.open(tmp_path / 'again.png')), imgs[1])
+        # decoding through the workers = decoding in-process, for colour and 16-bit depth files
+        depth = rng.integers(0, 65536, size=(23, 31)).astype(np.uint16)
+        PILImage.fromarray(depth).save(tmp_path / 'd.png')
+        got = pool.read(tmp_path / 'd.png', depth=True)
+        assert got.dtype == np.uint16 and np.array_equal(got, depth)
+        assert np.array_equal(pool.read(tmp_path / '0.png'), imgs[0])
+        with pytest.raises(FileNotFoundError):
+            pool.read(tmp_path / 'nope.png')
+        victim = pool._free.get(); pool._free.put(victim)   # a worker that dies is retired, the caller is told
+        victim.kill(); victim.wait()
+        lost = 0
+        for _ in range(3):
+            try:
+                pool.write(tmp_path / 'after.png', imgs[2])
+            except _png.WorkerLost:
+                lost += 1
+        assert lost <= 1 and np.array_equal(np.array(PILImage.open(tmp_path / 'after.png')), imgs[2])
+        _png.POOL = pool                                   # and loader's readers go through the pool when asked to
+        monkeypatch.setenv('SUCRE_DECODE_IN_WORKERS', '1')
+        try:
+            assert np.array_equal(loader._imread_rgb_u8(tmp_path / '1.png'), imgs[1])
+            assert np.array_equal(loader._imread_depth_u16(tmp_path / 'd.png'), depth)
+        finally:
+            _png.POOL = None
+    finally:
+        pool.close()

@@ -45,15 +45,77 @@ def main():
                         (sfm.Image, 'depth_range'), (engine.Restoration, '__init__'), (engine.Restoration, 'fit_init'),
                         (engine.Restoration, 'fit'), (sfm, 'COLMAPModel'), (loader, 'prefetch_for_targets')):
         wrap(owner, name, f'{getattr(owner, "__name__", owner)}.{name}'.replace('sucre_amd.', ''))
+    import os
+    if os.environ.get('TIMELINE_NO_OUTPUTS'):   # experiment: what does the loop cost without the output stage?
+        sucre._write_outputs = lambda job, keep, log=False: None
+    if os.environ.get('TIMELINE_NO_PLOTS'):
+        sucre.SUCRe.save_plots = lambda self, save_dir, iteration=None: None
+    if os.environ.get('TIMELINE_NO_PNG'):
+        sucre._save_png = lambda img, path: None
+    if os.environ.get('TIMELINE_PNG_SLEEP'):
+        sucre._save_png = lambda img, path: time.sleep(0.08)
+    if os.environ.get('TIMELINE_PNG_BURN'):
+        import zlib
+        blob = os.urandom(1 << 20) * 6
+        sucre._save_png = lambda img, path: zlib.compress(blob, 1)
+    if os.environ.get('TIMELINE_PNG_NOWRITE'):
+        import pathlib
+        real = pathlib.Path.write_bytes
+        pathlib.Path.write_bytes = lambda self, data: len(data) if str(self).endswith('.png') else real(self, data)
+    if os.environ.get('TIMELINE_PNG_PROCS'):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        import numpy as np
+        from sucre_amd import _pixelio as _png
+        pool = ProcessPoolExecutor(int(os.environ['TIMELINE_PNG_PROCS']), mp_context=mp.get_context('spawn'))
+        list(pool.map(abs, range(64)))   # start the workers now
+        sucre._save_png = lambda img, path: pool.submit(_png.write_rgb, str(path), np.asarray(img), 1).result()
+    if os.environ.get('TIMELINE_NO_RECON'):
+        from PIL import Image as _PI
+        sucre.SUCRe.plot_reconstruction = lambda self: _PI.new('RGB', (8, 8))
+    if os.environ.get('TIMELINE_NO_PLOTJ'):
+        from PIL import Image as _PI
+        sucre.SUCRe.plot_J = lambda self: _PI.new('RGB', (8, 8))
+    if os.environ.get('TIMELINE_SWITCH'):
+        sys.setswitchinterval(float(os.environ['TIMELINE_SWITCH']))
+    from sucre_amd import _lib
+    lib = _lib.load()
+    for name in ('sucre_match_views', 'sucre_finalize_matches_fmt', 'sucre_check_store', 'sucre_fit_init', 'sucre_fit_run',
+                 'sucre_export_J', 'sucre_select_ranks'):
+        wrap(lib, name, 'lib.' + name)
+    wrap(torch.Tensor, 'to', 'Tensor.to'); wrap(torch.Tensor, 'cpu', 'Tensor.cpu'); wrap(torch.Tensor, 'item', 'Tensor.item')
+    wrap(torch.cuda.Stream, 'synchronize', 'Stream.synchronize'); wrap(torch.cuda.Stream, 'wait_stream', 'Stream.wait_stream')
     with tempfile.TemporaryDirectory() as tmp:
         root = Path(tmp)
         synth.write_to_disk(survey, root)
         first = 1 if n >= gx * gy else gx * (gy // 2) + 1
         argv = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
                 '--output-dir', str(root / 'out'), '--image-ids', str(first), str(first + n)]
+        def throttled():
+            try:
+                return dict(line.split() for line in open('/sys/fs/cgroup/cpu.stat').read().splitlines())
+            except OSError:
+                return {}
+        ALLOCS = []
+        real_finish = sucre._restore_finish
+
+        def counting_finish(*a, **kw):
+            st = torch.cuda.memory_stats()
+            ALLOCS.append((st.get('num_device_alloc', 0), st.get('num_device_free', 0), st.get('reserved_bytes.all.current', 0) >> 20))
+            return real_finish(*a, **kw)
+        sucre._restore_finish = counting_finish
+        before = throttled()
         T0[0] = time.perf_counter()
         sucre.main(argv)
         dt = time.perf_counter() - T0[0]
+        after = throttled()
+        if after:
+            print('cgroup: cpu used %.2f s, throttled %d periods / %.3f s' % (
+                (int(after['usage_usec']) - int(before['usage_usec'])) * 1e-6,
+                int(after['nr_throttled']) - int(before['nr_throttled']),
+                (int(after['throttled_usec']) - int(before['throttled_usec'])) * 1e-6))
+    print('device allocations (hipMalloc, hipFree, reserved MiB) at finish 1, 10, 20, 30, last:',
+          [ALLOCS[i] for i in (0, 9, 19, 29, len(ALLOCS) - 1) if i < len(ALLOCS)])
     print(f'CLI: {n} images in {dt:.2f}s = {dt / n * 1e3:.0f} ms/image')
     tot = defaultdict(lambda: [0, 0.0])
     for th, label, a, b in SPANS:
@@ -68,10 +130,20 @@ def main():
             ('sucre._restore_submit', 'sucre._restore_enqueue_fit', 'sucre._restore_finish')]
     for a, b, label in sorted(rows)[:40]:
         print(f'  {a:7.3f} {b:7.3f} {(b - a) * 1e3:7.1f} ms  {label}')
+    third = sorted((a, b) for th, label, a, b in SPANS if th == 'MainThread' and label == 'sucre._restore_submit')
+    lo, hi = third[20][0], third[22][0]
+    print('main thread, images 21-22:')
+    for a, b, label in sorted((a, b, label) for th, label, a, b in SPANS if th == 'MainThread' and lo <= a < hi):
+        if b - a > 0.0002:
+            print(f'  {a:7.4f} {b:7.4f} {(b - a) * 1e3:7.2f} ms  {label}')
     print('everything the main thread did before the second image was submitted:')
     second = sorted(a for th, label, a, b in SPANS if th == 'MainThread' and label == 'sucre._restore_submit')[1]
     for a, b, label in sorted((a, b, label) for th, label, a, b in SPANS if th == 'MainThread' and a < second):
         print(f'  {a:7.3f} {b:7.3f} {(b - a) * 1e3:7.1f} ms  {label}')
+    fin = sorted((a, b) for th, label, a, b in SPANS if th == 'MainThread' and label == 'sucre._restore_finish')
+    sub = sorted((a, b) for th, label, a, b in SPANS if th == 'MainThread' and label == 'sucre._restore_submit')
+    print(f'first submit {sub[0][0]:.3f}-{sub[0][1]:.3f}; finishes: first {fin[0][1]:.3f}, 10th {fin[9][1]:.3f}, last {fin[-1][1]:.3f} '
+          f'-> {(fin[-1][1] - fin[9][1]) / (len(fin) - 10) * 1e3:.1f} ms per image in the loop; total {dt:.3f}')
     w = sorted((a, b) for th, label, a, b in SPANS if label == 'sucre._write_outputs')
     print('write_outputs: first start %.3f, last end %.3f, mean %.0f ms' % (w[0][0], max(b for _, b in w), sum(b - a for a, b in w) / len(w) * 1e3))
     d = sorted((a, b) for th, label, a, b in SPANS if label == 'loader._imread_rgb_u8')
