@@ -24,7 +24,9 @@
  * for every (tile, view) pair, one 1792-byte chunk = 256 float32 ranges z=||cP|| (0 = no observation) + 256 x 3
  * uint8 colours (7 B/observation instead of the reference's 28-byte (u,v,cP,I) records, loader.py:33-53,103-118,
  * and its HDF5 spill); sucre_finalize_matches then compacts them per pixel, sorted by observation count, into the
- * store the fit streams.  J and the Adam moments are float32 planes in that sorted pixel order.
+ * store the fit streams: the sorted pixels are cut into strips of 64 (one pixel per lane of the wave that fits the
+ * strip), a strip's observations are stored as chunks of 64 pixels x 4 levels, and finalize also writes every fit
+ * wave's list of items to stream (the plan).  J and the Adam moments are float32 planes per strip in that sorted order.
  */
 #ifndef SUCRE_HIP_H
 #define SUCRE_HIP_H

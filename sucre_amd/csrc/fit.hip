@@ -5,7 +5,7 @@
 // the ten global sums and -- in the workgroup that arrives last -- applies Adam to B, beta, gamma and logs the row.
 // The split form (launch_fit_grad + launch_fit_step) leaves the sums in the workspace for a host all-reduce.
 //
-// Work decomposition: 1536 persistent 256-thread workgroups; every WAVE works alone on strips of 64 count-sorted
+// Work decomposition: 256 x kFitWaves (1280) persistent 256-thread workgroups; every WAVE works alone on strips of 64 count-sorted
 // pixels (csrc/compact.hip, layout.h), one pixel per lane, and never synchronises with the other waves until the
 // launch's final reduction.  A strip is a sequence of ITEMS -- its J plane (768 B), its observation chunks (64 pixels
 // x 4 levels, 1792 B; the last one may hold fewer levels) and, in J-parameter mode, its Adam moments (1536 B) --

@@ -522,15 +522,25 @@ class MatchesFile:
         """True when a matches file written earlier (by this engine or by the reference) can be loaded."""
         return (self.path.exists() and h5bridge.available()) or self._npz_path.exists()
 
-    def load_file(self, target_image, device='cuda') -> None:
+    def load_file(self, target_image, device='cuda', light: bool = False) -> None:
         """Consumes an existing HDF5 matches file instead of matching (what the reference does when the file is
         already there, sucre.py:185): every group becomes one view of the engine's store.  cP / z are rebuilt like
-        loader.py:113 + sucre.py:53 (float32, same operation order as the match kernel)."""
+        loader.py:113 + sucre.py:53 (float32, same operation order as the match kernel).  ``light``: the store also
+        keeps cP per observation, which the artificial-light model needs (the reference derives it from the same
+        ``u2, v2, d`` every time it loads the file).  Kept colours that are not multiples of 1/255 (matches of resized
+        images, --image-scale) are carried as float32 colours."""
         from . import engine
         if self.path.exists() and h5bridge.available():
             groups = h5bridge.read_groups(self.path)
         else:
             groups = h5bridge.read_npz_groups(self._npz_path)
+        float_colour = False
+        for ds in groups.values():
+            k255 = ds['I'].astype(np.float64) * 255
+            float_colour = float_colour or bool(k255.size and np.abs(k255 - np.rint(k255)).max() > 1e-3)
+        if float_colour and light:
+            raise NotImplementedError(f'{self.path}: --light-model on kept matches of resized images (float32 colours and '
+                                      f'the camera points share the same extension planes)')
         images, lists = [], []
         for name, ds in groups.items():
             im = self.colmap_model[name]
@@ -540,15 +550,19 @@ class MatchesFile:
             u2, v2 = torch.tensor(ds['u2']), torch.tensor(ds['v2'])
             cP = im.unproject_depth(u=u2, v=v2, d=torch.tensor(ds['d']))
             z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
-            k255 = ds['I'].astype(np.float64) * 255
-            if k255.size and np.abs(k255 - np.rint(k255)).max() > 1e-3:
-                raise NotImplementedError(f'{self.path}: the kept colours are not multiples of 1/255 (matches of '
-                                          f'resized images); re-match with --force-compute-matches')
-            rgb = torch.tensor(np.rint(k255).astype(np.uint8).T.copy())
+            item = [torch.tensor(ds['u1']), torch.tensor(ds['v1']), z]
+            if float_colour:
+                item += [None, torch.tensor(ds['I'].astype(np.float32)).reshape(3, -1)]
+            else:
+                item.append(torch.tensor(np.rint(ds['I'].astype(np.float64) * 255).astype(np.uint8).T.copy()))
+                if light:
+                    item.append(cP.to(torch.float32).reshape(3, -1))
             images.append(im)
-            lists.append((torch.tensor(ds['u1']), torch.tensor(ds['v1']), z, rgb))
-        resto = engine.acquire_restoration(target_image.camera.height, target_image.camera.width, len(lists), device)
-        resto.import_matches(target_image.device_view(device), lists)
+            lists.append(tuple(item))
+        resto = engine.acquire_restoration(target_image.camera.height, target_image.camera.width, len(lists), device,
+                                           light=light, float_colour=float_colour)
+        target = target_image.device_view(device)
+        resto.import_matches(target.as_float_colour() if float_colour else target, lists)
         self.attach(resto, target_image=target_image, image_list=images)
 
     def __len__(self) -> int:
