@@ -105,6 +105,22 @@ class _PixelCache:
                 old._device_view = None     # benign race with a reader: it holds its own reference or re-decodes
                 self.total -= n
 
+    def grow(self, image: 'Image', extra: int, dev: torch.device) -> None:
+        """More bytes now hang on ``image``'s entry (the float32 colour twin of its view, 12 B/pixel)."""
+        with self.lock:
+            ent = self.entries.get(id(image))
+            if ent is None:
+                return
+            self.entries[id(image)] = (image, ent[1] + extra)
+            self.total += extra
+            while self.total > self.budget(dev) and len(self.entries) > 1:
+                key, (old, n) = next(iter(self.entries.items()))
+                if old is image:
+                    break
+                del self.entries[key]
+                old._device_view = None
+                self.total -= n
+
     def forget(self, image: 'Image') -> None:
         with self.lock:
             ent = self.entries.pop(id(image), None)
@@ -273,6 +289,9 @@ class Image:
             if light_model:
                 raise NotImplementedError('--light-model together with resized images (--image-scale != 1): the light '
                                           'model and float32 colours share the same extension planes')
+            for im, v in zip(image_list + [self], views + [target]):   # the float32 twins count against the cache budget
+                if v.rgb.dtype != torch.float32 and '_float_twin' not in v.__dict__:
+                    PIXEL_CACHE.grow(im, v.rgb.numel() * 4, _canonical_device(device))
             views = [v.as_float_colour() for v in views]
             target = target.as_float_colour()
         resto = engine.acquire_restoration(self.camera.height, self.camera.width, len(views), device, light=light_model,

@@ -306,6 +306,16 @@ def test_pixel_cache_evicts_least_recently_used(monkeypatch):
     assert cache.total == 100
     cache.insert(a, 1000, dev)          # a single image larger than the budget still stays (it is in use)
     assert a._device_view is not None and c._device_view is None and cache.total == 1000
+    # bytes added to an entry later (the float32 colour twin of a view) count too and may evict others, never itself
+    cache = sfm._PixelCache(); cache._budget = 250
+    a, b = Fake(), Fake()
+    cache.insert(a, 100, dev); cache.insert(b, 100, dev)
+    cache.grow(b, 100, dev)
+    assert cache.total == 200 and a._device_view is None and b._device_view is not None
+    cache.grow(b, 500, dev)
+    assert cache.total == 700 and b._device_view is not None
+    cache.grow(a, 50, dev)              # a is no longer cached: nothing to grow
+    assert cache.total == 700
 
 
 def test_matches_plot_draws_side_by_side(tmp_path):
