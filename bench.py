@@ -54,8 +54,9 @@ def parse():
     p.add_argument('--solo-images', type=int, default=3,
                    help='images restored one at a time after the timed region for the roofline block')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-views', type=int, default=25, help='views in the CPU-baseline sample')
-    p.add_argument('--cpu-iters', type=int, default=30, help='Adam iterations in the CPU-baseline sample')
+    p.add_argument('--cpu-views', type=int, default=65, help='views in the CPU-baseline sample (65 = all of config 2)')
+    p.add_argument('--cpu-iters', type=int, default=100, help='Adam iterations in the CPU-baseline sample (~15 s of CPU '
+                                                             'work on 16 cores together with the matching)')
     return p.parse_args()
 
 

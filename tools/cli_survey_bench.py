@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end timing of the reference-compatible CLI on a synthetic survey written to disk (PNG images, uint16
 depth maps, COLMAP text model): where does a user's wall time go once the GPU part takes ~30 ms per image?
-usage (GPU box): python3 tools/cli_survey_bench.py [width height grid_x grid_y n_restore]"""
+usage (GPU box): python3 tools/cli_survey_bench.py [width height grid_x grid_y n_restore [spacing]]"""
 import cProfile
 import io
 import os
@@ -21,8 +21,9 @@ from sucre_amd import sfm, sucre, synth  # noqa: E402
 
 
 def main():
-    W, H, gx, gy, n = (int(a) for a in (sys.argv[1:6] + [1920, 1080, 6, 5, 8][len(sys.argv) - 1:]))
-    survey = synth.make_survey(W, H, gx, gy, seed=3, device='cuda')
+    W, H, gx, gy, n = (int(a) for a in (sys.argv[1:6] + [1920, 1080, 6, 5, 8][len(sys.argv[1:6]):]))
+    spacing = float(sys.argv[6]) if len(sys.argv) > 6 else 0.1   # camera spacing in footprints (0.1 = 90 % overlap)
+    survey = synth.make_survey(W, H, gx, gy, seed=3, spacing=spacing, device='cuda')
     with tempfile.TemporaryDirectory() as tmp:
         root = Path(tmp)
         t0 = time.perf_counter()
@@ -41,6 +42,9 @@ def main():
             pr.disable()
         dt = time.perf_counter() - t0
         print(f'CLI: {n} images in {dt:.2f}s = {dt / n * 1e3:.0f} ms/image' + (' (under cProfile)' if profile else ''), flush=True)
+        from sucre_amd import engine
+        print(f'model of {len(survey.views)} images; workspaces held at the end (views of capacity, GB):',
+              sorted((r.capacity, round(r.ws.numel() / 2 ** 30, 2)) for r in engine._POOL.values()), flush=True)
         if not profile:
             return
         s = io.StringIO()
