@@ -131,6 +131,25 @@ class _PixelCache:
 PIXEL_CACHE = _PixelCache()
 
 
+_STACKED: dict = {}
+
+
+def _stacked_cameras(image_list):
+    """float64 stacks (R, t, K, W, H) of the images' poses and cameras, kept for the list that was asked about last (a
+    survey asks about the same list for every target)."""
+    key = (len(image_list), id(image_list[0]), id(image_list[-1]), id(image_list[len(image_list) // 2]))
+    hit = _STACKED.get('entry')
+    if hit is None or hit[0] != key:
+        R = np.stack([im.pose.R.numpy() for im in image_list]).astype(np.float64)              # (N, 3, 3) world-from-camera
+        t = np.stack([im.pose.t.numpy() for im in image_list]).astype(np.float64)              # (N, 3, 1)
+        K = np.stack([im.camera.K.numpy() for im in image_list]).astype(np.float64)
+        W2 = np.array([im.camera.width for im in image_list], np.float64).reshape(-1, 1)
+        H2 = np.array([im.camera.height for im in image_list], np.float64).reshape(-1, 1)
+        hit = (key, (R, t, K, W2, H2))
+        _STACKED['entry'] = hit
+    return hit[1]
+
+
 class Image:
     def __init__(self, image_id: int, rgb_path: Path, depth_map_path: Path, pose: Pose, camera: Camera):
         self.id = image_id
@@ -235,25 +254,25 @@ class Image:
         rng = self.depth_range(device)
         if rng is None or not image_list:
             return list(range(len(image_list)))
+        # numpy, not torch: for a model of a few hundred images torch's CPU kernels wake their whole OpenMP team (one
+        # thread per CPU of the machine, spinning after every call), which under a container's CPU quota got the process
+        # throttled and made this function take 50-140 ms
         W1, H1 = self.camera.width, self.camera.height
-        Kinv = self.camera.K.double().inverse()
-        px = torch.tensor([[0.0, W1, 0.0, W1], [0.0, 0.0, H1, H1], [1.0, 1.0, 1.0, 1.0]], dtype=torch.float64)
+        Kinv = np.linalg.inv(self.camera.K.double().numpy())
+        px = np.array([[0.0, W1, 0.0, W1], [0.0, 0.0, H1, H1], [1.0, 1.0, 1.0, 1.0]])
         rays = Kinv @ px                                                        # (3, 4): z component is 1
-        cP = torch.cat([rays * rng[0], rays * rng[1]], dim=1)                   # (3, 8) hull corners, camera frame
-        wP = self.pose.R.double() @ cP + self.pose.t.double()                   # world frame
-        R = torch.stack([im.pose.R for im in image_list]).double()             # (N, 3, 3) world-from-camera
-        t = torch.stack([im.pose.t for im in image_list]).double()             # (N, 3, 1)
-        K = torch.stack([im.camera.K for im in image_list]).double()
-        c = K @ (R.transpose(1, 2) @ (wP.unsqueeze(0) - t))                     # (N, 3, 8)
-        W2 = torch.tensor([im.camera.width for im in image_list], dtype=torch.float64).view(-1, 1)
-        H2 = torch.tensor([im.camera.height for im in image_list], dtype=torch.float64).view(-1, 1)
+        cP = np.concatenate([rays * rng[0], rays * rng[1]], axis=1)             # (3, 8) hull corners, camera frame
+        wP = self.pose.R.double().numpy() @ cP + self.pose.t.double().numpy()   # world frame
+        R, t, K, W2, H2 = _stacked_cameras(image_list)
+        rel = wP[None] - t                                                      # (N, 3, 8)
+        c = np.einsum('nij,njk->nik', K, np.einsum('nji,njk->nik', R, rel))     # K (R^T (P - t))
         c0, c1, c2 = c[:, 0], c[:, 1], c[:, 2]
-        a = torch.stack([c0 + (1 + margin) * c2, (W2 + margin) * c2 - c0,
-                         c1 + (1 + margin) * c2, (H2 + margin) * c2 - c1], dim=1)      # (N, 4, 8); inside the cone: all > 0
-        misses_cone = (a <= 0).all(dim=2).any(dim=1)      # some half-space excludes every corner
-        misses_mirror = (a >= 0).all(dim=2).any(dim=1)    # inside the mirrored cone: all < 0
+        a = np.stack([c0 + (1 + margin) * c2, (W2 + margin) * c2 - c0,
+                      c1 + (1 + margin) * c2, (H2 + margin) * c2 - c1], axis=1)          # (N, 4, 8); inside the cone: all > 0
+        misses_cone = (a <= 0).all(axis=2).any(axis=1)      # some half-space excludes every corner
+        misses_mirror = (a >= 0).all(axis=2).any(axis=1)    # inside the mirrored cone: all < 0
         keep = ~(misses_cone & misses_mirror)
-        return torch.nonzero(keep).flatten().tolist()
+        return np.nonzero(keep)[0].tolist()
 
     def match_one_way(self, other: 'Image', u1: Tensor, v1: Tensor, wP1: Tensor) -> 'Matches':
         """Pixels ``(u1, v1)`` of this image (world points ``wP1``) that land inside ``other`` (sfm.py:115-119):

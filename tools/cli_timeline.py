@@ -32,8 +32,9 @@ def wrap(owner, name, label=None):
 
 
 def main():
-    W, H, gx, gy, n = (int(a) for a in (sys.argv[1:6] + [1920, 1080, 8, 6, 48][len(sys.argv) - 1:]))
-    survey = synth.make_survey(W, H, gx, gy, seed=3, device='cuda')
+    W, H, gx, gy, n = (int(a) for a in (sys.argv[1:6] + [1920, 1080, 8, 6, 48][len(sys.argv[1:6]):]))
+    spacing = float(sys.argv[6]) if len(sys.argv) > 6 else 0.1
+    survey = synth.make_survey(W, H, gx, gy, seed=3, spacing=spacing, device='cuda')
     for owner, name in ((loader, '_imread_rgb_u8'), (loader, '_imread_depth_u16'), (sucre, '_restore_submit'),
                         (sucre, '_restore_enqueue_fit'), (sucre, '_restore_finish'), (sucre, '_write_outputs'),
                         (sucre.SUCRe, 'save_plots'), (sucre.SUCRe, '_plot_J_device'), (sucre.SUCRe, 'plot_J'),
