@@ -125,7 +125,9 @@ class WorkerPool:
         import subprocess
         import sys
         from pathlib import Path
-        env = dict(os.environ, PYTHONPATH=str(Path(__file__).resolve().parent.parent) + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        env = dict(os.environ, PYTHONPATH=str(Path(__file__).resolve().parent.parent) + os.pathsep + os.environ.get('PYTHONPATH', ''),
+                   # a worker is one thread of work: keep numpy's BLAS / OpenMP from starting a thread per CPU of the machine
+                   OPENBLAS_NUM_THREADS='1', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
         return subprocess.Popen([sys.executable, '-c', 'from sucre_amd import _pixelio; _pixelio._worker_main()'],
                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
 
