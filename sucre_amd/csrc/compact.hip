@@ -240,7 +240,9 @@ __device__ __forceinline__ void store_group(uint8_t *strip, float *estrip, uint3
                 *reinterpret_cast<float4 *>(e + pl * (kStripPx * kGroupLv) + lane * 4) = make_float4(q.e[pl][0], q.e[pl][1], q.e[pl][2], q.e[pl][3]);
         }
     } else {   // the strip's last chunk: r < 4 levels, same arrangement with rows of r
-        for (uint32_t j = 0; j < r; ++j) {
+#pragma unroll   // constant trip count: q stays in registers (a loop up to r indexes it dynamically -> scratch)
+        for (uint32_t j = 0; j < (uint32_t)kGroupLv - 1u; ++j) {
+            if (j >= r) break;
             if (kFmt) reinterpret_cast<uint16_t *>(ch)[lane * r + j] = (uint16_t)range_mm<kFmt>(q.z[j]);
             else reinterpret_cast<float *>(ch)[lane * r + j] = q.z[j];
             uint8_t *cb = ch + zb * kStripPx * r;
