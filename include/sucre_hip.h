@@ -70,7 +70,10 @@ extern "C" {
  */
 #define SUCRE_EXT_POINTS 1
 #define SUCRE_EXT_COLOUR 2
+#define SUCRE_EXT_POINTS_COLOUR 3 /* both, in two sets of planes: the light model on inputs whose colours are not k/255
+                                     (--light-model with --image-scale); needs sucre_light_workspace_bytes_ext(.., 3) */
 #define SUCRE_FIT_EXT_COLOUR 4u  /* flag of sucre_fit_run_light / sucre_update_J_ext: lws was matched with SUCRE_EXT_COLOUR */
+#define SUCRE_FIT_EXT_BOTH 16u   /* ... with SUCRE_EXT_POINTS_COLOUR: the light model on float32 colours (excludes the former) */
 
 /*
  * One view of the scene = the arguments the reference reads from an sfm.Image (sfm.py:81-88): depth map,
@@ -268,6 +271,19 @@ int sucre_match_views_light(void *ws, void *lws, int H, int W, int n_views, cons
 int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
                               const sucre_view_t *views_dev, int k0, int k1, void *stream);
 /*
+ * Both at once -- the reference accepts --light-model together with --image-scale (sfm.py:193-199, sucre.py:54-61): the
+ * views' `rgb` are (H,W,3) float32 images, the camera points go to the first set of planes and the float32 colours to
+ * a second one (SUCRE_EXT_POINTS_COLOUR).  `lws` must then be sucre_light_workspace_bytes_ext(H, W, n_views,
+ * SUCRE_EXT_POINTS_COLOUR) bytes (the second set sits behind everything else, so all other offsets are unchanged);
+ * finalise with sucre_finalize_matches_ext(.., SUCRE_EXT_POINTS_COLOUR, ..) and pass SUCRE_FIT_EXT_BOTH to
+ * sucre_fit_run_light / sucre_update_J_ext.  sucre_finalize_matches_ext with SUCRE_EXT_POINTS or SUCRE_EXT_COLOUR equals
+ * sucre_finalize_matches_light.
+ */
+size_t sucre_light_workspace_bytes_ext(int H, int W, int n_views, int ext_mode);
+int sucre_match_views_light_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                                    const sucre_view_t *views_dev, int k0, int k1, void *stream);
+int sucre_finalize_matches_ext(void *ws, void *lws, int H, int W, int n_views, double min_cover, int ext_mode, void *stream);
+/*
  * sucre_import_view with extension planes: ext_dev holds three float32 planes [3][n] -- the camera points cP of the
  * list (loader.py:113; ext_mode SUCRE_EXT_POINTS, rgb_dev required) or its colours I (loader.py:87; SUCRE_EXT_COLOUR,
  * for colours that are not k/255; rgb_dev may be NULL).  This is how a caller-built MatchesData (loader.py:36-53)
@@ -283,7 +299,7 @@ int sucre_fit_init_light(void *ws, void *lws, int H, int W, int n_views, const u
 int sucre_update_J_light(void *ws, void *lws, int H, int W, int n_views, void *stream);
 int sucre_update_J_ext(void *ws, void *lws, int H, int W, int n_views, unsigned flags, void *stream);
 int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, int T, double lr, double beta1,
-                        double beta2, double eps, unsigned flags /* SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR */, double *trace_dev,
+                        double beta2, double eps, unsigned flags /* SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_KEEP_J | SUCRE_FIT_EXT_COLOUR or SUCRE_FIT_EXT_BOTH */, double *trace_dev,
                         void *stream);
 
 #ifdef __cplusplus

@@ -16,9 +16,10 @@ LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent 
 FIT_CLOSED_FORM = 1
 FIT_OBS_U16MM = 2
 FIT_EXT_COLOUR = 4
+FIT_EXT_BOTH = 16
 FIT_KEEP_J = 8
 OBS_F32, OBS_U16MM = 0, 1
-EXT_POINTS, EXT_COLOUR = 1, 2
+EXT_POINTS, EXT_COLOUR, EXT_POINTS_COLOUR = 1, 2, 3
 OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL = range(6)
 
@@ -72,6 +73,9 @@ SIGNATURES = {
     'sucre_light_params_offset': (C.c_int64, [_i, _i, _i]),
     'sucre_match_views_light': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
     'sucre_match_views_fcolour': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_light_workspace_bytes_ext': (C.c_size_t, [_i, _i, _i, _i]),
+    'sucre_match_views_light_fcolour': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
+    'sucre_finalize_matches_ext': (_i, [_vp, _vp, _i, _i, _i, _d, _i, _vp]),
     'sucre_import_view_ext': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _vp]),
     'sucre_export_view_ext': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'sucre_finalize_matches_light': (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),

@@ -327,6 +327,13 @@ size_t sucre_light_workspace_bytes(int H, int W, int n_views) {
     return light_workspace_bytes(L);
 }
 
+size_t sucre_light_workspace_bytes_ext(int H, int W, int n_views, int ext_mode) {
+    Layout L;
+    if (!make_layout(H, W, n_views, &L)) { fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views); return 0; }
+    if (ext_mode < SUCRE_EXT_POINTS || ext_mode > SUCRE_EXT_POINTS_COLOUR) { fail(SUCRE_ERR_ARG, "unknown extension mode %d", ext_mode); return 0; }
+    return light_workspace_bytes(L, ext_mode == SUCRE_EXT_POINTS_COLOUR ? 2 : 1);
+}
+
 int64_t sucre_light_params_offset(int H, int W, int n_views) {
     Layout L;
     if (!make_layout(H, W, n_views, &L)) return fail(SUCRE_ERR_ARG, "invalid geometry H=%d W=%d n_views=%d", H, W, n_views);
@@ -361,6 +368,34 @@ int sucre_match_views_fcolour(void *ws, void *lws, int H, int W, int n_views, co
     if (k0 < 0 || k1 > n_views || k0 >= k1) return fail(SUCRE_ERR_RANGE, "view range [%d,%d) outside [0,%d)", k0, k1, n_views);
     return check_hip(launch_match(L, static_cast<uint8_t *>(ws), *target, views_dev, k0, k1, static_cast<hipStream_t>(stream),
                                   light_ext_dense(L, static_cast<uint8_t *>(lws)), SUCRE_EXT_COLOUR), "sucre_match_views_fcolour");
+}
+
+int sucre_match_views_light_fcolour(void *ws, void *lws, int H, int W, int n_views, const sucre_view_t *target,
+                                    const sucre_view_t *views_dev, int k0, int k1, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (!target || !views_dev || !target->depth) return fail(SUCRE_ERR_ARG, "target / views_dev / target depth is NULL");
+    if (target->H != H || target->W != W) return fail(SUCRE_ERR_ARG, "target is %dx%d, expected %dx%d", target->W, target->H, W, H);
+    if (k0 < 0 || k1 > n_views || k0 >= k1) return fail(SUCRE_ERR_RANGE, "view range [%d,%d) outside [0,%d)", k0, k1, n_views);
+    auto *l = static_cast<uint8_t *>(lws);
+    return check_hip(launch_match(L, static_cast<uint8_t *>(ws), *target, views_dev, k0, k1, static_cast<hipStream_t>(stream),
+                                  light_ext_dense(L, l), SUCRE_EXT_POINTS_COLOUR, light_ext2_dense(L, l)),
+                     "sucre_match_views_light_fcolour");
+}
+
+int sucre_finalize_matches_ext(void *ws, void *lws, int H, int W, int n_views, double min_cover, int ext_mode, void *stream) {
+    Layout L;
+    if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
+    if (int rc = check_lws(lws)) return rc;
+    if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
+    if (ext_mode < SUCRE_EXT_POINTS || ext_mode > SUCRE_EXT_POINTS_COLOUR) return fail(SUCRE_ERR_ARG, "unknown extension mode %d", ext_mode);
+    auto *l = static_cast<uint8_t *>(lws);
+    const bool both = ext_mode == SUCRE_EXT_POINTS_COLOUR;
+    return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream),
+                                     light_ext_dense(L, l), light_ext_comp(L, l), SUCRE_OBS_F32,
+                                     both ? light_ext2_dense(L, l) : nullptr, both ? light_ext2_comp(L, l) : nullptr),
+                     "sucre_finalize_matches_ext");
 }
 
 int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
@@ -420,7 +455,8 @@ int sucre_update_J_ext(void *ws, void *lws, int H, int W, int n_views, unsigned 
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (int rc = check_lws(lws)) return rc;
-    if (flags & ~SUCRE_FIT_EXT_COLOUR) return fail(SUCRE_ERR_ARG, "unknown flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "unknown flags 0x%x", flags);
+    if ((flags & SUCRE_FIT_EXT_COLOUR) && (flags & SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "SUCRE_FIT_EXT_COLOUR and SUCRE_FIT_EXT_BOTH exclude each other");
     return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), flags,
                                            static_cast<hipStream_t>(stream)), "sucre_update_J_ext");
 }
@@ -433,7 +469,8 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
     if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
-    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_KEEP_J)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_KEEP_J | SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    if ((flags & SUCRE_FIT_EXT_COLOUR) && (flags & SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "SUCRE_FIT_EXT_COLOUR and SUCRE_FIT_EXT_BOTH exclude each other");
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
         if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co, flags,
@@ -442,7 +479,7 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     }
     if ((flags & SUCRE_FIT_CLOSED_FORM) && !(flags & SUCRE_FIT_KEEP_J))  // the final update_J of sucre.py:156
         return check_hip(launch_light_update_J(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws),
-                                               flags & SUCRE_FIT_EXT_COLOUR, static_cast<hipStream_t>(stream)),
+                                               flags & (SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_EXT_BOTH), static_cast<hipStream_t>(stream)),
                          "sucre_fit_run_light/update_J");
     return SUCRE_OK;
 }

@@ -196,20 +196,20 @@ __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict
 //     -- 3.9 GB fetched for 0.55 GB of observations (rocprofv3 FETCH_SIZE), HBM-bound at 1.13 ms.)
 //     kFmt = SUCRE_OBS_U16MM: the range is stored as uint16 millimetres, rint(1000 z) clamped to [1, 65535]
 //     (0 stays the empty-slot marker), colours unchanged.
-//     kExt: the three float32 extension planes of every chunk (camera points of the light model / float32
-//     colours) ride along, 3072 more bytes per staged view.
-template <bool kExt>
+//     kExt = 1, 2: that many sets of three float32 extension planes per chunk ride along, 3072 more bytes per set and
+//     staged view (one set: the light model's camera points or float32 colours; two: both).
+template <int kExt>
 struct StageCfg {
-    static constexpr int kViews = kExt ? 16 : 32;                 // 16 x 4864 B = 76 KB / 32 x 1792 B = 56 KB of LDS
-    static constexpr int kBytes = kChunk + (kExt ? kExtChunk : 0);
+    static constexpr int kViews = kExt == 0 ? 32 : (kExt == 1 ? 16 : 8);   // 56 KB / 76 KB / 62 KB of LDS
+    static constexpr int kBytes = kChunk + kExt * kExtChunk;
 };
 
 // Four consecutive levels of one pixel on their way to the strip store.
-template <bool kExt>
+template <int kExt>
 struct LevelGroup {
     float z[kGroupLv];
     uint32_t c[3];              // four bytes per colour plane, level j in byte j
-    float e[kExt ? 3 : 1][kGroupLv];
+    float e[kExt ? 3 * kExt : 1][kGroupLv];
 };
 
 template <int kFmt>
@@ -219,8 +219,8 @@ __device__ __forceinline__ uint32_t range_mm(float z) {
 }
 
 // Writes chunk g (r of its four levels exist in the strip) of pixel `lane`.
-template <int kFmt, bool kExt>
-__device__ __forceinline__ void store_group(uint8_t *strip, float *estrip, uint32_t g, uint32_t r, uint32_t lane,
+template <int kFmt, int kExt>
+__device__ __forceinline__ void store_group(uint8_t *strip, float *const (&estrip)[2], uint32_t g, uint32_t r, uint32_t lane,
                                             const LevelGroup<kExt> &q) {
     uint8_t *ch = strip + (size_t)g * (kGroupLv * level_bytes(kFmt));
     constexpr uint32_t zb = kFmt ? 2 : 4;   // bytes per range
@@ -233,11 +233,13 @@ __device__ __forceinline__ void store_group(uint8_t *strip, float *estrip, uint3
         }
         uint32_t *cp = reinterpret_cast<uint32_t *>(ch + zb * kStripPx * kGroupLv) + lane;
         cp[0] = q.c[0]; cp[kStripPx] = q.c[1]; cp[2 * kStripPx] = q.c[2];
-        if (kExt) {
-            float *e = estrip + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
+#pragma unroll
+        for (int set = 0; set < kExt; ++set) {
+            float *e = estrip[set] + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                *reinterpret_cast<float4 *>(e + pl * (kStripPx * kGroupLv) + lane * 4) = make_float4(q.e[pl][0], q.e[pl][1], q.e[pl][2], q.e[pl][3]);
+                *reinterpret_cast<float4 *>(e + pl * (kStripPx * kGroupLv) + lane * 4) =
+                    make_float4(q.e[3 * set + pl][0], q.e[3 * set + pl][1], q.e[3 * set + pl][2], q.e[3 * set + pl][3]);
         }
     } else {   // the strip's last chunk: r < 4 levels, same arrangement with rows of r
 #pragma unroll   // constant trip count: q stays in registers (a loop up to r indexes it dynamically -> scratch)
@@ -248,34 +250,37 @@ __device__ __forceinline__ void store_group(uint8_t *strip, float *estrip, uint3
             uint8_t *cb = ch + zb * kStripPx * r;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) cb[pl * kStripPx * r + lane * r + j] = (uint8_t)(q.c[pl] >> (8 * j));
-            if (kExt) {
-                float *e = estrip + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) e[pl * kStripPx * r + lane * r + j] = q.e[pl][j];
+            for (int set = 0; set < kExt; ++set) {
+                float *e = estrip[set] + (size_t)g * (kGroupLv * kExtLevelBytes / 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) e[pl * kStripPx * r + lane * r + j] = q.e[3 * set + pl][j];
             }
         }
     }
 }
 
-template <bool kExt>
+template <int kExt>
 __device__ __forceinline__ void clear_group(LevelGroup<kExt> &q) {
 #pragma unroll
     for (int j = 0; j < kGroupLv; ++j) {
         q.z[j] = 0.0f;
 #pragma unroll
-        for (int pl = 0; pl < (kExt ? 3 : 1); ++pl) q.e[pl][j] = 0.0f;
+        for (int pl = 0; pl < (kExt ? 3 * kExt : 1); ++pl) q.e[pl][j] = 0.0f;
     }
     q.c[0] = q.c[1] = q.c[2] = 0u;
 }
 
-template <int kFmt, bool kExt>
+template <int kFmt, int kExt>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
                                                       const StripMeta *__restrict__ meta,
                                                       uint8_t *__restrict__ comp, int n_views,
                                                       const uint8_t *__restrict__ ext_dense,
-                                                      uint8_t *__restrict__ ext_comp) {
+                                                      uint8_t *__restrict__ ext_comp,
+                                                      const uint8_t *__restrict__ ext2_dense,
+                                                      uint8_t *__restrict__ ext2_comp) {
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kStageBytes];
     __shared__ uint32_t present;
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     const StripMeta sm = meta[dst / kStripPx];
     const uint32_t nl = sm.levels;
     uint8_t *out = comp + sm.lvoff * (uint64_t)level_bytes(kFmt);
-    float *eout = kExt ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr;
+    float *const eout[2] = {kExt >= 1 ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr,
+                            kExt >= 2 ? reinterpret_cast<float *>(ext2_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr};
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     const uint8_t *tbase = obs + (size_t)tile * tile_stride;
     constexpr int kUnits = kStageBytes / 16;  // 16-byte pieces of a staged view
@@ -308,9 +314,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         const int total = __builtin_popcount(p) * kUnits;
         for (int u = t; u < total; u += 256) {
             const int i = vl[u / kUnits], w = u % kUnits;
+            constexpr int kExtUnits = kExtChunk / 16;
             const uint8_t *src = (!kExt || w < kMainUnits)
                 ? tbase + (size_t)(g0 + i) * view_stride + (size_t)w * 16
-                : ext_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits) * 16;
+                : (kExt < 2 || w < kMainUnits + kExtUnits)
+                    ? ext_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits) * 16
+                    : ext2_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits - kExtUnits) * 16;
             *reinterpret_cast<uint4 *>(&stage[i][w * 16]) = *reinterpret_cast<const uint4 *>(src);
         }
         __syncthreads();
@@ -327,9 +336,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                 if (j == (uint32_t)jj) {
                     q.z[jj] = z;
                     if (kExt) {
-                        const float *se = reinterpret_cast<const float *>(&stage[i][kChunk]);
+                        const float *se = reinterpret_cast<const float *>(&stage[i][kChunk]);   // the sets follow each other
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) q.e[pl][jj] = se[pl * kTilePx + t];
+                        for (int pl = 0; pl < 3 * kExt; ++pl) q.e[pl][jj] = se[pl * kTilePx + t];
                     }
                 }
             q.c[0] |= cr << (8 * j); q.c[1] |= cg << (8 * j); q.c[2] |= cb << (8 * j);
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
 }
 
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
-                          int fmt) {
+                          int fmt, const uint8_t *ext2_dense, uint8_t *ext2_comp) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *keep = reinterpret_cast<const uint32_t *>(ws + L.off_view_keep);
     auto *pcount = reinterpret_cast<uint16_t *>(ws + L.off_pcount);
@@ -375,15 +384,18 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     const dim3 grid(L.n_tiles), block(256);
     const uint8_t *obs = ws + L.off_obs;
     uint8_t *comp = ws + L.off_comp;
-    if (ext_dense)  // light model / float32 colours: float32 store only
-        hipLaunchKernelGGL((scatter_kernel<0, true>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
+    if (ext_dense && ext2_dense)  // light model on float32 colours: camera points and colours ride along
+        hipLaunchKernelGGL((scatter_kernel<0, 2>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+    else if (ext_dense)  // light model / float32 colours: float32 store only
+        hipLaunchKernelGGL((scatter_kernel<0, 1>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else if (fmt)
-        hipLaunchKernelGGL((scatter_kernel<1, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
+        hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else
-        hipLaunchKernelGGL((scatter_kernel<0, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp);
+        hipLaunchKernelGGL((scatter_kernel<0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_plan(L, ws, fmt, s);   // the fit waves' item streams over the store just written (fit.hip)
 }

@@ -27,7 +27,8 @@ struct AdamCoef {
 AdamCoef adam_coef(int step, double lr, double beta1, double beta2, double eps);
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s, uint8_t *ext = nullptr, int ext_mode = SUCRE_EXT_POINTS);
+                        int k0, int k1, hipStream_t s, uint8_t *ext = nullptr, int ext_mode = SUCRE_EXT_POINTS,
+                        uint8_t *ext2 = nullptr);
 hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
                             int32_t *map, hipStream_t s);
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
@@ -35,9 +36,11 @@ hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t
                               const float *ext = nullptr);
 hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s);
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s,
-                           const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
+                           const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32,
+                           const uint8_t *ext2_dense = nullptr, uint8_t *ext2_comp = nullptr);
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense = nullptr,
-                          uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32);
+                          uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32, const uint8_t *ext2_dense = nullptr,
+                          uint8_t *ext2_comp = nullptr);
 hipError_t launch_check_store(const Layout &L, const uint8_t *ws, uint32_t *verdict, uint64_t *scratch, hipStream_t s);
 hipError_t launch_export_view(const Layout &L, const uint8_t *ws, int k, float *z, uint8_t *rgb, hipStream_t s);
 
@@ -69,7 +72,9 @@ hipError_t launch_plot_stretch(const float *J, int H, int W, const float *lo, co
 hipError_t launch_count_valid(const float *J, int H, int W, uint64_t *count, hipStream_t s);
 
 // artificial-light model (light.hip)
-size_t light_workspace_bytes(const Layout &L);
+size_t light_workspace_bytes(const Layout &L, int ext_sets = 1);
+uint8_t *light_ext2_dense(const Layout &L, uint8_t *lws);   // second extension set (float32 colours next to camera points);
+uint8_t *light_ext2_comp(const Layout &L, uint8_t *lws);    // only in a workspace of light_workspace_bytes(L, 2) bytes
 int64_t light_params_offset(const Layout &L);
 uint8_t *light_ext_dense(const Layout &L, uint8_t *lws);
 uint8_t *light_ext_comp(const Layout &L, uint8_t *lws);

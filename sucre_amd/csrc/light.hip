@@ -27,10 +27,12 @@ struct LightLayout {
     size_t off_geom;                      // float [16]: R[9], t[3], M[4] = Sigma^-1 (row-major)
     size_t off_partials;                  // float [26][n_blocks]
     size_t off_sums;                      // double [26]
+    size_t off_ext2_dense, off_ext2_comp; // second set of planes (float32 colours next to camera points); only with ext_sets = 2
     size_t total;
 };
 
-static bool make_light_layout(const Layout &L, LightLayout *X) {
+// ext_sets = 2 appends the second set at the END, so every other offset is the same in both kinds of workspace
+static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     const size_t chunks = (size_t)L.n_tiles * L.n_views;
@@ -40,6 +42,11 @@ static bool make_light_layout(const Layout &L, LightLayout *X) {
     X->off_geom = take(16 * sizeof(float));
     X->off_partials = take((size_t)kLightSums * L.n_blocks * sizeof(float));
     X->off_sums = take(kLightSums * sizeof(double));
+    X->off_ext2_dense = X->off_ext2_comp = 0;
+    if (ext_sets > 1) {
+        X->off_ext2_dense = take(chunks * kExtChunk);
+        X->off_ext2_comp = take(chunks * kExtChunk);
+    }
     X->total = o;
     return true;
 }
@@ -156,6 +163,29 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
 }
 
 struct LightChunk { float zz[4], xx[4], yy[4], ww[4]; uint32_t cc[3]; };
+struct ColourChunk { float c[3][4]; };   // float32 colours of the same four levels (second extension set)
+
+// The three planes of chunk g of a strip's SECOND extension set -> this lane's pixel (same arrangement as the first).
+__device__ __forceinline__ ColourChunk load_colour_chunk(const uint8_t *sext2, uint32_t g, uint32_t r, int lane) {
+    const float *ex = reinterpret_cast<const float *>(sext2 + (size_t)g * (kGroupLv * kExtLevelBytes));
+    ColourChunk q;
+    if (r == kGroupLv) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const float4 v = *reinterpret_cast<const float4 *>(ex + pl * kStripPx * kGroupLv + lane * 4);
+            q.c[pl][0] = v.x; q.c[pl][1] = v.y; q.c[pl][2] = v.z; q.c[pl][3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kGroupLv; ++j) {
+            const bool has = (uint32_t)j < r;
+            const uint32_t i = lane * r + (has ? j : 0);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) q.c[pl][j] = has ? ex[pl * kStripPx * r + i] : 0.0f;
+        }
+    }
+    return q;
+}
 
 // Chunk g of a strip (r of its four levels exist, layout.h / compact.hip) -> this lane's pixel: ranges, extension
 // planes (camera point or float colour) and colour bytes of up to four levels; levels that do not exist read z = 0.
@@ -193,9 +223,11 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
 // backscatter = l B (1 - g)) and is a constant of the gradient; kJOnly: only that closed-form J (final update_J).
 // kColour (SUCRE_EXT_COLOUR): the extension planes carry the observation's float32 colour instead of its camera
 // point; there is no light then (l = 1, z = the stored range) and the light sums stay zero.
+// kBoth (SUCRE_EXT_POINTS_COLOUR): the light model with float32 colours -- camera points in `ext`, colours in `ext2`.
 // Every wave works alone on strips of 64 sorted pixels, one pixel per lane (the deal of fit.hip).
-template <bool kClosed, bool kJOnly, bool kColour>
+template <bool kClosed, bool kJOnly, bool kColour, bool kBoth>
 __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restrict__ comp, const uint8_t *__restrict__ ext,
+                                                         const uint8_t *__restrict__ ext2,
                                                          const StripMeta *__restrict__ meta, int n_strips,
                                                          const float *__restrict__ pstate, const float *__restrict__ geom,
                                                          const uint64_t *__restrict__ n_obs_total,
@@ -234,13 +266,17 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         const uint32_t n = sm.levels, nch = (n + 3u) >> 2;
         const uint8_t *sobs = comp + sm.lvoff * (uint64_t)level_bytes(0);
         const uint8_t *sext = ext + sm.lvoff * (uint64_t)kExtLevelBytes;
+        const uint8_t *sext2 = kBoth ? ext2 + sm.lvoff * (uint64_t)kExtLevelBytes : nullptr;
         float *st = state + (size_t)strip * kStateFloats + lane;
         float J[3];
         if (kClosed) {
             // closed-form J of this pixel: numerator / denominator per channel over all levels
             float num[3] = {0.f, 0.f, 0.f}, den[3] = {0.f, 0.f, 0.f};
             for (uint32_t g = 0; g < nch; ++g) {
-                const LightChunk kk = load_light_chunk(sobs, sext, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane);
+                const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
+                const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
+                ColourChunk fc;
+                if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (!(kk.zz[j] > 0.0f)) continue;
@@ -252,7 +288,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     for (int c = 0; c < 3; ++c) {
                         const float a = o.l * fast_exp2(o.z * nb[c]);
                         const float b = o.l * B[c] * (1.0f - fast_exp2(o.z * ng[c]));
-                        const float I = kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
+                        const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
                         num[c] = __builtin_fmaf(I - b, a, num[c]);
                         den[c] = __builtin_fmaf(a, a, den[c]);
                     }
@@ -271,7 +307,10 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
         const float bJ[3] = {beta[0] * J[0], beta[1] * J[1], beta[2] * J[2]};   // constant over the pixel's observations
         for (uint32_t g = 0; g < nch; ++g) {
-            const LightChunk kk = load_light_chunk(sobs, sext, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane);
+            const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
+            const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
+            ColourChunk fc;
+            if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!(kk.zz[j] > 0.0f)) continue;  // padding slot
@@ -289,7 +328,8 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
                     // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
                     const uint32_t kb = (kk.cc[c] >> (8 * j)) & 255u;
-                    const float r = kColour ? cP[c] - l * E
+                    const float r = kBoth ? fc.c[c][j] - l * E
+                                  : kColour ? cP[c] - l * E
                                   : kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
                     const float rl = r * l;
                     const float rlz = rl * z;
@@ -435,9 +475,9 @@ __global__ void light_params_upload_kernel(float *dst, const LightParams19 p) {
     if (threadIdx.x < kLightParams) dst[threadIdx.x] = p.v[threadIdx.x];
 }
 
-size_t light_workspace_bytes(const Layout &L) {
+size_t light_workspace_bytes(const Layout &L, int ext_sets) {
     LightLayout X;
-    make_light_layout(L, &X);
+    make_light_layout(L, &X, ext_sets);
     return X.total;
 }
 
@@ -459,6 +499,18 @@ uint8_t *light_ext_comp(const Layout &L, uint8_t *lws) {
     return lws + X.off_ext_comp;
 }
 
+uint8_t *light_ext2_dense(const Layout &L, uint8_t *lws) {
+    LightLayout X;
+    make_light_layout(L, &X, 2);
+    return lws + X.off_ext2_dense;
+}
+
+uint8_t *light_ext2_comp(const Layout &L, uint8_t *lws) {
+    LightLayout X;
+    make_light_layout(L, &X, 2);
+    return lws + X.off_ext2_comp;
+}
+
 hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params19, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
@@ -472,11 +524,12 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     return hipGetLastError();
 }
 
-template <bool kClosed, bool kJOnly, bool kColour>
+template <bool kClosed, bool kJOnly, bool kColour, bool kBoth = false>
 static void launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
                                 hipStream_t s) {
-    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
-                       lws + X.off_ext_comp, reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips,
+    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour, kBoth>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+                       lws + X.off_ext_comp, kBoth ? light_ext2_comp(L, lws) : nullptr,
+                       reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips,
                        reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(lws + X.off_partials), co);
@@ -485,7 +538,8 @@ static void launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *
 template <bool kClosed, bool kJOnly>
 static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
                               unsigned flags, hipStream_t s) {
-    if (flags & SUCRE_FIT_EXT_COLOUR) launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
+    if (flags & SUCRE_FIT_EXT_BOTH) launch_light_grad_c<kClosed, kJOnly, false, true>(L, X, ws, lws, co, s);
+    else if (flags & SUCRE_FIT_EXT_COLOUR) launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
     else launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s);
 }
 

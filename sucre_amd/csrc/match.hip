@@ -73,12 +73,15 @@ __device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H
 
 constexpr int kViewsPerGroup = 16;
 
+// kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
+// `ext`, the float32 colour to `ext2` (light model on resized images).
+template <bool kBoth>
 __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                     const float *__restrict__ depth1, const CamDev c1,
                                                     const sucre_view_t *__restrict__ views, int n_views, int k0,
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
                                                     size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext,
-                                                    int ext_mode) {
+                                                    int ext_mode, uint8_t *__restrict__ ext2) {
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         const uint8_t *__restrict__ rgb2 = vw->rgb;
         const float W2f = (float)vw->W, H2f = (float)vw->H;
         float zo[4], cx[4], cy[4], cz[4];
+        float fr[kBoth ? 4 : 1], fg[kBoth ? 4 : 1], fb[kBoth ? 4 : 1];
         uint32_t r4 = 0, g4 = 0, b4 = 0;
         int total = 0;
 #pragma unroll
@@ -118,12 +122,16 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             float z = 0.0f;
             uint32_t r = 0, g = 0, b = 0;
             float c2[3] = {0.f, 0.f, 0.f};
+            float f2[3] = {0.f, 0.f, 0.f};
             if (m) {
                 size_t q;
                 m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
-                    if (ext_mode == SUCRE_EXT_COLOUR) {  // float32 colour image (resized inputs): the planes carry I
+                    if (kBoth) {                          // float32 colour image, camera point kept as well
+                        const float *pf = reinterpret_cast<const float *>(rgb2) + q * 3;
+                        f2[0] = pf[0]; f2[1] = pf[1]; f2[2] = pf[2];
+                    } else if (ext_mode == SUCRE_EXT_COLOUR) {  // float32 colour image (resized inputs): the planes carry I
                         const float *pf = reinterpret_cast<const float *>(rgb2) + q * 3;
                         c2[0] = pf[0]; c2[1] = pf[1]; c2[2] = pf[2];
                     } else {
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             }
             zo[j] = z;
             cx[j] = m ? c2[0] : 0.f; cy[j] = m ? c2[1] : 0.f; cz[j] = m ? c2[2] : 0.f;
+            if (kBoth) { fr[j] = m ? f2[0] : 0.f; fg[j] = m ? f2[1] : 0.f; fb[j] = m ? f2[2] : 0.f; }
             r4 |= r << (8 * j);
             g4 |= g << (8 * j);
             b4 |= b << (8 * j);
@@ -151,6 +160,12 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                 *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(cx[0], cx[1], cx[2], cx[3]);
                 *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(cy[0], cy[1], cy[2], cy[3]);
                 *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(cz[0], cz[1], cz[2], cz[3]);
+            }
+            if (kBoth) {
+                uint8_t *e = ext2 + ((size_t)tile * n_views + k) * kExtChunk;
+                *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(fr[0], fr[1], fr[2], fr[3]);
+                *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(fg[0], fg[1], fg[2], fg[3]);
+                *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(fb[0], fb[1], fb[2], fb[3]);
             }
         }
     }
@@ -372,12 +387,19 @@ static CamDev to_cam(const sucre_view_t &v) {
 }
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
-                        int k0, int k1, hipStream_t s, uint8_t *ext, int ext_mode) {
+                        int k0, int k1, hipStream_t s, uint8_t *ext, int ext_mode, uint8_t *ext2) {
     const int tiles_per_xcd = (L.n_tiles + 7) / 8;
     const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
-    hipLaunchKernelGGL(match_kernel, grid, dim3(256), 0, s, ws + L.off_obs,
-                       reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
-                       L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, ext_mode);
+    if (ext2)
+        hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), 0, s, ws + L.off_obs,
+                           reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
+                           L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext,
+                           SUCRE_EXT_POINTS_COLOUR, ext2);
+    else
+        hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), 0, s, ws + L.off_obs,
+                           reinterpret_cast<uint16_t *>(ws + L.off_cnt), target.depth, to_cam(target), views_dev,
+                           L.n_views, k0, k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext,
+                           ext_mode, ext2);
     return hipGetLastError();
 }
 
@@ -389,7 +411,7 @@ hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const s
 }
 
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s, const uint8_t *ext_dense,
-                           uint8_t *ext_comp, int fmt) {
+                           uint8_t *ext_comp, int fmt, const uint8_t *ext2_dense, uint8_t *ext2_comp) {
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *vc = reinterpret_cast<uint64_t *>(ws + L.off_view_count);
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
@@ -399,7 +421,7 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_compact(L, ws, s, ext_dense, ext_comp, fmt);
+    return launch_compact(L, ws, s, ext_dense, ext_comp, fmt, ext2_dense, ext2_comp);
 }
 
 hipError_t launch_check_store(const Layout &L, const uint8_t *ws, uint32_t *verdict, uint64_t *scratch, hipStream_t s) {

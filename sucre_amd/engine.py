@@ -88,8 +88,9 @@ class Restoration:
         self.lib = _lib.load()
         self.light = bool(light)
         self.float_colour = bool(float_colour)
-        if self.float_colour and (self.light or obs_format != 'f32'):
-            raise NotImplementedError('float32 colours share the extension planes with the light model and need the f32 store')
+        self.both = self.light and self.float_colour   # light model on float32 colours: two sets of extension planes
+        if self.float_colour and obs_format != 'f32':
+            raise NotImplementedError('float32 colours need the f32 store')
         if obs_format not in _lib.OBS_FORMATS:
             raise ValueError(f'obs_format must be one of {sorted(_lib.OBS_FORMATS)}, not {obs_format!r}')
         if self.light and obs_format != 'f32':
@@ -109,7 +110,8 @@ class Restoration:
         assert self.ws.data_ptr() % 256 == 0
         self.lws = None
         if self.light or self.float_colour:  # extension workspace: camera points / float colours + 19 parameters
-            lbytes = self.lib.sucre_light_workspace_bytes(self.H, self.W, self.n_views)
+            lbytes = (self.lib.sucre_light_workspace_bytes_ext(self.H, self.W, self.n_views, _lib.EXT_POINTS_COLOUR) if self.both
+                      else self.lib.sucre_light_workspace_bytes(self.H, self.W, self.n_views))
             self.lws = torch.empty(lbytes, dtype=torch.uint8, device=self.device)
             assert self.lws.data_ptr() % 256 == 0
         self._views_dev = None
@@ -122,6 +124,14 @@ class Restoration:
         self.steps_done = 0
 
     # -- plumbing -----------------------------------------------------------------------------------------
+    @property
+    def _ext_mode(self) -> int:
+        return _lib.EXT_POINTS_COLOUR if self.both else _lib.EXT_COLOUR if self.float_colour else _lib.EXT_POINTS
+
+    @property
+    def _ext_flag(self) -> int:
+        return _lib.FIT_EXT_BOTH if self.both else _lib.FIT_EXT_COLOUR if self.float_colour else 0
+
     @property
     def _geom(self):
         return C.c_void_p(self.ws.data_ptr()), self.H, self.W, self.n_views
@@ -155,9 +165,10 @@ class Restoration:
             assert all(v.rgb.dtype == want for v in views), f'this restoration takes {want} colour images'
             if self.light or self.float_colour:
                 lws = C.c_void_p(self.lws.data_ptr())
-                fn = self.lib.sucre_match_views_fcolour if self.float_colour else self.lib.sucre_match_views_light
+                fn = (self.lib.sucre_match_views_light_fcolour if self.both else
+                      self.lib.sucre_match_views_fcolour if self.float_colour else self.lib.sucre_match_views_light)
                 _lib.check(fn(ws, lws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()), 0, n, _stream_ptr()))
-                _lib.check(self.lib.sucre_finalize_matches_light(ws, lws, H, W, n, float(min_cover), _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches_ext(ws, lws, H, W, n, float(min_cover), self._ext_mode, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
                                                       0, n, _stream_ptr()))
@@ -170,11 +181,13 @@ class Restoration:
         float32 (3, n) tensor, fills the extension planes of a ``light`` restoration (the camera points cP) or of a
         ``float_colour`` one (the colours I; ``rgb_u8`` may then be None)."""
         assert 1 <= len(lists) <= self.capacity, (len(lists), self.capacity)
+        if self.both:
+            raise NotImplementedError('explicit match lists for the light model on float32 colours (two extension sets)')
         self.n_views = len(lists)
         self._keepalive = [target, lists]
         self._views_dev = None
         ws, H, W, n = self._geom
-        ext_mode = _lib.EXT_COLOUR if self.float_colour else _lib.EXT_POINTS
+        ext_mode = self._ext_mode
         with torch.cuda.device(self.device):
             for k, item in enumerate(lists):
                 u1, v1, z, rgb = item[:4]
@@ -265,7 +278,7 @@ class Restoration:
         npar = 19 if (self.light or self.float_colour) else 9
         default = np.concatenate([np.full(9, 0.1), np.zeros(6), [1.0, 0.0, 0.0, 1.0]])  # sucre.py:41-46
         p0 = default.copy() if params0 is None else np.asarray(params0, np.float64).reshape(-1)
-        if self.float_colour and p0.size == 9:
+        if self.float_colour and not self.light and p0.size == 9:
             p0 = np.concatenate([p0, default[9:]])   # no light: identity pose, unit beam (never updated)
         p0 = p0.astype(np.float32).reshape(-1)[:npar] if params0 is None else p0.astype(np.float32).reshape(npar)
         p0c = (C.c_float * npar)(*p0.tolist())
@@ -298,7 +311,7 @@ class Restoration:
         ext = self.light or self.float_colour
         width = 20 if ext else 10
         trace = torch.zeros((num_iter, width), dtype=torch.float64, device=self.device) if record_trace else None
-        flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag | (_lib.FIT_EXT_COLOUR if self.float_colour else 0)
+        flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | self._fmt_flag | self._ext_flag
         if keep_J and use_closed_form:
             flags |= _lib.FIT_KEEP_J
         ws, H, W, n = self._geom
@@ -313,7 +326,7 @@ class Restoration:
                                                   float(betas[0]), float(betas[1]), float(eps), flags, tp,
                                                   _stream_ptr()))
         self.steps_done += int(num_iter)
-        if trace is not None and self.float_colour:
+        if trace is not None and self.float_colour and not self.light:
             trace = trace[:, :10]   # the light columns are constants here
         self.trace = trace
         return trace
@@ -322,8 +335,7 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             if self.light or self.float_colour:
-                _lib.check(self.lib.sucre_update_J_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
-                                                       _lib.FIT_EXT_COLOUR if self.float_colour else 0, _stream_ptr()))
+                _lib.check(self.lib.sucre_update_J_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self._ext_flag, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_update_J_fmt(ws, H, W, n, self._fmt, _stream_ptr()))
 
@@ -331,7 +343,7 @@ class Restoration:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
         if self.light or self.float_colour:
             off = self.lib.sucre_light_params_offset(self.H, self.W, self.n_views)
-            return self.lws[off:off + (36 if self.float_colour else 76)].view(torch.float32)
+            return self.lws[off:off + (76 if self.light else 36)].view(torch.float32)
         return self._region(_lib.WS_PARAMS, torch.float32, 9)
 
     def J(self) -> torch.Tensor:

@@ -333,7 +333,13 @@ class MatchesData:
                 cP = other.unproject_depth(u=u2, v=v2, d=other.device_view(r.device).depth[v2, u2])
             else:
                 cP = torch.stack([torch.zeros_like(zz), torch.zeros_like(zz), zz])
-            if r.float_colour:
+            if r.float_colour and r.light:   # the colours sit in the second extension set: gathered from the view itself
+                other = self.image_list[k]
+                p2 = r.match_map(k)[v, u].long()
+                W2 = other.camera.width
+                rgbf = other.device_view(r.device).as_float_colour().rgb
+                I = rgbf[torch.div(p2, W2, rounding_mode='floor'), p2 % W2].T.contiguous()
+            elif r.float_colour:
                 I = r.export_view_ext(k)[:, v, u].contiguous()
             else:
                 I = (rgb[v, u].to(torch.float64) / 255).to(torch.float32).T.contiguous()

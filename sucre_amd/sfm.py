@@ -304,10 +304,7 @@ class Image:
         views = [im.device_view(device) for im in image_list]
         target = self.device_view(device)
         float_colour = any(v.rgb.dtype == torch.float32 for v in views + [target])   # resized inputs (--image-scale)
-        if float_colour:
-            if light_model:
-                raise NotImplementedError('--light-model together with resized images (--image-scale != 1): the light '
-                                          'model and float32 colours share the same extension planes')
+        if float_colour:   # (with light_model the engine keeps both the camera points and the float32 colours)
             for im, v in zip(image_list + [self], views + [target]):   # the float32 twins count against the cache budget
                 if v.rgb.dtype != torch.float32 and '_float_twin' not in v.__dict__:
                     PIXEL_CACHE.grow(im, v.rgb.numel() * 4, _canonical_device(device))

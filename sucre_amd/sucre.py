@@ -347,14 +347,19 @@ def _restore_submit(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir:
     params0 = sucre.water_vector().detach().cpu().numpy()   # still on the host: no wait
     sucre = sucre.to(device)
 
-    if force_compute_matches or not matches_file.on_disk():
+    reuse = not force_compute_matches and matches_file.on_disk()
+    if reuse:   # a kept matches file (ours or the reference's): consumed as is, like sucre.py:185
+        try:
+            matches_file.load_file(image, device=device, light=light_model)
+        except NotImplementedError as e:   # e.g. --light-model on kept matches of resized images
+            print(f'{matches_file.path.name} is not reused ({e}).')
+            reuse = False
+    if not reuse:
         print(f'Compute {image.name} matches.')
         image.match_images(image_list=image_list, matches_file=matches_file, min_cover=min_cover,
                            num_workers=num_workers, device=device, light_model=light_model)
         print('Prepare matches for optimization.')
         matches_file.prepare_matches(num_workers=num_workers)
-    else:  # a kept matches file (ours or the reference's): consumed as is, like sucre.py:185
-        matches_file.load_file(image, device=device, light=light_model)
     print('Check matches integrity.')
     matches_file.check_integrity(defer=defer_checks)
     print('Load matches.')

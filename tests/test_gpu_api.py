@@ -290,12 +290,16 @@ def test_cli_light_model_closed_form(disk_scene, tmp_path):
     assert len(list(tmp_path.glob('**/*.png'))) >= 3
 
 
-@pytest.mark.parametrize('extra', [['--light-model'], ['--image-scale', '0.5'], ['--light-model', '--use-closed-form']],
-                         ids=['light-model', 'image-scale', 'light-closed-form'])
-def test_cli_kept_matches_are_reused_in_every_mode(disk_scene, tmp_path, capsys, extra):
+@pytest.mark.parametrize('extra,reused', [(['--light-model'], True), (['--image-scale', '0.5'], True),
+                                          (['--light-model', '--use-closed-form'], True),
+                                          (['--light-model', '--image-scale', '0.5'], False)],
+                         ids=['light-model', 'image-scale', 'light-closed-form', 'light-image-scale'])
+def test_cli_kept_matches_are_reused_in_every_mode(disk_scene, tmp_path, capsys, extra, reused):
     """A matches file kept by one run is consumed by the next instead of re-matching (sucre.py:185) -- also with
     --light-model (the camera points are rebuilt from the file's u2, v2, d like loader.py:113) and for resized images
-    (the kept colours are then float32, not k/255) -- and gives the same restoration."""
+    (the kept colours are then float32, not k/255) -- and gives the same restoration.  The light model on resized images
+    is the one mode whose kept file cannot be imported (it would need both extension sets filled from lists): the second
+    run says so, matches again and must still reproduce the first."""
     from sucre_amd import sucre
     root, scene, model, loaded = disk_scene
     name = scene.names[scene.target]
@@ -312,7 +316,7 @@ def test_cli_kept_matches_are_reused_in_every_mode(disk_scene, tmp_path, capsys,
     shutil.copy(kept[0], again / kept[0].name)
     sucre.main(base + ['--output-dir', str(again)])
     txt = capsys.readouterr().out
-    assert 'Compute' not in txt and 'Total of' in txt
+    assert ('Compute' not in txt) == reused and 'Total of' in txt and ('is not reused' in txt) == (not reused)
     a, b = torch.load(first / f'{stem}.pt'), torch.load(again / f'{stem}.pt')
     assert set(a) == set(b)
     assert np.array_equal(np.isnan(a['J'].numpy()), np.isnan(b['J'].numpy()))
@@ -437,6 +441,40 @@ def test_cli_image_scale_half(disk_scene, tmp_path):
     assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-6
     got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
     assert np.abs(got - po).max() < 1e-5
+
+
+def test_cli_light_model_on_resized_images(disk_scene, tmp_path):
+    """--light-model --image-scale 0.5, a combination the reference accepts (sfm.py:193-199, sucre.py:54-61): the
+    observations carry float32 colours AND camera points.  The oracle's light fit is fed the same resized inputs."""
+    from sucre_amd import sfm, sucre
+    root, scene, _, _ = disk_scene
+    name = scene.names[scene.target]
+    T = 10
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(tmp_path), '--image-name', name, '--num-iter', str(T), '--image-scale', '0.5', '--light-model'])
+    stem = Path(name).stem
+    state = torch.load(tmp_path / (stem + '.pt'))
+    assert set(state) == {'B', 'beta', 'gamma', 'cam2light', 'sigma', 'J'} and state['J'].shape == (32, 48, 3)
+    for f in ('_rgb.png', '_reconstruction.png', '_vignetting.png'):
+        assert (tmp_path / (stem + f)).exists()
+    model = sfm.COLMAPModel(root / 'model', root / 'images', root / 'depth', image_scale=0.5)
+    tgt = model[name]
+    H, W = tgt.camera.height, tgt.camera.width
+    cam = lambda im: oracle.make_cam(H, W, **helpers.cam_matrices(im.camera.K, im.pose.R.contiguous(), im.pose.t.contiguous()))
+    d1 = tgt.get_depth_map().numpy()
+    samples = []
+    for im in sorted(model.images.values(), key=lambda i: i.name):
+        m = oracle.match_view(d1, cam(tgt), im.get_depth_map().numpy(), cam(im))
+        if len(m) / (W * H) > 1e-6:
+            cP = oracle.unproject(cam(im), m.u2, m.v2, m.d)
+            samples.append((m.u1, m.v1, cP, im.get_rgb().numpy()[m.v2.astype(np.int64), m.u2.astype(np.int64)].T.copy()))
+    J0 = tgt.get_rgb().numpy().copy()
+    J0[d1 <= 0] = np.nan
+    Jo, po, to = oracle.fit_light(H, W, samples, J0, num_iter=T)
+    J = state['J'].numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 2e-5
+    got = np.concatenate([state[k].numpy().ravel() for k in ('B', 'beta', 'gamma', 'cam2light', 'sigma')])
+    assert np.abs(got[:9] - po[:9]).max() < 2e-5 and np.abs(got[9:] - po[9:]).max() < 1e-3
 
 
 def test_overlap_cull_sizes_the_workspace_and_changes_nothing(tmp_path, monkeypatch):

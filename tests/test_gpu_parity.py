@@ -562,3 +562,36 @@ def test_target_without_any_valid_depth():
     tr = r.fit(3).cpu().numpy()
     torch.cuda.synchronize()
     assert np.isnan(r.J().cpu().numpy()).all() and tr.shape == (3, 10)
+
+
+@pytest.mark.parametrize('closed', [False, True], ids=['J-parameter', 'closed-form'])
+def test_light_model_on_float32_colours(golden, closed):
+    """--light-model on images whose colours are float32 (what --image-scale produces; SUCRE_EXT_POINTS_COLOUR: camera
+    points in one set of extension planes, colours in a second one).  Fed colours that are exactly k/255 it must agree
+    with the uint8 light path (same model, the colour merely arrives as float32(k/255) instead of a byte), and with
+    the oracle's light fit."""
+    from sucre_amd import engine
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    fviews = [v.as_float_colour() for v in views]
+    T = 8
+    out = []
+    for vs, fc in ((views, False), (fviews, True)):
+        r = engine.Restoration(sc.height, sc.width, len(vs), light=True, float_colour=fc)
+        r.match(vs[sc.target], vs)
+        r.fit_init(vs[sc.target])
+        tr = r.fit(T, use_closed_form=closed).cpu().numpy()
+        out.append((r.n_obs(), r.view_counts().cpu().numpy().tolist(), r.J().cpu().numpy(), tr, r.params().cpu().numpy()))
+    (n0, c0, J0, t0, p0), (n1, c1, J1, t1, p1) = out
+    assert n0 == n1 and c0 == c1 and t1.shape == (T, 20) and p1.shape == (19,)
+    assert np.array_equal(np.isnan(J0), np.isnan(J1))
+    assert abs(t1[0, 0] / t0[0, 0] - 1) < 1e-6
+    assert helpers.rms_per_channel(J1, J0).max() < (1e-4 if closed else 2e-5)
+    assert np.abs(t1[:, 1:10] - t0[:, 1:10]).max() < (5e-5 if closed else 2e-5) and np.abs(t1[:, 10:] - t0[:, 10:]).max() < 1e-3
+    _, samples = helpers.oracle_scene_samples(sc)
+    tgt = sc.views[sc.target]
+    Jinit = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    Jo, po, to = oracle.fit_light(sc.height, sc.width, samples, Jinit, num_iter=T, use_closed_form=closed)
+    assert abs(t1[0, 0] / to[0, 0] - 1) < 1e-6
+    assert helpers.rms_per_channel(J1, Jo).max() < (1e-4 if closed else 2e-5)
+    assert np.abs(t1[:, 1:10] - to[:, 1:10]).max() < (5e-5 if closed else 2e-5)
