@@ -286,7 +286,8 @@ int sucre_finalize_matches_ext(void *ws, void *lws, int H, int W, int n_views, d
 /*
  * sucre_import_view with extension planes: ext_dev holds three float32 planes [3][n] -- the camera points cP of the
  * list (loader.py:113; ext_mode SUCRE_EXT_POINTS, rgb_dev required) or its colours I (loader.py:87; SUCRE_EXT_COLOUR,
- * for colours that are not k/255; rgb_dev may be NULL).  This is how a caller-built MatchesData (loader.py:36-53)
+ * for colours that are not k/255; rgb_dev may be NULL), or both as six planes [6][n], cP first (SUCRE_EXT_POINTS_COLOUR;
+ * rgb_dev may be NULL).  This is how a caller-built MatchesData (loader.py:36-53)
  * enters the engine; sucre_export_view_ext returns the planes of view k as (3, H, W), zero where nothing was observed.
  */
 int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,

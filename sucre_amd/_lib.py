@@ -10,7 +10,7 @@ import os
 from pathlib import Path
 
 ABI_VERSION = 1
-# SUCRE_HIP_LIB selects another build of the same ABI (experiment builds of tools/microbench.py); default = the product
+# SUCRE_HIP_LIB selects another build of the same ABI (experiment builds, tools/exp/build_variants.sh); default = the product
 LIB_PATH = Path(os.environ.get('SUCRE_HIP_LIB', Path(__file__).resolve().parent / 'libsucre_hip.so'))
 
 FIT_CLOSED_FORM = 1

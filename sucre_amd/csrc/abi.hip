@@ -405,11 +405,13 @@ int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k,
     if (int rc = check_lws(lws)) return rc;
     if (k < 0 || k >= n_views) return fail(SUCRE_ERR_RANGE, "view %d outside [0,%d)", k, n_views);
     if (n < 0) return fail(SUCRE_ERR_RANGE, "negative observation count %lld", (long long)n);
-    if (ext_mode != SUCRE_EXT_POINTS && ext_mode != SUCRE_EXT_COLOUR) return fail(SUCRE_ERR_ARG, "unknown extension mode %d", ext_mode);
+    if (ext_mode < SUCRE_EXT_POINTS || ext_mode > SUCRE_EXT_POINTS_COLOUR) return fail(SUCRE_ERR_ARG, "unknown extension mode %d", ext_mode);
     if (n > 0 && (!u1_dev || !v1_dev || !z_dev || !ext_dev)) return fail(SUCRE_ERR_ARG, "NULL match list");
     if (n > 0 && ext_mode == SUCRE_EXT_POINTS && !rgb_dev) return fail(SUCRE_ERR_ARG, "camera-point lists need uint8 colours too");
+    auto *l = static_cast<uint8_t *>(lws);
     return check_hip(launch_import_view(L, static_cast<uint8_t *>(ws), k, u1_dev, v1_dev, z_dev, rgb_dev, (long long)n,
-                                        static_cast<hipStream_t>(stream), light_ext_dense(L, static_cast<uint8_t *>(lws)), ext_dev),
+                                        static_cast<hipStream_t>(stream), light_ext_dense(L, l), ext_dev,
+                                        ext_mode == SUCRE_EXT_POINTS_COLOUR ? light_ext2_dense(L, l) : nullptr),
                      "sucre_import_view_ext");
 }
 

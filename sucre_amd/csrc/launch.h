@@ -33,7 +33,7 @@ hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const s
                             int32_t *map, hipStream_t s);
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
                               const uint8_t *rgb, long long n, hipStream_t s, uint8_t *ext_dense = nullptr,
-                              const float *ext = nullptr);
+                              const float *ext = nullptr, uint8_t *ext2_dense = nullptr);
 hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s);
 hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipStream_t s,
                            const uint8_t *ext_dense = nullptr, uint8_t *ext_comp = nullptr, int fmt = SUCRE_OBS_F32,

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void import_view_kernel(uint8_t *__restrict__ 
                                                           const int16_t *__restrict__ u1, const int16_t *__restrict__ v1,
                                                           const float *__restrict__ z, const uint8_t *__restrict__ rgb,
                                                           long long n, uint8_t *__restrict__ ext_dense, int n_views,
-                                                          const float *__restrict__ ext) {
+                                                          const float *__restrict__ ext, uint8_t *__restrict__ ext2_dense) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int u = u1[i], v = v1[i];
@@ -322,6 +322,11 @@ __global__ __launch_bounds__(256) void import_view_kernel(uint8_t *__restrict__ 
         float *e = reinterpret_cast<float *>(ext_dense + ((size_t)tile * n_views + k) * kExtChunk);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) e[pl * kTilePx + slot] = ext[(size_t)pl * n + i];
+        if (ext2_dense) {   // SUCRE_EXT_POINTS_COLOUR: planes 3..5 of the list are the float32 colours
+            float *e2 = reinterpret_cast<float *>(ext2_dense + ((size_t)tile * n_views + k) * kExtChunk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) e2[pl * kTilePx + slot] = ext[(size_t)(3 + pl) * n + i];
+        }
     }
 }
 
@@ -366,13 +371,14 @@ hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint
 }
 
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
-                              const uint8_t *rgb, long long n, hipStream_t s, uint8_t *ext_dense, const float *ext) {
+                              const uint8_t *rgb, long long n, hipStream_t s, uint8_t *ext_dense, const float *ext,
+                              uint8_t *ext2_dense) {
     auto *cnt = reinterpret_cast<uint16_t *>(ws + L.off_cnt);
     hipLaunchKernelGGL(clear_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
                        L.obs_tile_stride, L.obs_view_stride);
     if (n > 0)
         hipLaunchKernelGGL(import_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws + L.off_obs, k,
-                           L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n, ext_dense, L.n_views, ext);
+                           L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n, ext_dense, L.n_views, ext, ext2_dense);
     hipLaunchKernelGGL(count_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
                        L.obs_tile_stride, L.obs_view_stride);
     return hipGetLastError();

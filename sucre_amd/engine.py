@@ -179,10 +179,8 @@ class Restoration:
         (int16[n], int16[n], float32[n], uint8[n,3]) -- what one group of a reference matches file provides after
         ``cP = unproject_depth(u2, v2, d)`` and ``z = ||cP||`` (loader.py:103-118, sucre.py:53).  A fifth element, a
         float32 (3, n) tensor, fills the extension planes of a ``light`` restoration (the camera points cP) or of a
-        ``float_colour`` one (the colours I; ``rgb_u8`` may then be None)."""
+        ``float_colour`` one (the colours I; ``rgb_u8`` may then be None); a restoration that is both takes (6, n): cP, then I."""
         assert 1 <= len(lists) <= self.capacity, (len(lists), self.capacity)
-        if self.both:
-            raise NotImplementedError('explicit match lists for the light model on float32 colours (two extension sets)')
         self.n_views = len(lists)
         self._keepalive = [target, lists]
         self._views_dev = None
@@ -201,7 +199,8 @@ class Restoration:
                 self._keepalive.append((u1, v1, z, rgb))
                 rgbp = C.c_void_p(rgb.data_ptr()) if rgb is not None else None
                 if self.lws is not None:
-                    assert ext is not None and ext.shape == (3, u1.numel()), 'this restoration needs the (3, n) extension planes'
+                    planes = 6 if self.both else 3   # both: the camera points, then the float32 colours
+                    assert ext is not None and ext.shape == (planes, u1.numel()), f'this restoration needs ({planes}, n) extension planes'
                     ext = ext.to(self.device, torch.float32).contiguous()
                     self._keepalive.append(ext)
                     _lib.check(self.lib.sucre_import_view_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, k,
@@ -212,8 +211,8 @@ class Restoration:
                     _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
                                                           C.c_void_p(z.data_ptr()), rgbp, u1.numel(), _stream_ptr()))
             if self.lws is not None:
-                _lib.check(self.lib.sucre_finalize_matches_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
-                                                                 float(min_cover), _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
+                                                               float(min_cover), self._ext_mode, _stream_ptr()))
             else:
                 _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
 

@@ -361,15 +361,13 @@ class MatchesData:
             I = s.I.to(torch.float32)
             k255 = I.to(torch.float64) * 255
             integral = integral and bool(((k255 - k255.round()).abs() < 1e-3).all()) and bool(((k255 >= 0) & (k255 <= 255)).all())
-        if light and not integral:
-            raise NotImplementedError('the light model on observations with float32 colours (resized images): both '
-                                      'need the extension planes')
         for s in self.data:
             cP = s.cP.to(torch.float32)
             z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
             I = s.I.to(torch.float32)
             rgb = (I.to(torch.float64) * 255).round().to(torch.uint8).T.contiguous() if integral else None
-            ext = cP.contiguous() if light else (None if integral else I.contiguous())
+            ext = (torch.cat([cP, I]).contiguous() if (light and not integral)      # both extension sets
+                   else cP.contiguous() if light else (None if integral else I.contiguous()))
             lists.append((s.u, s.v, z, rgb) if ext is None else (s.u, s.v, z, rgb, ext))
         resto = engine.acquire_restoration(height, width, len(lists), device, light=light, float_colour=not integral,
                                            tag='lists')
@@ -551,9 +549,6 @@ class MatchesFile:
         for ds in groups.values():
             k255 = ds['I'].astype(np.float64) * 255
             float_colour = float_colour or bool(k255.size and np.abs(k255 - np.rint(k255)).max() > 1e-3)
-        if float_colour and light:
-            raise NotImplementedError(f'{self.path}: --light-model on kept matches of resized images (float32 colours and '
-                                      f'the camera points share the same extension planes)')
         images, lists = [], []
         for name, ds in groups.items():
             im = self.colmap_model[name]
@@ -564,7 +559,9 @@ class MatchesFile:
             cP = im.unproject_depth(u=u2, v=v2, d=torch.tensor(ds['d']))
             z = torch.sqrt((cP[0] * cP[0] + cP[1] * cP[1]) + cP[2] * cP[2])
             item = [torch.tensor(ds['u1']), torch.tensor(ds['v1']), z]
-            if float_colour:
+            if float_colour and light:   # both extension sets: the camera points, then the float32 colours
+                item += [None, torch.cat([cP.to(torch.float32).reshape(3, -1), torch.tensor(ds['I'].astype(np.float32)).reshape(3, -1)])]
+            elif float_colour:
                 item += [None, torch.tensor(ds['I'].astype(np.float32)).reshape(3, -1)]
             else:
                 item.append(torch.tensor(np.rint(ds['I'].astype(np.float64) * 255).astype(np.uint8).T.copy()))

@@ -292,14 +292,13 @@ def test_cli_light_model_closed_form(disk_scene, tmp_path):
 
 @pytest.mark.parametrize('extra,reused', [(['--light-model'], True), (['--image-scale', '0.5'], True),
                                           (['--light-model', '--use-closed-form'], True),
-                                          (['--light-model', '--image-scale', '0.5'], False)],
+                                          (['--light-model', '--image-scale', '0.5'], True)],
                          ids=['light-model', 'image-scale', 'light-closed-form', 'light-image-scale'])
 def test_cli_kept_matches_are_reused_in_every_mode(disk_scene, tmp_path, capsys, extra, reused):
     """A matches file kept by one run is consumed by the next instead of re-matching (sucre.py:185) -- also with
     --light-model (the camera points are rebuilt from the file's u2, v2, d like loader.py:113) and for resized images
-    (the kept colours are then float32, not k/255) -- and gives the same restoration.  The light model on resized images
-    is the one mode whose kept file cannot be imported (it would need both extension sets filled from lists): the second
-    run says so, matches again and must still reproduce the first."""
+    (the kept colours are then float32, not k/255) -- and gives the same restoration.  (A file the engine cannot import
+    would be reported as not reused and matched again: `reused` says which behaviour a mode must show.)"""
     from sucre_amd import sucre
     root, scene, model, loaded = disk_scene
     name = scene.names[scene.target]
