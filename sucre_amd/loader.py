@@ -29,10 +29,9 @@ MatchesSample = namedtuple('MatchesSample', ['u', 'v', 'cP', 'I'])
 # ---- pixel loaders ----------------------------------------------------------------------------------------------------
 
 def _decode_pool():
-    """The worker processes, if image files are to be decoded there (SUCRE_DECODE_IN_WORKERS=1).  Off by default: PIL's
-    decoder scales to only ~4 threads' worth over 16 threads, but on the 48-image test survey starting enough workers
-    cost more at start-up (first image submitted after 1.4 s instead of 0.5 s) than their throughput gave back."""
-    return _pixelio.POOL if os.environ.get('SUCRE_DECODE_IN_WORKERS', '0') != '0' else None
+    """The worker processes, when the CLI has started some (image files are decoded there: PIL's decoder scales to only
+    ~4 threads' worth over 16 threads; SUCRE_DECODE_IN_WORKERS=0 keeps decoding in this process's threads)."""
+    return _pixelio.POOL if os.environ.get('SUCRE_DECODE_IN_WORKERS', '1') != '0' else None
 
 
 def _imread_rgb_u8(path: Path) -> np.ndarray:

@@ -216,6 +216,12 @@ class Image:
                     depth = self.get_depth_map().to(dev).contiguous()
                 else:
                     depth = (mm.to(dev).to(torch.float64) / 1000).to(torch.float32).contiguous()
+                    # the valid depth range (overlapping_views) from the stored integers, here on the decode thread: the
+                    # conversion is monotone, so these are the extremes of `depth` itself -- and the thread that drives
+                    # the GPU does not have to launch (and, the first time, load) three torch kernels and wait for them
+                    pos = mm[mm > 0]
+                    self.__dict__['_depth_range'] = ((float(np.float32(np.float64(int(pos.min())) / 1000)),
+                                                      float(np.float32(np.float64(int(pos.max())) / 1000))) if pos.numel() else ())
             view = engine.DeviceView(depth=depth, rgb=rgb.to(dev).contiguous(),
                                      K=self.camera.K, R=self.pose.R, t=self.pose.t, name=self.name)
             if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):

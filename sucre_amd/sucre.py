@@ -498,9 +498,10 @@ def parse_args(args: argparse.Namespace):
     in_flight = int(os.environ.get('SUCRE_IMAGES_IN_FLIGHT', '2'))   # engine knob, not a reference flag
     survey = len(images) > 1 and in_flight > 1 and args.save_interval is None and str(device).startswith('cuda')
     if survey:
-        # the result pictures are encoded by child processes (_pixelio.WorkerPool: CPU work in the process that drives
-        # the GPU slows its launches down); SUCRE_IO_PROCESSES=0 keeps the encoding in this process's writer threads
-        n_io = int(os.environ.get('SUCRE_IO_PROCESSES', min(8, max(1, loader.effective_cpus() // 2))))
+        # image files are decoded and the result pictures encoded by child processes (_pixelio.WorkerPool: CPU work in
+        # the process that drives the GPU slows its launches down, and PIL's decoder does not scale over threads);
+        # SUCRE_IO_PROCESSES=0 keeps both in this process's threads
+        n_io = int(os.environ.get('SUCRE_IO_PROCESSES', max(1, loader.effective_cpus() - 2)))
         if n_io > 0:
             _pixelio.start_pool(n_io)
     try:

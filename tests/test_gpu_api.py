@@ -610,3 +610,17 @@ def test_plot_J_on_the_device_is_the_reference_picture(golden):
     assert model.J.is_cuda
     assert np.array_equal(np.asarray(model.plot_J()), golden['plot_J_200'])
     assert np.array_equal(np.asarray(model.cpu().plot_J()), golden['plot_J_200'])    # and the host path
+
+
+def test_depth_range_from_the_stored_integers_is_the_range_of_the_device_depth(disk_scene):
+    """Image.depth_range (the overlap cull's input) is taken from the decoded uint16 millimetres on the host; it must be
+    exactly the extremes of the float32 depth map the engine holds (loader.py:167-170 conversion is monotone)."""
+    root, scene, model, loaded = disk_scene
+    for im in list(model.images.values())[:3]:
+        im.release_device(); im.__dict__.pop('_depth_range', None)
+        view = im.device_view('cuda')
+        d = view.depth
+        got = im.depth_range('cuda')
+        assert got == (float(d[d > 0].min()), float(d.max()))
+        im.__dict__.pop('_depth_range', None)      # and the device-side evaluation agrees
+        assert im.depth_range('cuda') == got
