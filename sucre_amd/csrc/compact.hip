@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict
 //     staged view (one set: the light model's camera points or float32 colours; two: both).
 template <int kExt>
 struct StageCfg {
-    static constexpr int kViews = kExt == 0 ? 32 : (kExt == 1 ? 16 : 8);   // 56 KB / 76 KB / 62 KB of LDS
+    // 16 views of 1792 B = 28 KB of LDS (5 workgroups per CU; 32 views = 2 workgroups per CU were 0.07 ms slower per
+    // image, 8 views no better) / 16 x 4864 B = 76 KB / 8 x 7936 B = 62 KB
+    static constexpr int kViews = kExt == 0 ? 16 : (kExt == 1 ? 16 : 8);
     static constexpr int kBytes = kChunk + kExt * kExtChunk;
 };
 
