@@ -37,12 +37,22 @@ def _decode_pool():
 def _imread_rgb_u8(path: Path) -> np.ndarray:
     """The colour image as stored (loader.py:157)."""
     pool = _decode_pool()
-    return pool.read(path) if pool is not None else _pixelio.imread_rgb_u8(path)
+    if pool is not None:
+        try:
+            return pool.read(path)
+        except _pixelio.WorkerLost:
+            pass   # the worker died mid-request: decode here instead
+    return _pixelio.imread_rgb_u8(path)
 
 
 def _imread_depth_u16(path: Path) -> np.ndarray:
     pool = _decode_pool()
-    return pool.read(path, depth=True) if pool is not None else _pixelio.imread_depth_u16(path)
+    if pool is not None:
+        try:
+            return pool.read(path, depth=True)
+        except _pixelio.WorkerLost:
+            pass
+    return _pixelio.imread_depth_u16(path)
 
 
 def load_rgb_u8(rgb_path: Path, width: int, height: int) -> Tensor | None:
