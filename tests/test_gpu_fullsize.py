@@ -122,3 +122,34 @@ def test_config5_shape_u16mm_vs_oracle(closed):
              cost_bar=1e-4 if closed else COST_BAR, label=f'config5-shape u16mm closed={closed}')
     if closed:
         assert abs(eng[2][0, 0] / orc[2][0, 0] - 1) < 1e-6   # the first iteration has no trajectory behind it
+
+
+@pytest.mark.timeout(1200)
+def test_config2_light_model_vs_oracle():
+    """The artificial-light model at config-2 size (79 M observations, 19 B/observation with the camera points): five
+    iterations against the oracle's analytic light fit.  The light parameters' gradients sit at Adam's eps, so they
+    carry the loose bar of tests/test_gpu_parity.py; cost, J and the water parameters the tight ones."""
+    from sucre_amd import engine, synth
+    scene = synth.make_scene(1920, 1080, 64, seed=0, device='cuda')
+    views = engine.device_views_from_scene(scene, 'cuda')
+    r = engine.Restoration(scene.height, scene.width, len(views), light=True)
+    r.match(views[scene.target], views)
+    r.fit_init(views[scene.target])
+    T = 5
+    tr = r.fit(T).cpu().numpy()
+    J = r.J().cpu().numpy()
+    n = r.n_obs()
+    del r, views
+    torch.cuda.empty_cache()
+    host = _host_scene(scene)
+    per_view, samples = helpers.oracle_scene_samples(host)
+    tgt = host.views[host.target]
+    Jo, po, to = oracle.fit_light(host.height, host.width, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()), num_iter=T)
+    assert n == sum(len(s[0]) for s in samples)
+    rms = helpers.rms_per_channel(J, Jo)
+    print(f'config2 light: n_obs={n} rms(J)={rms} water {np.abs(tr[:, 1:10] - to[:, 1:10]).max():.3e} '
+          f'light {np.abs(tr[:, 10:] - to[:, 10:]).max():.3e} cost rel {np.abs(tr[:, 0] / to[:, 0] - 1).max():.3e}')
+    assert np.array_equal(np.isnan(J), np.isnan(Jo))
+    assert abs(tr[0, 0] / to[0, 0] - 1) < 1e-6
+    assert rms.max() < 2e-5 and np.abs(tr[:, 1:10] - to[:, 1:10]).max() < 2e-5
+    assert np.abs(tr[:, 10:] - to[:, 10:]).max() < 1e-3
