@@ -108,13 +108,51 @@ def _resize_area(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
     return out
 
 
+def _cubic_taps(ssize: int, dsize: int) -> tuple[np.ndarray, np.ndarray]:
+    """Source indices and weights of OpenCV's INTER_CUBIC along one axis (its generic resize path): destination ``d``
+    samples the source at ``(d + 0.5) * scale - 0.5`` with the four-tap cubic kernel of parameter A = -0.75, position
+    and weights in float32 as OpenCV computes them, taps outside the image clamped to the border pixel.  Returns
+    ``(index, weight)`` of shape (dsize, 4)."""
+    scale = 1.0 / (dsize / ssize)
+    A = np.float32(-0.75)
+    idx = np.zeros((dsize, 4), np.int64)
+    wgt = np.zeros((dsize, 4), np.float64)
+    one = np.float32(1.0)
+    for d in range(dsize):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(np.floor(fx))
+        x = np.float32(fx - np.float32(sx))
+        c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+        c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+        c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+        c3 = one - c0 - c1 - c2
+        for j, c in enumerate((c0, c1, c2, c3)):
+            idx[d, j] = min(max(sx - 1 + j, 0), ssize - 1)
+            wgt[d, j] = float(np.float32(c))
+    return idx, wgt
+
+
+def _resize_cubic(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
+    """INTER_CUBIC of a float64 image (what the reference's loader uses when it enlarges, loader.py:158-162): rows
+    filtered horizontally first, then vertically, every four-tap sum taken left to right in float64."""
+    ix, wx = _cubic_taps(rgb.shape[1], width)
+    iy, wy = _cubic_taps(rgb.shape[0], height)
+    cols = rgb[:, ix[:, 0]] * wx[None, :, 0, None]
+    for k in range(1, 4):
+        cols = cols + rgb[:, ix[:, k]] * wx[None, :, k, None]
+    out = cols[iy[:, 0]] * wy[:, 0, None, None]
+    for k in range(1, 4):
+        out = out + cols[iy[:, k]] * wy[:, k, None, None]
+    return out
+
+
 def _resize_rgb(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
     """The reference's resize of the float64 colour image (loader.py:158-162): OpenCV INTER_AREA when shrinking,
     INTER_CUBIC otherwise.  OpenCV is used when it is installed.  Without it, shrinking is restated here from
     OpenCV's published algorithm: integer factors (--image-scale 0.5 / 0.25) the way its fast path does them (the
     block's pixels summed in row-major order, times 1/area), any other factor by `_resize_area`.  The restatement
     could not be checked against OpenCV in the build image (no cv2 there): install opencv-python where bit-identical
-    --image-scale output matters.  Enlarging (INTER_CUBIC) needs OpenCV."""
+    --image-scale output matters.  Enlarging (INTER_CUBIC, `_resize_cubic`) is restated the same way."""
     try:
         import cv2
         return cv2.resize(rgb, (width, height), interpolation=cv2.INTER_AREA if width < rgb.shape[1] else cv2.INTER_CUBIC)
@@ -130,8 +168,9 @@ def _resize_rgb(rgb: np.ndarray, width: int, height: int) -> np.ndarray:
         return acc * float(np.float32(1.0) / np.float32(fx * fy))   # OpenCV keeps 1/area in float32
     if width < W0 and height <= H0:
         return _resize_area(rgb, width, height)
-    raise NotImplementedError(f'resizing {W0}x{H0} to {width}x{height} (enlarging: INTER_CUBIC) needs OpenCV, which is '
-                              f'not installed')
+    if width < W0:   # (narrower but taller: OpenCV would still take INTER_AREA, whose tap table does not enlarge)
+        raise NotImplementedError(f'resizing {W0}x{H0} to {width}x{height} needs OpenCV, which is not installed')
+    return _resize_cubic(rgb, width, height)
 
 
 def load_rgb(rgb_path: Path, width: int, height: int) -> Tensor:

@@ -546,8 +546,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help='solve J in closed form from the water parameters instead of optimising it')
     p.add_argument('--min-cover', type=float, default=0.000001,
                    help='drop a neighbour whose matches cover at most this fraction of the image')
-    p.add_argument('--image-scale', type=float, default=1.0, help='rescale factor applied to all images (colour: OpenCV INTER_AREA when shrinking, used when cv2 is '
-                        'installed and restated otherwise; enlarging needs cv2; depth: nearest neighbour)')
+    p.add_argument('--image-scale', type=float, default=1.0, help='rescale factor applied to all images (colour: OpenCV INTER_AREA when shrinking, INTER_CUBIC when '
+                        'enlarging -- cv2 is used when installed, otherwise both are restated from its published algorithms, '
+                        'unchecked against cv2 itself; depth: nearest neighbour)')
     p.add_argument('--filter-images-path', type=Path, help='text file of image names never used as neighbours')
     p.add_argument('--learning-rate', type=float, default=0.05, help='Adam learning rate')
     p.add_argument('--num-iter', type=int, default=200, help='Adam iterations')

@@ -150,8 +150,7 @@ def test_pixel_loaders_reproduce_reference_quantisation(tmp_path):
     assert half.dtype == torch.float32 and np.array_equal(half.numpy(), want.astype(np.float32))
     dh = loader.load_depth_map(tmp_path / 'depth_a.png', width=4, height=3)
     assert np.array_equal(dh.numpy(), (depth[0::2, 0::2].astype(np.float64) / 1000).astype(np.float32))
-    with pytest.raises(NotImplementedError, match='OpenCV'):
-        loader.load_rgb(tmp_path / 'a.png', width=16, height=12)   # enlarging is INTER_CUBIC: not restated
+    assert loader.load_rgb(tmp_path / 'a.png', width=16, height=12).shape == (12, 16, 3)   # enlarging: INTER_CUBIC restated
     assert loader.load_rgb(tmp_path / 'a.png', width=5, height=4).shape == (4, 5, 3)
 
 
@@ -496,8 +495,16 @@ def test_area_resize_without_opencv():
                 ref[y, x] = acc / (sx * sy)
         assert np.abs(out - ref).max() < 2e-3   # OpenCV drops slivers below 1e-3 of a pixel and keeps float32 weights
         assert np.abs(loader._resize_rgb(np.ones((36, 60, 3)), w, h) - 1).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        loader._resize_rgb(img, 120, 72)
+    # enlarging = INTER_CUBIC (A = -0.75): weights sum to one, constants survive, and a ramp comes out as that kernel's
+    # first moment makes it (it does not reproduce linear functions: 0.25 -> 0.296875 for the tap set (-1, 0, 1, 2))
+    up = loader._resize_rgb(img, 120, 72)
+    assert up.shape == (72, 120, 3) and np.abs(loader._resize_rgb(np.full((36, 60, 3), 0.37), 120, 72) - 0.37).max() < 1e-6
+    idx, wgt = loader._cubic_taps(60, 120)
+    assert np.abs(wgt.sum(axis=1) - 1).max() < 1e-6 and idx.min() == 0 and idx.max() == 59
+    d = 9                                       # samples the source at (9.5 * 0.5 - 0.5) = 4.25
+    assert idx[d].tolist() == [3, 4, 5, 6] and abs(float((wgt[d] * np.arange(-1, 3)).sum()) - 0.296875) < 1e-6
+    ramp = np.tile(np.arange(60, dtype=np.float64)[None, :, None], (36, 1, 3))
+    assert abs(loader._resize_rgb(ramp, 120, 72)[10, d, 0] - (4 + 0.296875)) < 1e-5
 
 
 def test_png_writer_keeps_every_pixel(tmp_path, monkeypatch):
