@@ -2,7 +2,7 @@
 """Randomised parity sweep on the GPU box: many small scenes (odd sizes, few/many views, steep relief, large twist
 noise, many invalid pixels, far views) -- matching must be bit-identical to the CPU oracle and the fit must stay
 within the test tolerances, in every mode.  Not a test (too long for the suite); run by hand:
-    python3 tools/parity_sweep.py [n_scenes] [seed0]"""
+    python3 tools/parity_sweep.py [n_scenes] [seed0] [max_width max_height]"""
 import os
 import sys
 import time
@@ -21,11 +21,12 @@ from sucre_amd import engine, synth  # noqa: E402
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    max_w, max_h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (260, 200)
     rng = np.random.default_rng(seed0)
     worst = {'J': 0.0, 'Jc': 0.0, 'Ju': 0.0, 'p': 0.0, 'pc': 0.0}
     t0 = time.time()
     for s in range(n_scenes):
-        W, H = int(rng.integers(33, 260)), int(rng.integers(33, 200))
+        W, H = int(rng.integers(33, max_w)), int(rng.integers(33, max_h))
         nn = int(rng.integers(1, 14))
         kw = dict(relief=float(rng.choice([0.0, 0.15, 0.6])), spacing=float(rng.choice([0.05, 0.1, 0.25, 0.5])),
                   invalid_frac=float(rng.choice([0.0, 0.01, 0.3])), rot_sigma=float(rng.choice([0.0, 0.03, 0.15])),
