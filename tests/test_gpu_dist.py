@@ -66,6 +66,33 @@ def test_bench_launches_its_own_ranks(extra):
 
 
 @pytest.mark.timeout(600)
+def test_bench_json_line_keeps_the_contract():
+    """`python bench.py` at N = 1: one JSON line with every key of the driver's contract, the roofline block and (on a
+    tiny sample) the CPU baseline leg."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, str(ROOT / 'bench.py'), '--steps', '2', '--warmup', '1', '--width', '320', '--height', '240',
+           '--neighbours', '8', '--num-iter', '6', '--solo-images', '1', '--cpu-views', '3', '--cpu-iters', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in rec, key
+    assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['warmup'] == 1 and rec['higher_is_better'] is True
+    assert rec['unit'] == 'Mpix/s' and rec['dtype'] == 'f32' and rec['data'] == 'synthetic' and rec['vs_baseline'] is None
+    assert 'workload' in rec['config'] and 'model' not in rec['config']
+    roof = rec['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in roof, key
+    assert roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12
+    cpu = rec['cpu_baseline']
+    assert cpu['kind'] == 'port' and cpu['cores'] >= 1 and cpu['value'] > 0 and 'sample' in cpu
+    assert abs(rec['value'] - 2 * 320 * 240 / 1e6 / (rec['ms_per_step'] * 2e-3)) < 1e-6 * rec['value']   # value = work / time
+
+
+@pytest.mark.timeout(600)
 def test_results_do_not_depend_on_who_else_uses_the_gpu(golden):
     """Two processes fitting at the same time (workgroups of a launch no longer start together, latencies stretch):
     every repetition in both processes, on the fused per-image path and on the single-launch group path, must be the
