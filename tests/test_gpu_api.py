@@ -624,3 +624,72 @@ def test_depth_range_from_the_stored_integers_is_the_range_of_the_device_depth(d
         assert got == (float(d[d > 0].min()), float(d.max()))
         im.__dict__.pop('_depth_range', None)      # and the device-side evaluation agrees
         assert im.depth_range('cuda') == got
+
+
+def _cli(root, out, *extra):
+    from sucre_amd import sucre
+    sucre.main(['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+                '--output-dir', str(out)] + [str(x) for x in extra])
+
+
+def test_cli_flags_that_shape_the_problem(disk_scene, tmp_path, capsys):
+    """The reference's remaining command-line flags end to end (sucre.py:222-261, 264-305): --filter-images-path removes
+    neighbour views, --min-cover drops thin ones, --learning-rate and --params-path reach the optimiser, --image-list
+    selects the targets, --force-compute-matches ignores a kept file, --batch-size / --num-workers change nothing."""
+    root, scene, model, loaded = disk_scene
+    name = scene.names[scene.target]
+    stem = Path(name).stem
+    tgt = loaded.views[loaded.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    H, W = loaded.height, loaded.width
+
+    # --filter-images-path: the listed image is no neighbour any more (sucre.py:238-239)
+    dropped = scene.names[0] if scene.target != 0 else scene.names[1]
+    (tmp_path / 'skip.txt').write_text(dropped + '\n')
+    _cli(root, tmp_path / 'f', '--image-name', name, '--num-iter', 6, '--filter-images-path', tmp_path / 'skip.txt')
+    txt = capsys.readouterr().out
+    per_view, samples = helpers.oracle_scene_samples(loaded)
+    keep = [i for i, v in enumerate(loaded.views) if v.name != dropped]
+    kept_names = [vname for vname, kept, _ in per_view if kept]            # `samples` holds the kept views, in this order
+    sub = [s for vname, s in zip(kept_names, samples) if vname != dropped]
+    assert f'Total of {sum(len(s[0]) for s in sub)} observations.' in txt
+    Jo, po, to = oracle.fit(H, W, sub, J0, num_iter=6)
+    st = torch.load(tmp_path / 'f' / f'{stem}.pt')
+    assert helpers.rms_per_channel(st['J'].numpy(), Jo).max() < 1e-5
+    assert len(keep) == len(loaded.views) - 1
+
+    # --min-cover 0.8 (strict >, sfm.py:136) and --learning-rate
+    _, samples80 = helpers.oracle_scene_samples(loaded, 0.8)
+    _cli(root, tmp_path / 'm', '--image-name', name, '--num-iter', 6, '--min-cover', 0.8, '--learning-rate', 0.01)
+    txt = capsys.readouterr().out
+    assert f'Total of {sum(len(s[0]) for s in samples80)} observations.' in txt
+    Jo, po, to = oracle.fit(H, W, samples80, J0, num_iter=6, lr=0.01)
+    st = torch.load(tmp_path / 'm' / f'{stem}.pt')
+    got = np.concatenate([st[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
+    assert helpers.rms_per_channel(st['J'].numpy(), Jo).max() < 1e-5 and np.abs(got - po).max() < 1e-5
+
+    # --params-path: the water parameters start from a saved state (sucre.py:206-207)
+    start = {'B': torch.tensor([[0.2], [0.3], [0.4]]), 'beta': torch.tensor([[0.15], [0.12], [0.11]]),
+             'gamma': torch.tensor([[0.05], [0.25], [0.3]])}
+    torch.save(start, tmp_path / 'start.pt')
+    _cli(root, tmp_path / 'p', '--image-name', name, '--num-iter', 5, '--params-path', tmp_path / 'start.pt',
+         '--batch-size', 3, '--num-workers', 2)
+    capsys.readouterr()
+    p0 = np.concatenate([start[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
+    Jo, po, to = oracle.fit(H, W, samples, J0, params0=p0, num_iter=5)
+    st = torch.load(tmp_path / 'p' / f'{stem}.pt')
+    got = np.concatenate([st[k].numpy().ravel() for k in ('B', 'beta', 'gamma')])
+    assert np.abs(got - po).max() < 1e-5 and helpers.rms_per_channel(st['J'].numpy(), Jo).max() < 1e-5
+
+    # --image-list selects the targets; --keep-matches then --force-compute-matches
+    names = [scene.names[scene.target], scene.names[(scene.target + 1) % len(scene.names)]]
+    (tmp_path / 'targets.txt').write_text('\n'.join(names) + '\n')
+    _cli(root, tmp_path / 'l', '--image-list', tmp_path / 'targets.txt', '--num-iter', 4, '--keep-matches')
+    txt = capsys.readouterr().out
+    assert txt.count('Compute') == 2
+    for n in names:
+        assert (tmp_path / 'l' / (Path(n).stem + '.pt')).exists() and (tmp_path / 'l' / (Path(n).stem + '_rgb.png')).exists()
+    _cli(root, tmp_path / 'l', '--image-list', tmp_path / 'targets.txt', '--num-iter', 4, '--keep-matches')
+    assert 'Compute' not in capsys.readouterr().out                       # kept files are consumed ...
+    _cli(root, tmp_path / 'l', '--image-list', tmp_path / 'targets.txt', '--num-iter', 4, '--force-compute-matches')
+    assert capsys.readouterr().out.count('Compute') == 2                  # ... unless matching is forced
