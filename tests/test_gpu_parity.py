@@ -595,3 +595,25 @@ def test_light_model_on_float32_colours(golden, closed):
     assert abs(t1[0, 0] / to[0, 0] - 1) < 1e-6
     assert helpers.rms_per_channel(J1, Jo).max() < (1e-4 if closed else 2e-5)
     assert np.abs(t1[:, 1:10] - to[:, 1:10]).max() < (5e-5 if closed else 2e-5)
+
+
+@pytest.mark.timeout(600)
+def test_six_hundred_views_of_a_small_image():
+    """More views than count bins (256) and than one 64-bit view mask word: 600 views of a 64x48 image (spacing so small
+    that every view overlaps the target) -- matching bit-exact, per-pixel counts up to 600, the fit against the oracle."""
+    from sucre_amd import synth
+    scene = synth.make_scene(64, 48, 599, seed=77, spacing=0.004)
+    r, views, samples = _check_matching(scene)
+    assert len(samples) > 500 and r.n_obs() > 500 * 64 * 48 // 2
+    tgt = scene.views[scene.target]
+    for closed in (False, True):
+        r.fit_init(views[scene.target])
+        tr = r.fit(6, use_closed_form=closed).cpu().numpy()
+        J = r.J().cpu().numpy()
+        J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+        Jo, po, to = oracle.fit(48, 64, samples, J0, num_iter=6, use_closed_form=closed)
+        assert np.array_equal(np.isnan(J), np.isnan(Jo))
+        assert helpers.rms_per_channel(J, Jo).max() < (1e-4 if closed else 1e-5)
+        assert np.abs(tr[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
+        assert abs(tr[0, 0] / to[0, 0] - 1) < 1e-6                                         # no step behind the first cost
+        assert np.abs(tr[:, 0] / to[:, 0] - 1).max() < (1e-4 if closed else 1e-5)          # closed form amplifies (DESIGN 5)
