@@ -53,6 +53,9 @@ def parse():
                    help="observation store: f32 = 7 B/obs, lossless (configs 1-4); u16mm = 5 B/obs (config 5)")
     p.add_argument('--solo-images', type=int, default=3,
                    help='images restored one at a time after the timed region for the roofline block')
+    p.add_argument('--timeout-s', type=float, default=1500.0,
+                   help='a rank (and, without a launcher, the whole N-rank job) that has produced no result after this long '
+                        'says where it is stuck and exits non-zero')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=65, help='views in the CPU-baseline sample (65 = all of config 2)')
     p.add_argument('--cpu-iters', type=int, default=100, help='Adam iterations in the CPU-baseline sample (~15 s of CPU '
@@ -106,20 +109,74 @@ def cpu_baseline(scene, n_obs_full, n_views_full, num_iter, sample_views, sample
 
 def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves (one process per GPU, the same
-    environment contract torchrun provides) and return the worst exit code.  Runs BEFORE anything in this process
-    touches the GPU; the children are ordinary child processes (never an exec of a GPU-initialised process)."""
+    environment contract torchrun provides) and return 0 only if every rank exited cleanly.  Runs BEFORE anything in
+    this process touches the GPU; the children are ordinary child processes (never an exec of a GPU-initialised
+    process).  All children are polled together: the first one that fails (non-zero OR killed by a signal, i.e. a
+    negative return code) takes the others down with it instead of leaving them in a collective until its timeout,
+    and after ``--timeout-s`` the whole job is killed and reported as failed."""
     import socket
     import subprocess
+    from sucre_amd.loader import effective_cpus
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
+    threads = max(1, effective_cpus() // args.gpus)   # N ranks share the CPU quota: no 256-thread OpenMP teams per rank
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(threads))
+        env.setdefault('MKL_NUM_THREADS', str(threads))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
-    return max(p.wait() for p in procs)
+    deadline = time.monotonic() + args.timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f'rank {bad[0][0]} exited with code {bad[0][1]}'
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.monotonic() > deadline:
+            failed = f'no result after --timeout-s {args.timeout_s:.0f} s; still running: ranks {[r for r, c in enumerate(codes) if c is None]}'
+            break
+        time.sleep(0.2)
+    print(f'bench.py: {failed}; stopping the other ranks', file=sys.stderr, flush=True)
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return 1
+
+
+STAGE = ['start']
+
+
+def watchdog(rank: int, timeout_s: float) -> None:
+    """Every rank gives itself ``--timeout-s``: a rank stuck in a collective (or anywhere else) says where and exits with
+    code 3, under torchrun as well as under spawn_ranks (a fresh exit, never a re-exec of a GPU-initialised process)."""
+    import threading
+
+    def run():
+        time.sleep(timeout_s)
+        print(f'bench.py rank {rank}: no result after {timeout_s:.0f} s, stuck in stage {STAGE[0]!r}; giving up',
+              file=sys.stderr, flush=True)
+        os._exit(3)
+    threading.Thread(target=run, daemon=True).start()
+
+
+def note(rank: int, stage: str, extra: str = '') -> None:
+    """One line per rank and stage on stderr (stdout carries the JSON line only): a rank that hangs is identifiable."""
+    STAGE[0] = stage
+    if int(os.environ.get('WORLD_SIZE', 1)) > 1 or os.environ.get('SUCRE_BENCH_VERBOSE'):
+        print(f'bench.py rank {rank}: {stage}{(" -- " + extra) if extra else ""}', file=sys.stderr, flush=True)
 
 
 def main():
@@ -128,12 +185,21 @@ def main():
         sys.exit(spawn_ranks(args))
     from sucre_amd import dist as sdist
     from sucre_amd import engine, synth
+    from sucre_amd.loader import effective_cpus
+    rank0, _, world0 = sdist.env_rank_world()
+    watchdog(rank0, args.timeout_s)
+    # N ranks share this box's CPU quota (16 CPUs on the MI355X boxes, 256 visible): torch's host-side 3x3 inverses and
+    # R.T @ t of 65 views per rank must not wake a machine-wide OpenMP team in every rank
+    torch.set_num_threads(max(1, effective_cpus() // max(1, world0)))
+    note(rank0, 'rendezvous', f'world {world0}, {torch.get_num_threads()} torch CPU threads')
     rank, local_rank, world = sdist.init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP engine has no CPU fallback'
     # one GPU per rank; SUCRE_DIST_BACKEND=gloo lets several ranks share a GPU on a 1-GPU test box
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    note(rank, 'device', f'{torch.cuda.get_device_name(device)} (cuda:{device.index}), backend '
+                         f'{dist.get_backend() if world > 1 else None}')
     W, H, T = args.width, args.height, args.num_iter
 
     # every rank restores its own image(s) (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
@@ -221,22 +287,32 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[device.index])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     torch.cuda.synchronize()   # the scene was uploaded on the default stream; the slots have their own
+    note(rank, 'warmup', f'scene resident, {len(jobs)} image(s) x {n_views} views per step')
     for slot in range(args.warmup * len(jobs), S):   # setup: slots the W warmup steps will not reach run once too
         restore_one(*jobs[0], False, slot=slot)
     for _ in range(args.warmup):
         step(False)
+    note(rank, 'barrier before the timed region')
     barrier()
+    note(rank, 'timed region')
     base = torch.cuda.Event(enable_timing=True)
     base.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    torch.cuda.synchronize()
+    note(rank, 'barrier after the timed region',
+         f'own time {(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms/step, n_obs {resto.n_obs()}')
     barrier()
     elapsed = time.perf_counter() - t0
+    note(rank, 'reductions')
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -366,6 +442,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scene, n_obs, n_views, T, args.cpu_views, args.cpu_iters)
         print(json.dumps(out), flush=True)
+    note(rank, 'done')
     if world > 1:
         dist.destroy_process_group()
 

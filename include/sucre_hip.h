@@ -131,6 +131,17 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
                     int32_t *map_dev, void *stream);
 
 /*
+ * Image.project_to_view + the truncation and bound test of Image.match_one_way (sfm.py:103-107, 115-117) for an
+ * explicit list of world points: wP_dev is (3, n) float32 row-major (x[n], y[n], z[n], as sfm.py lays points out),
+ * pix_dev[i] = v2 * W + u2 of the pixel of `view` that point i truncates into, or -1 when it falls outside the
+ * sensor (NaN / inf included; like the reference, nothing tests that the point is in front of the camera).  Same
+ * float32 operation order as the fused match kernel, i.e. bit-identical to the reference's torch CPU arithmetic.
+ * `view` is a HOST struct (only its camera and pose are read).  This is the building block behind
+ * sfm.Image.match_one_way / match_two_way when a caller passes its own point sets.
+ */
+int sucre_project_points(const sucre_view_t *view, const float *wP_dev, int64_t n, int32_t *pix_dev, void *stream);
+
+/*
  * Alternative to sucre_match_views for one view: loads an explicit match list -- one group of a matches file
  * written by the reference (loader.py:68-76: u1, v1 int16; the ranges z = ||K2^-1 d [u2+.5, v2+.5, 1]|| of
  * loader.py:113 + sucre.py:53 and the colours I*255 as uint8, n x 3) -- into view k of the observation store,

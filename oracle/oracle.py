@@ -213,12 +213,15 @@ def update_J(H: int, W: int, samples, params) -> np.ndarray:
 
 
 class SharedWaterImage:
-    """One image of a shared-water (lock-step) fit on the CPU oracle: holds J and its Adam moments."""
+    """One image of a shared-water (lock-step) fit on the CPU oracle: holds J and its Adam moments.
+    ``use_closed_form``: J is re-solved by update_J from the shared parameters at the top of every pass
+    (sucre.py:141) and takes no Adam step; ``final_update_J`` is the update_J of sucre.py:156."""
 
-    def __init__(self, H: int, W: int, samples, J0: np.ndarray, lr: float = 0.05):
+    def __init__(self, H: int, W: int, samples, J0: np.ndarray | None, lr: float = 0.05, use_closed_form: bool = False):
         self.H, self.W, self.lr = H, W, lr
+        self.closed = bool(use_closed_form)
         self.s = _Samples(samples)
-        self.J = np.ascontiguousarray(J0, np.float32).copy()
+        self.J = np.ascontiguousarray(J0, np.float32).copy() if J0 is not None else np.zeros((H, W, 3), np.float32)
         self.mJ = np.zeros_like(self.J)
         self.vJ = np.zeros_like(self.J)
         self.n_obs = int(self.s.counts.sum())
@@ -226,14 +229,22 @@ class SharedWaterImage:
     def grad(self, params: np.ndarray, step: int, n_obs_total: int) -> np.ndarray:
         sums = np.zeros(10, np.float64)
         params = np.ascontiguousarray(params, np.float32)
-        lib().oracle_shared_grad.restype = C.c_int
-        rc = lib().oracle_shared_grad(C.c_int(self.H), C.c_int(self.W), C.c_int(self.s.n), _p(self.s.counts, C.c_int64),
-                                      self.s.us, self.s.vs, self.s.cPs, self.s.Is, _p(self.J, C.c_float),
-                                      _p(self.mJ, C.c_float), _p(self.vJ, C.c_float), _p(params, C.c_float),
-                                      C.c_int(step), C.c_double(self.lr), C.c_int64(n_obs_total), _p(sums, C.c_double))
+        lib().oracle_shared_grad_mode.restype = C.c_int
+        rc = lib().oracle_shared_grad_mode(C.c_int(self.H), C.c_int(self.W), C.c_int(self.s.n), _p(self.s.counts, C.c_int64),
+                                           self.s.us, self.s.vs, self.s.cPs, self.s.Is, _p(self.J, C.c_float),
+                                           _p(self.mJ, C.c_float), _p(self.vJ, C.c_float), _p(params, C.c_float),
+                                           C.c_int(step), C.c_double(self.lr), C.c_int64(n_obs_total),
+                                           C.c_int(int(self.closed)), _p(sums, C.c_double))
         if rc != 0:
-            raise MemoryError('oracle_shared_grad')
+            raise MemoryError('oracle_shared_grad_mode')
         return sums
+
+    def final_update_J(self, params: np.ndarray) -> None:
+        params = np.ascontiguousarray(params, np.float32)
+        rc = lib().oracle_update_J(C.c_int(self.H), C.c_int(self.W), C.c_int(self.s.n), _p(self.s.counts, C.c_int64),
+                                   self.s.us, self.s.vs, self.s.cPs, self.s.Is, _p(params, C.c_float), _p(self.J, C.c_float))
+        if rc != 0:
+            raise MemoryError('oracle_update_J')
 
 
 def shared_step(pstate: np.ndarray, sums: np.ndarray, step: int, n_obs_total: int, lr: float = 0.05) -> None:

@@ -153,6 +153,7 @@ int64_t oracle_match_view(const float *depth1, const oracle_cam_t *c1, const flo
 
 /* loader.py:113  cP = image.unproject_depth(u2, v2, d), u2/v2 int16; cP is (3,n) row-major */
 void oracle_unproject(const oracle_cam_t *c, const int16_t *u, const int16_t *v, const float *d, int64_t n, float *cP) {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         float p[3];
         unproject(c, (float)u[i], (float)v[i], d[i], p);
@@ -164,6 +165,7 @@ void oracle_unproject(const oracle_cam_t *c, const int16_t *u, const int16_t *v,
 
 /* loader.py:87  I = rgb[v2,u2].T with rgb = uint8/255 (loader.py:157,163); rgb is (H,W,3) uint8, I is (3,n) */
 void oracle_gather_rgb(const uint8_t *rgb, int W, const int16_t *u, const int16_t *v, int64_t n, float *I) {
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i)
         for (int c = 0; c < 3; ++c)
             I[c * n + i] = (float)((double)rgb[((int64_t)v[i] * W + u[i]) * 3 + c] / 255.0);
@@ -251,6 +253,7 @@ int oracle_fit(int H, int W, int n_samples, const int64_t *counts, const int16_t
     for (int s = 0; s < n_samples; ++s) {
         zs[s] = (float *)malloc(sizeof(float) * (size_t)(counts[s] > 0 ? counts[s] : 1));
         if (!zs[s]) return -1;
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < counts[s]; ++i) zs[s][i] = norm3(cPs[s], counts[s], i);
     }
     float mP[9] = {0}, vP[9] = {0};
@@ -323,20 +326,27 @@ void oracle_init_J(const uint8_t *rgb, const float *depth, int H, int W, float *
  * water gradients summed over images before one Adam step (a tied-parameter composition of reference modules,
  * SURVEY.md section 8e).  One image's half-iteration:
  *   sums[0..2] = dS/dB, sums[3..5] = dS/dbeta, sums[6..8] = dS/dgamma for S = sum r^2 (unscaled, float64),
- *   sums[9] = S;  J takes its Adam step with gradient (dS/dJ) * (1/3)/n_obs_total.
+ *   sums[9] = S;  J takes its Adam step with gradient (dS/dJ) * (1/3)/n_obs_total (J-parameter mode), or is re-solved
+ *   by update_J from the shared parameters before the pass and held constant (closed-form mode, sucre.py:141).
  */
-int oracle_shared_grad(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
-                       const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
-                       float *mJ, float *vJ, const float *params, int step, double lr, int64_t n_obs_total,
-                       double *sums) {
+int oracle_shared_grad_mode(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                            const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
+                            float *mJ, float *vJ, const float *params, int step, double lr, int64_t n_obs_total,
+                            int use_closed_form, double *sums) {
     const size_t npx = (size_t)H * W * 3;
-    float *gJ = (float *)calloc(npx, sizeof(float));
-    if (!gJ) return -1;
+    /* closed-form mode (sucre.py:141): J is re-solved from the shared parameters at the top of the iteration and is
+     * a constant of the gradient pass; it takes no Adam step. */
+    if (use_closed_form && oracle_update_J(H, W, n_samples, counts, us, vs, cPs, Is, params, J) != 0) return -1;
+    float *gJ = use_closed_form ? NULL : (float *)calloc(npx, sizeof(float));
+    if (!use_closed_form && !gJ) return -1;
     const float scale = (1.0f / 3.0f) / (float)n_obs_total;
     const float *B = params, *beta = params + 3, *gamma = params + 6;
     for (int k = 0; k < 10; ++k) sums[k] = 0.0;
     for (int s = 0; s < n_samples; ++s) {
         const int64_t n = counts[s];
+        double tB[3] = {0, 0, 0}, tb[3] = {0, 0, 0}, tg[3] = {0, 0, 0}, tc = 0.0;
+        /* (v,u) are unique within one view, so gJ has no race inside this loop */
+#pragma omp parallel for schedule(static) reduction(+ : tB[:3], tb[:3], tg[:3], tc)
         for (int64_t i = 0; i < n; ++i) {
             const float z = norm3(cPs[s], n, i);
             const size_t px = ((size_t)vs[s][i] * W + us[s][i]) * 3;
@@ -344,18 +354,30 @@ int oracle_shared_grad(int H, int W, int n_samples, const int64_t *counts, const
                 const float a = expf(-beta[c] * z), g = expf(-gamma[c] * z);
                 const float Jc = J[px + c];
                 const float r = Is[s][c * n + i] - (Jc * a + B[c] * (1.0f - g));
-                sums[9] += (double)r * (double)r;
-                gJ[px + c] += (-2.0f * r * scale) * a;
-                sums[c] += (double)(-2.0f * r * (1.0f - g));
-                sums[3 + c] += (double)(-2.0f * r * Jc * a * -z);
-                sums[6 + c] += (double)(-2.0f * r * B[c] * g * z);
+                tc += (double)r * (double)r;
+                if (gJ) gJ[px + c] += (-2.0f * r * scale) * a;
+                tB[c] += (double)(-2.0f * r * (1.0f - g));
+                tb[c] += (double)(-2.0f * r * Jc * a * -z);
+                tg[c] += (double)(-2.0f * r * B[c] * g * z);
             }
         }
+        for (int c = 0; c < 3; ++c) { sums[c] += tB[c]; sums[3 + c] += tb[c]; sums[6 + c] += tg[c]; }
+        sums[9] += tc;
     }
-    const adam_coef_t co = adam_coef(step, lr, 0.9, 0.999, 1e-8);
-    for (size_t i = 0; i < npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
-    free(gJ);
+    if (gJ) {
+        const adam_coef_t co = adam_coef(step, lr, 0.9, 0.999, 1e-8);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)npx; ++i) adam_step(&J[i], &mJ[i], &vJ[i], gJ[i], &co);
+        free(gJ);
+    }
     return 0;
+}
+
+int oracle_shared_grad(int H, int W, int n_samples, const int64_t *counts, const int16_t *const *us,
+                       const int16_t *const *vs, const float *const *cPs, const float *const *Is, float *J,
+                       float *mJ, float *vJ, const float *params, int step, double lr, int64_t n_obs_total,
+                       double *sums) {
+    return oracle_shared_grad_mode(H, W, n_samples, counts, us, vs, cPs, Is, J, mJ, vJ, params, step, lr, n_obs_total, 0, sums);
 }
 
 /* pstate = params[9], exp_avg[9], exp_avg_sq[9]; sums = all-reduced output of oracle_shared_grad */

@@ -133,21 +133,37 @@ class WorkerPool:
 
     def _acquire(self):
         import queue
-        try:
-            return self._free.get_nowait()
-        except queue.Empty:
-            pass
+        while True:
+            try:
+                return self._free.get_nowait()
+            except queue.Empty:
+                pass
+            with self._lock:
+                # workers that died while idle or while serving someone else leave room for a replacement; a waiter
+                # re-checks this every so often, so it cannot sleep for ever on a pool whose workers were all killed
+                self._procs = [q for q in self._procs if q.poll() is None]
+                if len(self._procs) < self._n:
+                    p = self._spawn()
+                    self._procs.append(p)
+                    return p
+            try:
+                return self._free.get(timeout=0.5)
+            except queue.Empty:
+                continue
+
+    def _retire(self, p, why: str):
         with self._lock:
-            if len(self._procs) < self._n:
-                p = self._spawn()
-                self._procs.append(p)
-                return p
-        return self._free.get()
+            if p in self._procs:
+                self._procs.remove(p)
+        p.kill()
+        return WorkerLost(f'image worker process died ({why})')
 
     def _call(self, op: bytes, path, px=None, level: int = 0):
         name = str(path).encode()
         H, W = (px.shape[0], px.shape[1]) if px is not None else (0, 0)
         p = self._acquire()
+        if p.poll() is not None:      # died while idle in the free queue
+            raise self._retire(p, f'exit code {p.returncode}')
         try:
             p.stdin.write(_HEADER.pack(op, len(name), H, W, level) + name)
             if px is not None:
@@ -157,11 +173,9 @@ class WorkerPool:
             msg = p.stdout.read(n_msg)
             payload = p.stdout.read(n_payload)
         except (OSError, struct.error) as e:   # the worker is gone: retire it (another one is started on demand)
-            with self._lock:
-                if p in self._procs:
-                    self._procs.remove(p)
-            p.kill()
-            raise WorkerLost(f'image worker process died ({e!r})') from e
+            raise self._retire(p, repr(e)) from e
+        if len(msg) != n_msg or len(payload) != n_payload:   # it died mid-reply: a short read raises nothing by itself
+            raise self._retire(p, f'short reply: {len(msg)}/{n_msg} + {len(payload)}/{n_payload} bytes')
         self._free.put(p)
         if msg:
             text = msg.decode()

@@ -113,6 +113,16 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
     return check_hip(launch_match_map(L, *target, views_dev, k, map_dev, static_cast<hipStream_t>(stream)), "sucre_match_map");
 }
 
+int sucre_project_points(const sucre_view_t *view, const float *wP_dev, int64_t n, int32_t *pix_dev, void *stream) {
+    if (!view) return fail(SUCRE_ERR_ARG, "view is NULL");
+    if (view->H <= 0 || view->W <= 0 || view->H > 32767 || view->W > 32767)
+        return fail(SUCRE_ERR_ARG, "invalid sensor size %dx%d", view->W, view->H);
+    if (n < 0) return fail(SUCRE_ERR_RANGE, "negative point count %lld", (long long)n);
+    if (n > 0 && (!wP_dev || !pix_dev)) return fail(SUCRE_ERR_ARG, "wP_dev / pix_dev is NULL");
+    return check_hip(launch_project_points(*view, wP_dev, (long long)n, pix_dev, static_cast<hipStream_t>(stream)),
+                     "sucre_project_points");
+}
+
 int sucre_import_view(void *ws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
                       const float *z_dev, const uint8_t *rgb_dev, int64_t n, void *stream) {
     Layout L;

@@ -193,6 +193,18 @@ __global__ __launch_bounds__(256) void match_map_kernel(const float *__restrict_
     map[idx] = out;
 }
 
+// Image.match_one_way's arithmetic for an explicit point list (sfm.py:103-107, 115-117): world point i -> linear pixel
+// index in the view, -1 = outside.  wP is (3, n) row-major.
+__global__ __launch_bounds__(256) void project_points_kernel(const CamDev cam, const float *__restrict__ wP, long long n,
+                                                             int32_t *__restrict__ pix) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {wP[i], wP[n + i], wP[2 * n + i]};
+    float px, py;
+    const bool inside = project(cam.Rinv, cam.tinv, cam.K, (float)cam.W, (float)cam.H, p, &px, &py);
+    pix[i] = inside ? (int32_t)py * cam.W + (int32_t)px : -1;
+}
+
 // len(matches) per view and the min_cover rule of sfm.py:136 (Python int/int true division, strict >).
 __global__ __launch_bounds__(256) void view_count_kernel(const uint16_t *__restrict__ cnt, int n_tiles, int n_views,
                                                          double min_cover, double hw,
@@ -390,6 +402,12 @@ static CamDev to_cam(const sucre_view_t &v) {
     for (int i = 0; i < 3; ++i) { c.t[i] = v.t[i]; c.tinv[i] = v.tinv[i]; }
     c.H = v.H; c.W = v.W;
     return c;
+}
+
+hipError_t launch_project_points(const sucre_view_t &view, const float *wP, long long n, int32_t *pix, hipStream_t s) {
+    if (n > 0)
+        hipLaunchKernelGGL(project_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, to_cam(view), wP, n, pix);
+    return hipGetLastError();
 }
 
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,

@@ -54,18 +54,39 @@ class DeviceView:
         H, W = self.depth.shape
         assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
         assert self.rgb.dtype in (torch.uint8, torch.float32) and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
-        K = self.K.to(torch.float32).cpu()
-        R = self.R.to(torch.float32).cpu()
-        t = self.t.to(torch.float32).cpu().view(3, 1)
-        Kinv = K.inverse()      # sfm.py:92
-        Rinv = R.T              # sfm.py:47
-        tinv = -R.T @ t         # sfm.py:47
-        s = _lib.SucreView()
-        s.depth, s.rgb, s.H, s.W = self.depth.data_ptr(), self.rgb.data_ptr(), H, W
-        for name, val in (('K', K), ('Kinv', Kinv), ('R', R), ('t', t), ('Rinv', Rinv), ('tinv', tinv)):
-            flat = val.contiguous().view(-1).tolist()
-            setattr(s, name, (C.c_float * len(flat))(*flat))
-        return s
+        return camera_struct(self.K, self.R, self.t, H, W, self.depth.data_ptr(), self.rgb.data_ptr())
+
+
+def camera_struct(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor, H: int, W: int, depth_ptr: int = 0,
+                  rgb_ptr: int = 0) -> _lib.SucreView:
+    """sucre_view_t from a camera matrix and a world-from-camera pose, the derived matrices computed on the host the way
+    the reference computes them (K.inverse(): sfm.py:92; Pose.inverse() = (R.T, -R.T @ t): sfm.py:42-47)."""
+    K = K.to(torch.float32).cpu()
+    R = R.to(torch.float32).cpu()
+    t = t.to(torch.float32).cpu().view(3, 1)
+    Kinv = K.inverse()      # sfm.py:92
+    Rinv = R.T              # sfm.py:47
+    tinv = -R.T @ t         # sfm.py:47
+    s = _lib.SucreView()
+    s.depth, s.rgb, s.H, s.W = depth_ptr or None, rgb_ptr or None, int(H), int(W)
+    for name, val in (('K', K), ('Kinv', Kinv), ('R', R), ('t', t), ('Rinv', Rinv), ('tinv', tinv)):
+        flat = val.contiguous().view(-1).tolist()
+        setattr(s, name, (C.c_float * len(flat))(*flat))
+    return s
+
+
+def project_points(view: _lib.SucreView, wP: torch.Tensor) -> torch.Tensor:
+    """int32[n]: the pixel ``v * W + u`` of ``view`` that each world point of ``wP`` ((3, n) float32, cuda) truncates
+    into, -1 = outside the sensor -- ``Image.project_to_view`` + the cast and bound test of ``match_one_way``
+    (sfm.py:103-107, 115-117) in the match kernel's float32 operation order (csrc/match.hip, project_points_kernel)."""
+    assert wP.is_cuda and wP.dtype == torch.float32 and wP.dim() == 2 and wP.shape[0] == 3
+    wP = wP.contiguous()
+    n = wP.shape[1]
+    out = torch.empty(n, dtype=torch.int32, device=wP.device)
+    with torch.cuda.device(wP.device):
+        _lib.check(_lib.load().sucre_project_points(C.byref(view), C.c_void_p(wP.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                    _stream_ptr()))
+    return out
 
 
 MAX_VIEWS = 4096   # kMaxViews of csrc/layout.h: views of one restoration (after the overlap cull of sfm.Image.match_images)
@@ -489,6 +510,11 @@ class HipWaterGroup:
 
     def grad(self, step: int) -> torch.Tensor:
         assert self.total, 'set_n_obs_total() first'
+        if int(step) != self.steps_done + 1:
+            # the water state is double-buffered by step parity and the pending step is taken by the NEXT launch: a group
+            # runs iterations 1, 2, 3, ... once; starting over needs fit_init on the images and a new group
+            raise _lib.SucreError(f'HipWaterGroup: iteration {step} asked after {self.steps_done} done -- iterations run in '
+                                  f'order, once; build a new group (after fit_init) to fit again')
         with torch.cuda.device(self.device):
             if self.closed and step == 1:   # start the one-pass closed-form kernel from a solved J (see sucre_fit_run)
                 for r in self.rs:
@@ -529,7 +555,7 @@ def acquire_restoration(height: int, width: int, n_views: int, device='cuda', li
         obs_format = 'f32' if (light or float_colour) else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
     # capacities come in steps, so targets whose surviving view counts differ a little share one workspace
     n = int(n_views)
-    cap = (n + 7) // 8 * 8 if n <= 64 else (n + 31) // 32 * 32
+    cap = (n + 7) // 8 * 8 if n <= 256 else (n + 31) // 32 * 32   # (65 views -> 72, not 96: +11 % HBM per slot, not +48 %)
     key = (int(height), int(width), str(dev), bool(light), _SLOT, obs_format, bool(float_colour), tag)
     have = _POOL.get(key)
     if have is None or have.capacity < n:

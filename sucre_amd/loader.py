@@ -417,8 +417,12 @@ class MatchesData:
             ext = (torch.cat([cP, I]).contiguous() if (light and not integral)      # both extension sets
                    else cP.contiguous() if light else (None if integral else I.contiguous()))
             lists.append((s.u, s.v, z, rgb) if ext is None else (s.u, s.v, z, rgb, ext))
-        resto = engine.acquire_restoration(height, width, len(lists), device, light=light, float_colour=not integral,
-                                           tag='lists')
+        # A private workspace, not a pooled one: the reference's MatchesData objects are independent of each other, and
+        # a pooled workspace (keyed by geometry) would hand md_A the observations md_B imported after it.
+        dev = torch.device(device)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        resto = engine.Restoration(height, width, len(lists), device=dev, light=light, float_colour=not integral)
         resto.import_matches(None, lists)
         self.restoration = resto
         return resto

@@ -63,6 +63,14 @@ def _canonical_device(device) -> torch.device:
     return dev
 
 
+def require_gpu(device, what: str) -> None:
+    """The reference's functions default to ``device='cpu'`` (sfm.py:128, sucre.py:176); this engine keeps that default in
+    its signatures and refuses it loudly -- a silently different default would hide that there is no CPU path."""
+    if torch.device(device).type != 'cuda':
+        raise RuntimeError(f"{what}(device={str(device)!r}): the HIP engine runs on a GPU and has no CPU path -- "
+                           f"pass device='cuda' (or 'cuda:<index>')")
+
+
 class _PixelCache:
     """Budget for the pixels kept resident in HBM (uint8 colour + float32 depth = 7 B/pixel per image): least
     recently used images are dropped from the cache once the budget (SUCRE_DEVICE_CACHE_GB, default half of the
@@ -280,24 +288,34 @@ class Image:
         keep = ~(misses_cone & misses_mirror)
         return np.nonzero(keep)[0].tolist()
 
-    def match_one_way(self, other: 'Image', u1: Tensor, v1: Tensor, wP1: Tensor) -> 'Matches':
+    def match_one_way(self, other: 'Image', u1: Tensor, v1: Tensor, wP1: Tensor, device: str = 'cuda') -> 'Matches':
         """Pixels ``(u1, v1)`` of this image (world points ``wP1``) that land inside ``other`` (sfm.py:115-119):
         the continuous projection is truncated towards zero and tested against ``other``'s sensor; nothing checks
-        that the point is in front of ``other``.  Plain tensor arithmetic on whatever device the inputs are on (the
-        engine's fused kernel never materialises one-way lists; this is the reference's building block, kept for
-        callers that use it)."""
-        q = other.project_to_view(wP1).long()
-        inside = (q[0] >= 0) & (q[0] < other.camera.width) & (q[1] >= 0) & (q[1] < other.camera.height)
-        return Matches(image1=self, image2=other, u1=u1[inside], v1=v1[inside], u2=q[0][inside], v2=q[1][inside])
+        that the point is in front of ``other``.  The projection runs on the GPU (``sucre_project_points``: the match
+        kernel's own float32 operation order, bit-identical to the reference's torch CPU arithmetic); the lists come
+        back on the device the caller's tensors live on (host tensors are staged through ``device``)."""
+        from . import engine
+        home = wP1.device
+        dev = home if home.type == 'cuda' else _canonical_device(device)
+        cam = engine.camera_struct(other.camera.K, other.pose.R, other.pose.t, other.camera.height, other.camera.width)
+        q = engine.project_points(cam, wP1.to(dev, torch.float32)).long()
+        inside = q >= 0
+        q = q[inside]
+        W2 = other.camera.width
+        u2, v2 = (q % W2).to(home), torch.div(q, W2, rounding_mode='floor').to(home)
+        inside = inside.to(home)
+        return Matches(image1=self, image2=other, u1=u1[inside], v1=v1[inside], u2=u2, v2=v2)
 
     def match_images(self, image_list: list['Image'], matches_file: 'loader.MatchesFile', min_cover: float = 0.000001,
-                     num_workers: int = 0, device: str = 'cuda', light_model: bool = False):
+                     num_workers: int = 0, device: str = 'cpu', light_model: bool = False):
         """Two-way dense matching of this image against every image of ``image_list`` and preparation of the
         observations the fit consumes (replaces sfm.py:127-138 + loader.py:78-118).  One HIP launch matches all
         views; views failing ``n_matches / (W*H) > min_cover`` are dropped on the device; nothing is written to
         disk unless the matches file is asked to persist.  ``light_model`` (not a reference argument) also keeps the
-        camera-frame point of every observation, which the artificial-light model needs."""
+        camera-frame point of every observation, which the artificial-light model needs.  ``device`` defaults to the
+        reference's 'cpu' and must be given as a GPU (``require_gpu``)."""
         from . import engine
+        require_gpu(device, 'Image.match_images')
         image_list = list(image_list)
         if min_cover >= 0 and len(image_list) > 1 and os.environ.get('SUCRE_CULL_VIEWS', '1') != '0':
             # images whose field of view cannot contain anything this image sees have no match and would be dropped
@@ -321,10 +339,23 @@ class Image:
         resto.match(target, views, min_cover=min_cover)
         matches_file.attach(resto, target_image=self, image_list=image_list)
 
-    def match_two_way(self, other: 'Image', device: str = 'cuda', **_unused) -> 'Matches':
+    def match_two_way(self, other: 'Image', u1: Tensor = None, v1: Tensor = None, wP1: Tensor = None,
+                      u2: Tensor = None, v2: Tensor = None, wP2: Tensor = None, device: str = 'cuda') -> 'Matches':
         """Mutually consistent matches between this image and ``other`` (sfm.py:121-125) as explicit lists.
-        The reference's positional ``u1, v1, wP1, u2, v2, wP2`` arguments are accepted and ignored: the engine
-        recomputes the unprojections on the device."""
+
+        With the reference's arguments -- pixels ``(u1, v1)`` of this image with their world points ``wP1`` and
+        ``(u2, v2, wP2)`` of ``other``, positionally or by keyword -- this is the reference's own composition on the
+        caller's point sets: ``self.match_one_way(other, ...) & other.match_one_way(self, ...)``, so a caller that
+        passes a subset of the pixels gets the matches of that subset.  Without them (not a reference call form) both
+        images' full valid sets are matched by the fused kernel from the depth maps on the device -- the same
+        match set the reference computes from ``unproject_depth_map`` of both images (sfm.py:129-135)."""
+        given = [a is not None for a in (u1, v1, wP1, u2, v2, wP2)]
+        if any(given):
+            if not all(given):
+                raise TypeError('match_two_way() takes (other, u1, v1, wP1, u2, v2, wP2) like the reference (sfm.py:121), '
+                                'or (other) alone')
+            return (self.match_one_way(other, u1=u1, v1=v1, wP1=wP1, device=device)
+                    & other.match_one_way(self, u1=u2, v1=v2, wP1=wP2, device=device))
         from . import engine
         views = [other.device_view(device)]
         target = self.device_view(device)

@@ -103,7 +103,7 @@ class SUCRe(torch.nn.Module):
     @torch.no_grad()
     def plot_J(self) -> PILImage.Image:
         """Restored image: per-channel 1-99 percentile stretch of the valid pixels, invalid pixels black."""
-        if self.J.is_cuda:
+        if self.J.is_cuda and _NUMPY_2:
             return PILImage.fromarray(self._plot_J_device().cpu().numpy())
         J = self.J.detach().cpu().numpy().copy()
         ok = ~np.isnan(J).any(axis=2)
@@ -191,6 +191,12 @@ def _save_png(img: PILImage.Image, path: Path) -> None:
             except _pixelio.WorkerLost as e:
                 print(f'warning: {e}; writing {path} in-process')
         _pixelio.write_rgb(str(path), np.asarray(img), level)
+
+
+# percentile_plan / percentile_lerp restate numpy >= 2, where the quantile, the virtual index and the interpolation of a
+# float32 array stay float32.  numpy 1.x runs np.percentile in float64 (and promotes the clipped image): there plot_J takes
+# the host path, which calls np.percentile itself, so the picture equals the reference's on the same install either way.
+_NUMPY_2 = int(np.__version__.split('.')[0]) >= 2
 
 
 def percentile_plan(n: int, q: float) -> tuple[int, int, np.floating]:
@@ -423,8 +429,10 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
                   use_closed_form: bool = False, min_cover: float = 0.000001, image_list: list[sfm.Image] = None,
                   lr: float = 0.05, num_iter: int = 200, batch_size: int = 1, save_interval: int = None,
                   params_path: Path = None, force_compute_matches: bool = False, keep_matches: bool = False,
-                  num_workers: int = 0, device: str = 'cuda'):
-    """Per-image pipeline (sucre.py:160-219): match -> prepare -> check -> load -> fit -> save."""
+                  num_workers: int = 0, device: str = 'cpu'):
+    """Per-image pipeline (sucre.py:160-219): match -> prepare -> check -> load -> fit -> save.  The signature is the
+    reference's, default ``device='cpu'`` included -- which this engine refuses (``sfm.require_gpu``): pass a GPU."""
+    sfm.require_gpu(device, 'restore_image')
     job = _restore_submit(image, colmap_model, output_dir, light_model, use_closed_form, min_cover, image_list, lr,
                           num_iter, params_path, force_compute_matches, num_workers, device)
     adam(sucre=job.sucre, matches_data=job.matches_data, lr=lr, num_iter=num_iter, batch_size=batch_size,
@@ -475,11 +483,16 @@ def parse_args(args: argparse.Namespace):
     rank, local_rank, world = sdist.env_rank_world()
     # torch's CPU thread pool follows the machine's CPU count; inside a container with a CPU quota that many spinning
     # threads only get the process throttled (147 CPU-seconds for 64 images on a 256-CPU box with a 16-CPU quota)
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), loader.effective_cpus())))
+    local_world = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    cpus = max(1, loader.effective_cpus() // local_world)   # the ranks of one node share its CPUs (and its quota)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpus)))
     device = args.device
     if world > 1 and str(device).startswith('cuda'):
-        device = f'cuda:{local_rank}'
-        torch.cuda.set_device(local_rank)
+        # one GPU per rank; ranks beyond the GPUs of the box wrap around (two ranks on a one-GPU test box: per-image mode
+        # has no collective, so sharing a GPU only shares its time)
+        index = local_rank % max(1, torch.cuda.device_count())
+        device = f'cuda:{index}'
+        torch.cuda.set_device(index)
     print('Loading COLMAP model.')
     colmap_model = sfm.COLMAPModel(model_dir=args.model_dir, image_dir=args.image_dir, depth_dir=args.depth_dir,
                                    image_scale=args.image_scale)
@@ -501,7 +514,7 @@ def parse_args(args: argparse.Namespace):
         # image files are decoded and the result pictures encoded by child processes (_pixelio.WorkerPool: CPU work in
         # the process that drives the GPU slows its launches down, and PIL's decoder does not scale over threads);
         # SUCRE_IO_PROCESSES=0 keeps both in this process's threads
-        n_io = int(os.environ.get('SUCRE_IO_PROCESSES', max(1, loader.effective_cpus() - 2)))
+        n_io = int(os.environ.get('SUCRE_IO_PROCESSES', max(1, cpus - 2)))
         if n_io > 0:
             _pixelio.start_pool(n_io)
     try:

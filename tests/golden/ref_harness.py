@@ -147,16 +147,18 @@ def reference_fit(scene, matches_data, target, num_iter: int, use_closed_form: b
     return dict(J=J, trace=np.asarray(trace, dtype=np.float64), snaps=snaps, model=model)
 
 
-def reference_shared_water(scenes, num_iter: int, batch_size: int = 5, lr: float = 0.05):
+def reference_shared_water(scenes, num_iter: int, batch_size: int = 5, lr: float = 0.05, use_closed_form: bool = False):
     """Shared-water composition built from reference classes only: one reference SUCRe
     module per image, their B / beta / gamma attributes bound to the SAME Parameter objects, one
     torch.optim.Adam over the de-duplicated parameter set, every batch loss divided by the TOTAL observation count
-    (the per-image loop body of sucre.py:143-146 otherwise unchanged)."""
+    (the per-image loop body of sucre.py:143-146 otherwise unchanged).  ``use_closed_form``: every module re-solves
+    its J with its own ``update_J`` at the top of the iteration (sucre.py:140-141) and once more after the last
+    step (sucre.py:155-156), exactly as ``sucre.adam`` does for one image."""
     _, loader, _, sucre_mod = import_reference()
     models, datas = [], []
     for scene in scenes:
         _, md, target = reference_matches(scene)
-        models.append(sucre_mod.SUCRe(image=target))
+        models.append(sucre_mod.SUCRe(image=target, use_closed_form=use_closed_form))
         datas.append(md)
     for m in models[1:]:
         m.B, m.beta, m.gamma = models[0].B, models[0].beta, models[0].gamma
@@ -172,10 +174,15 @@ def reference_shared_water(scenes, num_iter: int, batch_size: int = 5, lr: float
         opt.zero_grad()
         cost = 0.0
         for m, d in zip(models, datas):
+            if use_closed_form:
+                m.update_J(d)
             for u, v, cP, I in d.iter(batch_size=batch_size, device='cpu'):
                 loss = torch.square(I - m(u=u, v=v, cP=cP)).sum()
                 (loss / n_total / 3).backward()
                 cost += loss.item()
         opt.step()
         trace.append([cost] + [float(x) for p in (models[0].B, models[0].beta, models[0].gamma) for x in p.detach().flatten()])
+    if use_closed_form:
+        for m, d in zip(models, datas):
+            m.update_J(d)
     return dict(J=[m.J.detach().numpy().copy() for m in models], trace=np.asarray(trace), n_total=n_total)

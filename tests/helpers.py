@@ -98,3 +98,32 @@ def load_fixture(name: str) -> Fixture:
     if name not in _FIXTURES:
         _FIXTURES[name] = Fixture(name)
     return _FIXTURES[name]
+
+
+# ---- closed-form "knee" scenes (tests/golden/gen_golden_extras.py) --------------------------------------------------------
+
+KNEE_FIXTURES = ['knee_190x51_n1', 'knee_215x74_n1', 'knee_225x87_n1', 'knee_115x67_n5']
+
+
+def knee_bars(fx):
+    """The reference against ITSELF on a knee scene (batch_size 1 vs 5: only the summation order differs): the spread
+    of the water parameters over the trajectory and of the final J.  A restatement is 'as good as the reference' when
+    it lies within a small multiple of that spread; the cost of iteration 0 has no step behind it and stays tight."""
+    t1, t5 = fx['trace_closed_bs1'], fx['trace_closed_bs5']
+    par = float(np.abs(t1[:, 1:] - t5[:, 1:]).max())
+    Jsp = float(rms_per_channel(fx['J_closed_bs1'], fx['J_closed_bs5']).max())
+    return par, Jsp
+
+
+def check_knee(fx, J, trace, label):
+    t1, t5 = fx['trace_closed_bs1'], fx['trace_closed_bs5']
+    par, Jsp = knee_bars(fx)
+    # this IS a knee scene: some water parameter's first Adam step is visibly shorter than lr (|g| ~ eps)
+    assert np.any(np.abs(t5[0, 1:] - 0.1) / 0.05 < 0.99)
+    assert abs(trace[0, 0] / t5[0, 0] - 1) < 1e-6, (label, 'cost of iteration 0')
+    d = min(float(np.abs(trace[:, 1:] - t5[:, 1:]).max()), float(np.abs(trace[:, 1:] - t1[:, 1:]).max()))
+    assert d < 3 * par, (label, 'parameters', d, par)
+    assert np.array_equal(np.isnan(J), np.isnan(fx['J_closed_bs5'])), label
+    dJ = min(float(rms_per_channel(J, fx['J_closed_bs5']).max()), float(rms_per_channel(J, fx['J_closed_bs1']).max()))
+    assert dJ < 3 * Jsp, (label, 'J', dJ, Jsp)
+    return d / par, dJ / Jsp

@@ -115,7 +115,9 @@ def test_match_two_way_and_matches_data_compat(disk_scene):
     # the reference-format iterator over the HBM store
     image_list = list(model.images.values())
     mf = loader.MatchesFile(Path('/tmp/unused.h5'), colmap_model=model)
-    target.match_images(image_list, mf)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        target.match_images(image_list, mf)          # the reference's default device='cpu' is refused, not replaced
+    target.match_images(image_list, mf, device='cuda')
     mf.prepare_matches(); mf.check_integrity()
     md = mf.load_matches()
     assert len(md) == sum(len(s[0]) for s in samples) and len(mf) == len(md)
@@ -145,7 +147,8 @@ def test_shared_water_group_vs_oracle():
             rs.append(r)
             _, samples = helpers.oracle_scene_samples(scene)
             tgt = scene.views[scene.target]
-            oimgs.append(oracle.SharedWaterImage(32, 48, samples, oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())))
+            oimgs.append(oracle.SharedWaterImage(32, 48, samples, None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()),
+                                                 use_closed_form=closed))
         total = sum(r.n_obs() for r in rs)
         assert total == sum(o.n_obs for o in oimgs)
         trace = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
@@ -154,15 +157,19 @@ def test_shared_water_group_vs_oracle():
         p0, p1 = rs[0].params().cpu().numpy(), rs[1].params().cpu().numpy()
         assert np.array_equal(p0, p1) and np.array_equal(p0, trace[-1, 1:].cpu().numpy().astype(np.float32))
         assert np.all(np.isfinite(trace.cpu().numpy())) and float(trace[-1, 0]) < float(trace[0, 0])
-        if closed:
-            continue   # the oracle's lock-step helper is J-parameter only; closed form is held to the single-image path below
+        from sucre_amd import _lib
+        with pytest.raises(_lib.SucreError, match='iterations run in order'):
+            group.grad(1)          # a group runs its iterations once (its water state is double-buffered by step parity)
         pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
         for it in range(1, T + 1):
             acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
             oracle.shared_step(pstate, acc, it, total)
-        assert np.abs(p0 - pstate[:9]).max() < 1e-5
+        if closed:
+            for o in oimgs:
+                o.final_update_J(pstate[:9])
+        assert np.abs(p0 - pstate[:9]).max() < (1e-4 if closed else 1e-5)
         for r, o in zip(rs, oimgs):
-            assert helpers.rms_per_channel(r.J().cpu().numpy(), o.J).max() < 1e-5
+            assert helpers.rms_per_channel(r.J().cpu().numpy(), o.J).max() < (1e-4 if closed else 1e-5)
 
 
 @pytest.mark.parametrize('closed', [False, True])
@@ -693,3 +700,81 @@ def test_cli_flags_that_shape_the_problem(disk_scene, tmp_path, capsys):
     assert 'Compute' not in capsys.readouterr().out                       # kept files are consumed ...
     _cli(root, tmp_path / 'l', '--image-list', tmp_path / 'targets.txt', '--num-iter', 4, '--force-compute-matches')
     assert capsys.readouterr().out.count('Compute') == 2                  # ... unless matching is forced
+
+
+def _golden_lists(golden, k):
+    """Match lists of view k from the reference-made golden, as (H1*W1,) linear target pixel -> linear other pixel."""
+    u1, v1, u2, v2 = golden.match_lists(k)
+    W = golden.scene.width
+    return v1.astype(np.int64) * W + u1, v2.astype(np.int64) * W + u2
+
+
+def test_match_one_way_and_two_way_take_the_reference_arguments(golden):
+    """sfm.Image.match_one_way (sfm.py:115-119) and match_two_way (sfm.py:121-125) with the reference's own arguments,
+    positionally: the full valid sets give the golden match lists (made by the reference); a caller that passes a
+    SUBSET of the pixels gets the matches of that subset -- the reference's composition on the caller's points, with the
+    projection on the GPU (sucre_project_points).  Host tensors in, host tensors out."""
+    sc = golden.scene
+    images = [SynthImage(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)]
+    target = images[sc.target]
+    W = sc.width
+    u1, v1, wP1 = target.unproject_depth_map(target.get_depth_map(), to_world=True)      # host tensors, like device='cpu'
+    for k, other in enumerate(images):
+        u2, v2, wP2 = other.unproject_depth_map(other.get_depth_map(), to_world=True)
+        p1, p2 = _golden_lists(golden, k)
+        # one-way: truncation towards zero, bound test on the other sensor, no in-front-of-camera test
+        m1 = target.match_one_way(other, u1, v1, wP1)
+        px = other.project_to_view(wP1)
+        ref = (px[0] > -1) & (px[0] < other.camera.width) & (px[1] > -1) & (px[1] < other.camera.height)
+        assert m1.u1.device.type == 'cpu' and len(m1) == int(ref.sum())
+        assert torch.equal(m1.u1, u1[ref]) and torch.equal(m1.v1, v1[ref])
+        assert torch.equal(m1.u2, px[0][ref].long()) and torch.equal(m1.v2, px[1][ref].long())
+        # two-way, positional, full sets: the golden lists
+        m = target.match_two_way(other, u1, v1, wP1, u2, v2, wP2)
+        assert np.array_equal((m.v1 * W + m.u1).numpy(), p1) and np.array_equal((m.v2 * W + m.u2).numpy(), p2)
+        # the same on device tensors
+        md = target.match_two_way(other, u1.cuda(), v1.cuda(), wP1.cuda(), u2.cuda(), v2.cuda(), wP2.cuda())
+        assert md.u1.is_cuda and np.array_equal((md.v1 * W + md.u1).cpu().numpy(), p1)
+        # and the fused no-argument form agrees
+        mf = target.match_two_way(other)
+        assert np.array_equal((mf.v1 * W + mf.u1).cpu().numpy(), p1) and np.array_equal((mf.v2 * W + mf.u2).cpu().numpy(), p2)
+        # a subset of the target's pixels (every third) -> the golden lists restricted to it
+        sub = torch.arange(0, u1.numel(), 3)
+        ms = target.match_two_way(other, u1[sub], v1[sub], wP1[:, sub], u2, v2, wP2)
+        keep = np.isin(p1, (v1[sub] * W + u1[sub]).numpy())
+        assert np.array_equal((ms.v1 * W + ms.u1).numpy(), p1[keep]) and np.array_equal((ms.v2 * W + ms.u2).numpy(), p2[keep])
+        # a subset of the OTHER image's pixels: only matches whose p2 is in it survive (Matches.__and__, sfm.py:171-175)
+        sub2 = torch.arange(0, u2.numel(), 2)
+        ms2 = target.match_two_way(other, u1, v1, wP1, u2[sub2], v2[sub2], wP2[:, sub2])
+        keep2 = np.isin(p2, (v2[sub2] * W + u2[sub2]).numpy())
+        assert np.array_equal((ms2.v1 * W + ms2.u1).numpy(), p1[keep2])
+    with pytest.raises(TypeError):
+        target.match_two_way(images[0], u1, v1, wP1)
+
+
+def test_list_backed_matches_data_objects_are_independent(golden):
+    """Two hand-built MatchesData of the same image size (loader.py:36-53): importing the second into the engine must
+    not change what a fit of the first one sees (advisor r02: a pooled workspace handed A the observations of B)."""
+    from sucre_amd import loader, sucre
+    sc = golden.scene
+    images = [SynthImage(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)]
+    _, samples = helpers.oracle_scene_samples(sc)
+    target = images[sc.target]
+
+    def build(smps):
+        md = loader.MatchesData()
+        for u, v, cP, I in smps:
+            md.append(u=torch.tensor(u), v=torch.tensor(v), cP=torch.tensor(cP), I=torch.tensor(I))
+        return md
+    md_a, md_b = build(samples), build(samples[:2])            # B: fewer views -> different observations
+    a = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
+    a.update_J(md_a)
+    J_a = a.J.cpu().numpy().copy()
+    b = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
+    b.update_J(md_b)                                            # imports B
+    assert md_a.restoration is not md_b.restoration
+    a2 = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
+    a2.update_J(md_a)                                           # A again, after B was imported
+    assert np.array_equal(a2.J.cpu().numpy(), J_a, equal_nan=True)
+    assert helpers.rms_per_channel(J_a, golden['J_closed_init']).max() < 1e-6
+    assert not np.array_equal(b.J.cpu().numpy(), J_a, equal_nan=True)

@@ -166,3 +166,45 @@ def test_images_in_flight_equal_one_by_one_under_load():
     finally:
         stop.append(1)
         th.join()
+
+
+@pytest.mark.timeout(900)
+def test_cli_sharded_over_two_processes_equals_one_process(tmp_path):
+    """`python -m sucre_amd.sucre --image-ids ...` under WORLD_SIZE=2 (the torchrun contract; both ranks on this box's one
+    GPU): every rank restores its shard of the images (dist.shard_images, no collective) and the union of the two
+    ranks' output files equals the one-process run byte for byte (.pt tensors bit for bit, PNGs as files)."""
+    import torch
+    from sucre_amd import synth
+    scene_dir = tmp_path / 'scene'
+    survey = synth.make_survey(160, 120, 3, 2, seed=4)
+    synth.write_to_disk(survey, scene_dir)
+    base = [sys.executable, '-m', 'sucre_amd.sucre', '--image-dir', str(scene_dir / 'images'), '--depth-dir', str(scene_dir / 'depth'),
+            '--model-dir', str(scene_dir / 'model'), '--image-ids', '1', '7', '--num-iter', '12']
+    clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    clean['PYTHONPATH'] = str(ROOT) + os.pathsep + clean.get('PYTHONPATH', '')
+    one = subprocess.run(base + ['--output-dir', str(tmp_path / 'one')], env=clean, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    procs = []
+    for rank in range(2):
+        env = dict(clean, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', LOCAL_WORLD_SIZE='2')
+        procs.append(subprocess.Popen(base + ['--output-dir', str(tmp_path / 'two')], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    # every rank restored its own three images and nobody else's
+    restored = [sorted(ln.split()[1].rstrip('.') for ln in so.splitlines() if ln.startswith('Restore ')) for so, _ in outs]
+    names = sorted(v.name for v in survey.views)
+    assert restored[0] == names[:3] and restored[1] == names[3:], restored
+    files_one = sorted(f.name for f in (tmp_path / 'one').iterdir())
+    files_two = sorted(f.name for f in (tmp_path / 'two').iterdir())
+    assert files_one == files_two and len([f for f in files_one if f.endswith('.pt')]) == 6
+    for name in files_one:
+        a, b = tmp_path / 'one' / name, tmp_path / 'two' / name
+        if name.endswith('.pt'):
+            sa, sb = torch.load(a), torch.load(b)
+            assert set(sa) == set(sb)
+            for k in sa:
+                assert torch.equal(torch.nan_to_num(sa[k]), torch.nan_to_num(sb[k])) and torch.equal(torch.isnan(sa[k]), torch.isnan(sb[k])), (name, k)
+        else:
+            assert a.read_bytes() == b.read_bytes(), name

@@ -153,3 +153,107 @@ def test_config2_light_model_vs_oracle():
     assert abs(tr[0, 0] / to[0, 0] - 1) < 1e-6
     assert rms.max() < 2e-5 and np.abs(tr[:, 1:10] - to[:, 1:10]).max() < 2e-5
     assert np.abs(tr[:, 10:] - to[:, 10:]).max() < 1e-3
+
+
+@pytest.mark.timeout(1800)
+def test_config4_shape_group_of_four_1080p_images_vs_oracle():
+    """BASELINE config 4's per-rank shape, scaled to what the oracle does in a minute: FOUR 1920x1080 images x 65 views
+    (~316 M observations) in ONE HipWaterGroup -- one launch per iteration walks all four images and every lane's ten
+    float32 sums keep running across them (csrc/fit.hip, group_iter_kernel) -- five iterations against the oracle's
+    lock-step run (oracle.SharedWaterImage; pinned to tied reference modules by tests/test_oracle_golden.py), in
+    J-parameter and in closed-form mode.  Bars (task 1a): B, beta, gamma <= 1e-5, per-channel RMS(J)
+    <= 1e-5, cost <= 1e-5 relative."""
+    from sucre_amd import dist as sdist
+    from sucre_amd import engine, synth
+    T = 5
+    rs, views_keep, host = [], [], []
+    for seed in (0, 1, 2, 3):
+        scene = synth.make_scene(1920, 1080, 64, seed=seed, device='cuda')
+        views = engine.device_views_from_scene(scene, 'cuda')
+        r = engine.Restoration(scene.height, scene.width, len(views))
+        r.match(views[scene.target], views)
+        rs.append(r); views_keep.append((views, scene.target))
+        host.append(_host_scene(scene))
+        del scene
+    torch.cuda.synchronize()
+    samples, J0s = [], []
+    for h in host:
+        _, smp = helpers.oracle_scene_samples(h)
+        tgt = h.views[h.target]
+        samples.append(smp)
+        J0s.append(oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()))
+    n_each = [sum(len(s[0]) for s in smp) for smp in samples]
+    assert [r.n_obs() for r in rs] == n_each
+    total = sum(n_each)
+    H, W = 1080, 1920
+    for closed in (False, True):
+        for r, (views, t) in zip(rs, views_keep):
+            r.fit_init(views[t])
+        trace = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
+        group = engine.HipWaterGroup(rs, use_closed_form=closed, trace=trace)
+        sdist.fit_shared_water(group, T)
+        torch.cuda.synchronize()
+        tr = trace.cpu().numpy()
+        oimgs = [oracle.SharedWaterImage(H, W, smp, None if closed else J0, use_closed_form=closed)
+                 for smp, J0 in zip(samples, J0s)]
+        pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
+        to = np.zeros((T, 10))
+        for it in range(1, T + 1):
+            acc = sum(o.grad(pstate[:9], it, total) for o in oimgs)
+            oracle.shared_step(pstate, acc, it, total)
+            to[it - 1, 0] = acc[9]; to[it - 1, 1:] = pstate[:9]
+        if closed:
+            for o in oimgs:
+                o.final_update_J(pstate[:9])
+        dpar = np.abs(tr[:, 1:] - to[:, 1:]).max()
+        dcost = np.abs(tr[:, 0] / to[:, 0] - 1).max()
+        rms = []
+        for r, o in zip(rs, oimgs):
+            J = r.J().cpu().numpy()
+            assert np.array_equal(np.isnan(J), np.isnan(o.J))
+            rms.append(helpers.rms_per_channel(J, o.J).max())
+            assert np.array_equal(r.params().cpu().numpy(), tr[-1, 1:].astype(np.float32))
+        print(f'config-4 shape, 4 x 1080p x 65 views in one group, closed={closed}: n_obs={total} max rms(J)={max(rms):.3e} '
+              f'max|dparams|={dpar:.3e} max rel dcost={dcost:.3e}')
+        print('   rel dcost per iteration:', np.array2string(tr[:, 0] / to[:, 0] - 1, precision=2))
+        assert max(rms) < RMS_BAR and dpar < PARAM_BAR and dcost < COST_BAR, (closed, rms, dpar, dcost)
+        del oimgs
+
+
+@pytest.mark.timeout(2400)
+def test_config5_all_257_views_u16mm_vs_oracle():
+    """BASELINE config 5 on ALL of its views: 3840x2160 x 257 views (~605 M observations) in the compact 5 B/obs store,
+    two iterations against the oracle fed `quantize_ranges_u16mm` (17 GB of host lists in the reference's 28 B/obs
+    format), J-parameter and closed-form."""
+    from sucre_amd import engine, synth
+    W, H, T = 3840, 2160, 2
+    scene = synth.make_scene(W, H, 256, seed=2, device='cuda', spacing=0.05)
+    views = engine.device_views_from_scene(scene, 'cuda')
+    r = engine.Restoration(H, W, len(views), obs_format='u16mm')
+    r.match(views[scene.target], views)
+    n = r.n_obs()
+    counts = r.view_counts().cpu().numpy().tolist()
+    eng = {}
+    for closed in (False, True):
+        r.fit_init(views[scene.target])
+        trace = r.fit(T, use_closed_form=closed)
+        torch.cuda.synchronize()
+        eng[closed] = (r.J().cpu().numpy(), r.params().cpu().numpy().copy(), trace.cpu().numpy(), n, counts)
+    host = _host_scene(scene)
+    del r, views, scene
+    torch.cuda.empty_cache()
+    per_view, samples = helpers.oracle_scene_samples(host)
+    countso = [len(m) for _, _, m in per_view]
+    del per_view
+    samples = oracle.quantize_ranges_u16mm(samples)
+    tgt = host.views[host.target]
+    no = sum(len(s[0]) for s in samples)
+    assert no > 550_000_000, no
+    for closed in (False, True):
+        J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+        Jo, po, to = oracle.fit(H, W, samples, J0, num_iter=T, use_closed_form=closed)
+        _compare(eng[closed], (Jo, po, to, no, countso), rms_bar=5e-5 if closed else RMS_BAR,
+                 param_bar=2e-5 if closed else PARAM_BAR, cost_bar=1e-4 if closed else COST_BAR,
+                 label=f'config 5, all 257 views, u16mm, closed={closed}')
+        if closed:
+            assert abs(eng[closed][2][0, 0] / to[0, 0] - 1) < 1e-6

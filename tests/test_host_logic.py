@@ -200,6 +200,15 @@ def test_api_surface_mirrors_reference_signatures():
         'num_iter', 'batch_size', 'save_interval', 'params_path', 'force_compute_matches', 'keep_matches', 'num_workers', 'device']
     # the reference's positional arguments first; light_model is an extra trailing keyword (default False)
     assert list(inspect.signature(sfm.Image.match_images).parameters)[:6] == ['self', 'image_list', 'matches_file', 'min_cover', 'num_workers', 'device']
+    # match_two_way / match_one_way take the reference's arguments positionally (sfm.py:115,121)
+    assert list(inspect.signature(sfm.Image.match_two_way).parameters)[:8] == ['self', 'other', 'u1', 'v1', 'wP1', 'u2', 'v2', 'wP2']
+    assert list(inspect.signature(sfm.Image.match_one_way).parameters)[:5] == ['self', 'other', 'u1', 'v1', 'wP1']
+    # the reference's default device is 'cpu' (sfm.py:128, sucre.py:133,176): kept in the signatures, refused loudly at run time
+    for fn in (sfm.Image.match_images, sucre.restore_image, sucre.adam):
+        assert inspect.signature(fn).parameters['device'].default == 'cpu', fn
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        sfm.require_gpu('cpu', 'restore_image')
+    sfm.require_gpu('cuda:3', 'x')
     assert list(inspect.signature(sfm.COLMAPModel.__init__).parameters) == ['self', 'model_dir', 'image_dir', 'depth_dir', 'image_scale']
     assert list(inspect.signature(loader.MatchesFile.__init__).parameters) == ['self', 'path', 'colmap_model', 'overwrite']
     for name in ('MatchesSample', 'MatchesData', 'MatchesFile', 'ImageDataset', 'load_rgb', 'load_depth_map', 'load_image_list'):
@@ -376,22 +385,6 @@ def test_overlap_cull_never_drops_a_view_that_has_matches():
     assert kept_empty <= 3 * 10            # and few empty ones are kept (the test is conservative, not blind)
 
 
-def test_match_one_way_mirrors_the_reference_semantics():
-    """sfm.Image.match_one_way (sfm.py:115-119): truncation towards zero, bounds test on the other sensor, no
-    in-front-of-camera test; against the oracle's forward half of the two-way matcher on a plane fixture."""
-    from sucre_amd import synth
-    scene = synth.make_scene(64, 48, 2, seed=3)
-    ims = _images_of(scene)
-    t, o = ims[scene.target], ims[0]
-    d = scene.views[scene.target].depth_f32()
-    u1, v1, wP1 = t.unproject_depth_map(d, to_world=True)
-    m = t.match_one_way(o, u1=u1, v1=v1, wP1=wP1)
-    px = o.project_to_view(wP1)
-    ref = (px[0] > -1) & (px[0] < 64) & (px[1] > -1) & (px[1] < 48)      # trunc(x) in [0, W) <=> -1 < x < W
-    assert len(m) == int(ref.sum()) and len(m) > 0
-    assert torch.equal(m.u1, u1[ref]) and torch.equal(m.v2, px[1][ref].long()) and int(m.u2.min()) >= 0
-
-
 def test_percentile_plan_and_lerp_are_numpys_percentile():
     """plot_J's percentiles on the device = two exact order statistics (GPU) + numpy's interpolation restated on the
     host: ranks, weight and lerp must reproduce np.percentile of a float32 array bit for bit (and its dtype)."""
@@ -564,6 +557,25 @@ def test_png_writer_processes(tmp_path, monkeypatch):
             except _png.WorkerLost:
                 lost += 1
         assert lost <= 1 and np.array_equal(np.array(PILImage.open(tmp_path / 'after.png')), imgs[2])
+        # every worker killed at once (the OOM killer): callers neither hang nor see a short read as garbage -- each gets
+        # WorkerLost at most once and the pool starts replacements
+        for q in list(pool._procs):
+            q.kill(); q.wait()
+        results = []
+
+        def attempt(i):
+            for _ in range(3):
+                try:
+                    pool.write(tmp_path / f'k{i}.png', imgs[i])
+                    results.append(i)
+                    return
+                except _png.WorkerLost:
+                    continue
+        threads = [threading.Thread(target=attempt, args=(i,)) for i in range(4)]
+        [t.start() for t in threads]
+        [t.join(timeout=60) for t in threads]
+        assert not any(t.is_alive() for t in threads) and sorted(results) == [0, 1, 2, 3]
+        assert all(q.poll() is None for q in pool._procs) and 1 <= len(pool._procs) <= 2
         _png.POOL = pool                                   # and loader's readers go through the pool when asked to
         monkeypatch.setenv('SUCRE_DECODE_IN_WORKERS', '1')
         try:

@@ -178,3 +178,56 @@ def test_u16mm_ranges_stay_inside_the_parity_bar(golden):
     assert np.array_equal(np.isnan(J), np.isnan(golden['J_param_200']))
     assert helpers.rms_per_channel(J, golden['J_param_200']).max() < 2e-5
     assert np.abs(tr[:, 1:] - golden['trace_param'][:, 1:]).max() < 1e-4
+
+
+# ---- round 3: closed-form "knee" scenes and the closed-form shared-water composition (gen_golden_extras.py) ----------
+
+def test_knee_scenes_oracle_within_reference_self_spread():
+    for name in helpers.KNEE_FIXTURES:
+        fx = helpers.load_fixture(name)
+        sc = fx.scene
+        per_view, samples = helpers.oracle_scene_samples(sc)
+        assert [k for _, k, _ in per_view] == fx['kept'].tolist() and sum(len(s[0]) for s in samples) == int(fx['n_obs'])
+        T = fx['trace_closed_bs5'].shape[0]
+        J, params, trace = oracle.fit(sc.height, sc.width, samples, None, num_iter=T, use_closed_form=True)
+        helpers.check_knee(fx, J, trace, name)
+
+
+def shared_oracle_run(scene, targets, T, closed):
+    """Lock-step oracle fit of several targets of one scene with shared B, beta, gamma."""
+    import copy
+    imgs = []
+    for tgt_idx in targets:
+        sc = copy.copy(scene)
+        sc.target = int(tgt_idx)
+        _, samples = helpers.oracle_scene_samples(sc)
+        tgt = sc.views[sc.target]
+        J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+        imgs.append(oracle.SharedWaterImage(sc.height, sc.width, samples, J0, use_closed_form=closed))
+    total = sum(o.n_obs for o in imgs)
+    pstate = np.zeros(27, np.float32); pstate[:9] = 0.1
+    trace = np.zeros((T, 10))
+    for it in range(1, T + 1):
+        acc = sum(o.grad(pstate[:9], it, total) for o in imgs)
+        oracle.shared_step(pstate, acc, it, total)
+        trace[it - 1, 0] = acc[9]; trace[it - 1, 1:] = pstate[:9]
+    if closed:
+        for o in imgs:
+            o.final_update_J(pstate[:9])
+    return imgs, pstate, trace, total
+
+
+def test_shared_water_closed_form_oracle_vs_tied_reference_modules():
+    """The oracle's closed-form lock-step path against two reference SUCRe modules with tied Parameters, each
+    re-solving its J with its own update_J (shared_closed_96x64.npz)."""
+    fx = helpers.load_fixture('relief_96x64_n6')
+    g = np.load(helpers.GOLDEN_DIR / 'shared_closed_96x64.npz')
+    rt = g['trace_bs5']
+    imgs, pstate, trace, total = shared_oracle_run(fx.scene, g['targets'], rt.shape[0], closed=True)
+    assert total == int(g['n_total'])
+    spread = float(np.abs(g['trace_bs1'][:, 1:] - rt[:, 1:]).max())
+    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < max(3 * spread, 2e-5)
+    assert np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 1e-4 and abs(trace[0, 0] / rt[0, 0] - 1) < 1e-6
+    for o, key in zip(imgs, ('J0_bs5', 'J1_bs5')):
+        assert np.array_equal(np.isnan(o.J), np.isnan(g[key]))
+        assert helpers.rms_per_channel(o.J, g[key]).max() < 1e-4
