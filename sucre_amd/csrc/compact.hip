@@ -27,67 +27,33 @@ __device__ __forceinline__ int bin_of(uint32_t count, int n_views) {
     return (int)(((uint64_t)count * (kMaxBins - 1) + n_views - 1) / n_views);
 }
 
-// The views a tile has observations in (kept by min_cover, non-empty in this tile), compacted into LDS by one
-// wave with ballot prefix sums; returns how many.  All 256 threads call it.
-__device__ __forceinline__ int tile_view_list(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ view_keep,
-                                              int tile, int n_views, uint16_t *vlist, int *vn) {
-    const int t = threadIdx.x;
-    if (t < 64) {
-        int n = 0;
-        for (int base = 0; base < n_views; base += 64) {
-            const int k = base + t;
-            const bool f = k < n_views && view_keep[k] != 0 && cnt[(size_t)tile * n_views + k] > 0;
-            const unsigned long long m = __ballot(f);
-            if (f) vlist[n + __builtin_popcountll(m & ((1ull << t) - 1ull))] = (uint16_t)k;
-            n += __builtin_popcountll(m);
-        }
-        if (t == 0) *vn = n;
+// Bit k of keep[] = view k passed the min_cover rule (sfm.py:136); built by ballots, word w by wave w (mod 4).
+// All 256 threads call it; ends with a barrier.
+__device__ __forceinline__ void keep_words(const uint32_t *__restrict__ view_keep, int n_views, int mask_words, uint64_t *keep) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int wv = wave; wv < mask_words; wv += 4) {
+        const int k = wv * 64 + lane;
+        const unsigned long long m = __ballot(k < n_views && view_keep[k] != 0);
+        if (lane == 0) keep[wv] = m;
     }
     __syncthreads();
-    return *vn;
 }
 
-constexpr int kBatch = 8;  // views loaded per thread before any dependent work: independent loads in flight
-
-// 1. per-pixel observation count over the kept views + per-block histogram (blockhist is bin-major).
-__global__ __launch_bounds__(256) void pixel_count_kernel(const uint8_t *__restrict__ obs,
-                                                          const uint16_t *__restrict__ cnt,
+// 1. per-pixel observation count over the kept views + per-block histogram (blockhist is bin-major).  Which views
+//    observe a pixel is bit k of its mask in `pmask`, written by whatever filled view k (match_kernel, or
+//    count_view_kernel after an import) -- the dense ranges are not read again.
+__global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__restrict__ pmask, int mask_words,
                                                           const uint32_t *__restrict__ view_keep, int n_views,
-                                                          int n_tiles, size_t tile_stride, size_t view_stride,
-                                                          uint16_t *__restrict__ pcount,
-                                                          uint64_t *__restrict__ pmask, int mask_words,
+                                                          int n_tiles, uint16_t *__restrict__ pcount,
                                                           uint32_t *__restrict__ blockhist) {
     __shared__ uint32_t hist[kMaxBins];
-    __shared__ uint16_t vlist[kMaxViews];
-    __shared__ int vn;
+    __shared__ uint64_t keep[kMaxViews / 64];
     const int tile = blockIdx.x, t = threadIdx.x;
     hist[t] = 0;
-    const int n = tile_view_list(cnt, view_keep, tile, n_views, vlist, &vn);
-    const uint8_t *tbase = obs + (size_t)tile * tile_stride;
-    uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
-    for (int wv = 0; wv < mask_words; ++wv) mask[wv] = 0ull;
+    keep_words(view_keep, n_views, mask_words, keep);
+    const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     uint32_t c = 0;
-    unsigned long long word = 0ull;
-    int word_idx = 0;
-    for (int i0 = 0; i0 < n; i0 += kBatch) {
-        float z[kBatch];
-        int kk[kBatch];
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            kk[b] = i0 + b < n ? vlist[i0 + b] : -1;
-            z[b] = kk[b] >= 0 ? reinterpret_cast<const float *>(tbase + (size_t)kk[b] * view_stride)[t] : 0.0f;
-        }
-#pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            if (kk[b] >= 0 && (kk[b] >> 6) != word_idx) {  // views come in increasing order: flush the finished word
-                mask[word_idx] = word;
-                word = 0ull;
-                word_idx = kk[b] >> 6;
-            }
-            if (z[b] > 0.0f) { word |= 1ull << (kk[b] & 63); ++c; }
-        }
-    }
-    mask[word_idx] = word;
+    for (int wv = 0; wv < mask_words; ++wv) c += (uint32_t)__builtin_popcountll(mask[wv] & keep[wv]);
     pcount[(size_t)tile * kTilePx + t] = (uint16_t)c;
     atomicAdd(&hist[bin_of(c, n_views)], 1u);  // integer LDS atomics: order-independent result
     __syncthreads();
@@ -277,6 +243,7 @@ template <int kFmt, int kExt>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
+                                                      const uint32_t *__restrict__ view_keep,
                                                       const StripMeta *__restrict__ meta,
                                                       uint8_t *__restrict__ comp, int n_views,
                                                       const uint8_t *__restrict__ ext_dense,
@@ -287,7 +254,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kStageBytes];
     __shared__ uint32_t present;
     __shared__ uint8_t vl[kStageViews];
+    __shared__ uint64_t keep[kMaxViews / 64];
     const int tile = blockIdx.x, t = threadIdx.x;
+    keep_words(view_keep, n_views, mask_words, keep);   // pmask holds every view; the fit streams the kept ones
     const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
     const uint32_t dlane = dst % kStripPx;
     const StripMeta sm = meta[dst / kStripPx];
@@ -303,7 +272,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     LevelGroup<kExt> q;
     clear_group(q);
     for (int g0 = 0; g0 < n_views; g0 += kStageViews) {
-        const uint32_t bits = (uint32_t)(mask[g0 >> 6] >> (g0 & 63)) &
+        const uint32_t bits = (uint32_t)((mask[g0 >> 6] & keep[g0 >> 6]) >> (g0 & 63)) &
                               (kStageViews == 32 ? 0xffffffffu : ((1u << (kStageViews & 31)) - 1u));  // views g0 .. g0+kStageViews-1
         if (t == 0) present = 0u;
         __syncthreads();
@@ -363,7 +332,6 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
 
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
                           int fmt, const uint8_t *ext2_dense, uint8_t *ext2_comp) {
-    auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *keep = reinterpret_cast<const uint32_t *>(ws + L.off_view_keep);
     auto *pcount = reinterpret_cast<uint16_t *>(ws + L.off_pcount);
     auto *pmask = reinterpret_cast<uint64_t *>(ws + L.off_pmask);
@@ -374,8 +342,8 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     auto *invperm = reinterpret_cast<uint32_t *>(ws + L.off_invperm);
     auto *meta = reinterpret_cast<StripMeta *>(ws + L.off_strip_meta);
     const int bins = num_bins(L.n_views);
-    hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, keep, L.n_views,
-                       L.n_tiles, L.obs_tile_stride, L.obs_view_stride, pcount, pmask, L.mask_words, blockhist);
+    hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, pmask, L.mask_words, keep, L.n_views, L.n_tiles,
+                       pcount, blockhist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), dim3(256), 0, s, blockhist, L.n_tiles, totals);
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, s, totals, bins, bin_base);
     hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, bin_base, L.n_views,
@@ -388,16 +356,16 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     uint8_t *comp = ws + L.off_comp;
     if (ext_dense && ext2_dense)  // light model on float32 colours: camera points and colours ride along
         hipLaunchKernelGGL((scatter_kernel<0, 2>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else if (ext_dense)  // light model / float32 colours: float32 store only
         hipLaunchKernelGGL((scatter_kernel<0, 1>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else if (fmt)
         hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else
         hipLaunchKernelGGL((scatter_kernel<0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_plan(L, ws, fmt, s);   // the fit waves' item streams over the store just written (fit.hip)
 }
