@@ -39,21 +39,41 @@ __device__ __forceinline__ void keep_words(const uint32_t *__restrict__ view_kee
     __syncthreads();
 }
 
-// 1. per-pixel observation count over the kept views + per-block histogram (blockhist is bin-major).  Which views
-//    observe a pixel is bit k of its mask in `pmask`, written by whatever filled view k (match_kernel, or
-//    count_view_kernel after an import) -- the dense ranges are not read again.
-__global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__restrict__ pmask, int mask_words,
-                                                          const uint32_t *__restrict__ view_keep, int n_views,
-                                                          int n_tiles, uint16_t *__restrict__ pcount,
+// 1. per-pixel observation count over the kept views + per-block histogram (blockhist is bin-major), from the views'
+//    pixel bits (`vbits`: 32 bytes per (tile, view), written by whatever filled view k: match_kernel, or
+//    count_view_kernel after an import) -- the dense ranges are not read again (that pass took 129 us per image).
+//    Also writes every pixel's mask of kept views (`pmask`), which drives the scatter.
+constexpr int kBitsStage = 256;   // views whose bits are staged in LDS at a time (8 KB)
+
+__global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__restrict__ vbits, uint64_t *__restrict__ pmask,
+                                                          int mask_words, const uint32_t *__restrict__ view_keep,
+                                                          int n_views, int n_tiles, uint16_t *__restrict__ pcount,
                                                           uint32_t *__restrict__ blockhist) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint64_t keep[kMaxViews / 64];
+    __shared__ uint64_t vb[kBitsStage][4];
     const int tile = blockIdx.x, t = threadIdx.x;
     hist[t] = 0;
     keep_words(view_keep, n_views, mask_words, keep);
-    const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
+    const int l = t >> 2, j = t & 3;   // slot t = 4 l + j: bit l of word j
+    uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     uint32_t c = 0;
-    for (int wv = 0; wv < mask_words; ++wv) c += (uint32_t)__builtin_popcountll(mask[wv] & keep[wv]);
+    for (int base = 0; base < n_views; base += kBitsStage) {
+        const int nv = min(kBitsStage, n_views - base);
+        __syncthreads();
+        for (int i = t; i < nv * 4; i += 256) vb[i >> 2][i & 3] = vbits[((size_t)tile * n_views + base) * 4 + i];
+        __syncthreads();
+        for (int w0 = 0; w0 < nv; w0 += 64) {   // one 64-bit word of the pixel's mask
+            const int wv = (base + w0) >> 6;
+            const uint64_t kw = keep[wv];
+            uint64_t word = 0ull;
+            const int n = min(64, nv - w0);
+            for (int i = 0; i < n; ++i) word |= ((vb[w0 + i][j] >> l) & 1ull) << i;
+            word &= kw;
+            mask[wv] = word;
+            c += (uint32_t)__builtin_popcountll(word);
+        }
+    }
     pcount[(size_t)tile * kTilePx + t] = (uint16_t)c;
     atomicAdd(&hist[bin_of(c, n_views)], 1u);  // integer LDS atomics: order-independent result
     __syncthreads();
@@ -111,10 +131,11 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint16_t *__restrict
 
 // 3a. levels of every strip (64 consecutive sorted pixels) = the largest pixel count in it; the chunks wholly below
 //     the smallest count hold real observations only, which lets the fit skip the validity select there.
-//     One workgroup per sorted tile = four strips, one per wave.
+//     One workgroup per sorted tile = four strips, one per wave; also the tile's total, for the offsets below.
 __global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__restrict__ pcount,
                                                            const uint32_t *__restrict__ perm,
-                                                           StripMeta *__restrict__ meta) {
+                                                           StripMeta *__restrict__ meta, uint32_t *__restrict__ tile_levels) {
+    __shared__ uint32_t lv[kStripsPerTile];
     const int t = threadIdx.x;
     uint32_t mx = pcount[perm[(size_t)blockIdx.x * kTilePx + t]], mn = mx;
 #pragma unroll
@@ -126,29 +147,54 @@ __global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__res
         StripMeta *m = meta + (size_t)blockIdx.x * kStripsPerTile + (t >> 6);
         m->levels = mx;
         m->full = mn;
+        lv[t >> 6] = mx;
     }
+    __syncthreads();
+    if (t == 0) tile_levels[blockIdx.x] = lv[0] + lv[1] + lv[2] + lv[3];
 }
 
-// 3b. where every strip's chunks start, in levels (exclusive scan of the strips' level counts; one workgroup).
-__global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict__ meta, int n_strips,
-                                                           uint64_t *__restrict__ total_levels, int fmt) {
-    __shared__ unsigned long long part[256];
-    const int t = threadIdx.x;
-    const int per = (n_strips + 255) / 256;
-    const int lo = t * per, hi = min(lo + per, n_strips);
+// 3b. where every strip's chunks start, in levels: exclusive scan of the sorted tiles' totals by one workgroup of 1024
+//     (coalesced reads: thread t takes a run of consecutive tiles), then every tile spreads its offset over its four
+//     strips.  (Scanning the 16-byte StripMeta records themselves in one workgroup took 62 us per image.)
+__global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__restrict__ tile_levels, int n_tiles,
+                                                           uint64_t *__restrict__ tile_off, uint64_t *__restrict__ total_levels,
+                                                           int fmt) {
+    __shared__ unsigned long long wave_base[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (n_tiles + 1023) / 1024;
+    const int lo = min(t * per, n_tiles), hi = min(lo + per, n_tiles);
     unsigned long long s = 0;
-    for (int i = lo; i < hi; ++i) s += meta[i].levels;
-    part[t] = s;
+    for (int i = lo; i < hi; ++i) s += tile_levels[i];
+    unsigned long long incl = s;   // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_base[wave] = incl;
     __syncthreads();
     if (t == 0) {
         unsigned long long run = 0;
-        for (int i = 0; i < 256; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        for (int i = 0; i < 16; ++i) { const unsigned long long v = wave_base[i]; wave_base[i] = run; run += v; }
         *total_levels = run;
         *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
     }
     __syncthreads();
-    unsigned long long run = part[t];
-    for (int i = lo; i < hi; ++i) { meta[i].lvoff = run; run += meta[i].levels; }
+    unsigned long long run = wave_base[wave] + incl - s;
+    for (int i = lo; i < hi; ++i) { tile_off[i] = run; run += tile_levels[i]; }
+}
+
+__global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict__ meta, const uint64_t *__restrict__ tile_off,
+                                                           int n_tiles) {
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= n_tiles) return;
+    uint64_t run = tile_off[tile];
+#pragma unroll
+    for (int i = 0; i < kStripsPerTile; ++i) {
+        StripMeta *m = meta + (size_t)tile * kStripsPerTile + i;
+        m->lvoff = run;
+        run += m->levels;
+    }
 }
 
 // 3c. the compaction itself, driven from the DENSE side.  One workgroup owns one dense tile: it stages the tile's
@@ -239,11 +285,22 @@ __device__ __forceinline__ void clear_group(LevelGroup<kExt> &q) {
     q.c[0] = q.c[1] = q.c[2] = 0u;
 }
 
+// Position (0..15) of the (n+1)-th set bit of a 16-bit mask that has more than n bits set.
+__device__ __forceinline__ int nth_set_bit(uint32_t p, int n) {
+    int pos = 0;
+    int c = __builtin_popcount(p & 0xffu);
+    if (n >= c) { n -= c; pos = 8; p >>= 8; }
+    c = __builtin_popcount(p & 0xfu);
+    if (n >= c) { n -= c; pos += 4; p >>= 4; }
+    c = __builtin_popcount(p & 0x3u);
+    if (n >= c) { n -= c; pos += 2; p >>= 2; }
+    return pos + ((n >= (int)(p & 1u)) ? 1 : 0);
+}
+
 template <int kFmt, int kExt>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
-                                                      const uint32_t *__restrict__ view_keep,
                                                       const StripMeta *__restrict__ meta,
                                                       uint8_t *__restrict__ comp, int n_views,
                                                       const uint8_t *__restrict__ ext_dense,
@@ -251,12 +308,13 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                                                       const uint8_t *__restrict__ ext2_dense,
                                                       uint8_t *__restrict__ ext2_comp) {
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
+    constexpr uint32_t kStageMask = (1u << kStageViews) - 1u;
+    static_assert(kStageViews == 8 || kStageViews == 16, "a stage group is a byte or a half word of the 32-bit presence words");
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageViews][kStageBytes];
-    __shared__ uint32_t present;
-    __shared__ uint8_t vl[kStageViews];
-    __shared__ uint64_t keep[kMaxViews / 64];
+    __shared__ uint32_t tpres[kMaxViews / 32];   // bit k: some pixel of the tile has a kept observation in view k
     const int tile = blockIdx.x, t = threadIdx.x;
-    keep_words(view_keep, n_views, mask_words, keep);   // pmask holds every view; the fit streams the kept ones
+    for (int i = t; i < 2 * mask_words; i += 256) tpres[i] = 0u;
+    __syncthreads();
     const uint32_t dst = invperm[(size_t)tile * kTilePx + t];
     const uint32_t dlane = dst % kStripPx;
     const StripMeta sm = meta[dst / kStripPx];
@@ -266,38 +324,74 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                             kExt >= 2 ? reinterpret_cast<float *>(ext2_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr};
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     const uint8_t *tbase = obs + (size_t)tile * tile_stride;
+    for (int wv = 0; wv < mask_words; ++wv) {
+        const uint64_t m = mask[wv];
+        if ((uint32_t)m) atomicOr(&tpres[2 * wv], (uint32_t)m);
+        if ((uint32_t)(m >> 32)) atomicOr(&tpres[2 * wv + 1], (uint32_t)(m >> 32));
+    }
+    __syncthreads();
     constexpr int kUnits = kStageBytes / 16;  // 16-byte pieces of a staged view
     constexpr int kMainUnits = kChunk / 16;
+    constexpr int kExtUnits = kExtChunk / 16;
+    // The views of a group that some pixel of the tile uses are staged through LDS: every dense chunk is read once,
+    // coalesced.  Without extension planes the NEXT group's pieces are fetched into registers while this group is being
+    // scattered (7 x 16 bytes per thread), so the fetch latency hides behind the stores instead of preceding them.
+    constexpr bool kPrefetch = kExt == 0;
+    constexpr int kIters = (kStageViews * kUnits + 255) / 256;
+    auto present = [&](int g0) -> uint32_t { return g0 < n_views ? (tpres[g0 >> 5] >> (g0 & 31)) & kStageMask : 0u; };
+    auto next_group = [&](int g0) { while (g0 < n_views && present(g0) == 0u) g0 += kStageViews; return g0; };   // workgroup-uniform
+    auto piece = [&](int g0, uint32_t p, int u) -> const uint8_t * {
+        const int sl = u / kUnits, w = u - sl * kUnits;
+        const int k = g0 + nth_set_bit(p, sl);
+        return (!kExt || w < kMainUnits)
+            ? tbase + (size_t)k * view_stride + (size_t)w * 16
+            : (kExt < 2 || w < kMainUnits + kExtUnits)
+                ? ext_dense + ((size_t)tile * n_views + k) * kExtChunk + (size_t)(w - kMainUnits) * 16
+                : ext2_dense + ((size_t)tile * n_views + k) * kExtChunk + (size_t)(w - kMainUnits - kExtUnits) * 16;
+    };
+    static_assert(!kPrefetch || kIters <= 8, "eight named prefetch registers");
+    uint4 r0, r1, r2, r3, r4, r5, r6, r7;   // named, not an array: an indexed uint4 array ended up in scratch memory
+    r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = make_uint4(0u, 0u, 0u, 0u);
+#define SUCRE_EACH_REG(X) X(0, r0) X(1, r1) X(2, r2) X(3, r3) X(4, r4) X(5, r5) X(6, r6) X(7, r7)
     uint32_t lv = 0;
     LevelGroup<kExt> q;
     clear_group(q);
-    for (int g0 = 0; g0 < n_views; g0 += kStageViews) {
-        const uint32_t bits = (uint32_t)((mask[g0 >> 6] & keep[g0 >> 6]) >> (g0 & 63)) &
-                              (kStageViews == 32 ? 0xffffffffu : ((1u << (kStageViews & 31)) - 1u));  // views g0 .. g0+kStageViews-1
-        if (t == 0) present = 0u;
-        __syncthreads();
-        if (bits) atomicOr(&present, bits);
-        __syncthreads();
-        const uint32_t p = present;  // views of the group that some pixel of the tile uses (workgroup-uniform)
-        if (p == 0u) continue;
-        if (t < kStageViews && ((p >> t) & 1u)) vl[__builtin_popcount(p & ((1u << t) - 1u))] = (uint8_t)t;
-        __syncthreads();
-        const int total = __builtin_popcount(p) * kUnits;
-        for (int u = t; u < total; u += 256) {
-            const int i = vl[u / kUnits], w = u % kUnits;
-            constexpr int kExtUnits = kExtChunk / 16;
-            const uint8_t *src = (!kExt || w < kMainUnits)
-                ? tbase + (size_t)(g0 + i) * view_stride + (size_t)w * 16
-                : (kExt < 2 || w < kMainUnits + kExtUnits)
-                    ? ext_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits) * 16
-                    : ext2_dense + ((size_t)tile * n_views + (g0 + i)) * kExtChunk + (size_t)(w - kMainUnits - kExtUnits) * 16;
-            *reinterpret_cast<uint4 *>(&stage[i][w * 16]) = *reinterpret_cast<const uint4 *>(src);
+    int g0 = next_group(0);
+    if (kPrefetch && g0 < n_views) {
+        const uint32_t pf = present(g0);
+        const int total_f = __builtin_popcount(pf) * kUnits;
+#define SUCRE_X(IT, R) if (IT < kIters && t + 256 * IT < total_f) R = *reinterpret_cast<const uint4 *>(piece(g0, pf, t + 256 * IT));
+        SUCRE_EACH_REG(SUCRE_X)
+#undef SUCRE_X
+    }
+    while (g0 < n_views) {
+        const uint32_t p = present(g0);
+        if (kPrefetch) {
+            __syncthreads();  // everyone is done with the stage of the previous group
+            const int total_s = __builtin_popcount(p) * kUnits;   // staged slot sl holds the (sl+1)-th present view of the group
+#define SUCRE_X(IT, R) if (IT < kIters && t + 256 * IT < total_s) *reinterpret_cast<uint4 *>(&stage[(t + 256 * IT) / kUnits][((t + 256 * IT) % kUnits) * 16]) = R;
+            SUCRE_EACH_REG(SUCRE_X)
+#undef SUCRE_X
+        } else {
+            __syncthreads();
+            const int total = __builtin_popcount(p) * kUnits;
+            for (int u = t; u < total; u += 256)
+                *reinterpret_cast<uint4 *>(&stage[u / kUnits][(u % kUnits) * 16]) = *reinterpret_cast<const uint4 *>(piece(g0, p, u));
         }
         __syncthreads();
-        uint32_t m = bits;
+        const int gn = next_group(g0 + kStageViews);
+        if (kPrefetch && gn < n_views) {
+            const uint32_t pf = present(gn);
+            const int total_f = __builtin_popcount(pf) * kUnits;
+#define SUCRE_X(IT, R) if (IT < kIters && t + 256 * IT < total_f) R = *reinterpret_cast<const uint4 *>(piece(gn, pf, t + 256 * IT));
+            SUCRE_EACH_REG(SUCRE_X)
+#undef SUCRE_X
+        }
+        uint32_t m = (uint32_t)(mask[g0 >> 6] >> (g0 & 63)) & kStageMask;   // this pixel's views of the group
         while (m) {
-            const int i = __builtin_ctz(m);
+            const int b = __builtin_ctz(m);
             m &= m - 1u;
+            const int i = __builtin_popcount(p & ((1u << b) - 1u));   // the staged slot of view g0 + b
             const uint32_t j = lv & 3u;
             // select-style updates (no dynamic register indexing)
             const float z = reinterpret_cast<const float *>(&stage[i][0])[t];
@@ -319,7 +413,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                 clear_group(q);
             }
         }
-        __syncthreads();  // everyone is done with the stage before the next group overwrites it
+        g0 = gn;
     }
     // the open group (zero-filled past the pixel's last observation), then the all-zero groups up to the strip's
     // level count: the strip has as many levels as its richest pixel
@@ -328,6 +422,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         store_group<kFmt, kExt>(out, eout, g, r, dlane, q);
         clear_group(q);
     }
+#undef SUCRE_EACH_REG
 }
 
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
@@ -342,30 +437,34 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     auto *invperm = reinterpret_cast<uint32_t *>(ws + L.off_invperm);
     auto *meta = reinterpret_cast<StripMeta *>(ws + L.off_strip_meta);
     const int bins = num_bins(L.n_views);
-    hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, pmask, L.mask_words, keep, L.n_views, L.n_tiles,
-                       pcount, blockhist);
+    hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(ws + L.off_vbits),
+                       pmask, L.mask_words, keep, L.n_views, L.n_tiles, pcount, blockhist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), dim3(256), 0, s, blockhist, L.n_tiles, totals);
     hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, s, totals, bins, bin_base);
     hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, bin_base, L.n_views,
                        L.n_tiles, perm, invperm);
-    hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta);
-    hipLaunchKernelGGL(strip_offset_kernel, dim3(1), dim3(256), 0, s, meta, L.n_strips,
+    // the counting sort is done with its histograms: their space holds the sorted tiles' totals and offsets
+    auto *tile_levels = blockhist;
+    auto *tile_off = reinterpret_cast<uint64_t *>(blockhist + align_up((size_t)L.n_tiles, 2));
+    hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels);
+    hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(1024), 0, s, tile_levels, L.n_tiles, tile_off,
                        reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+    hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles);
     const dim3 grid(L.n_tiles), block(256);
     const uint8_t *obs = ws + L.off_obs;
     uint8_t *comp = ws + L.off_comp;
     if (ext_dense && ext2_dense)  // light model on float32 colours: camera points and colours ride along
         hipLaunchKernelGGL((scatter_kernel<0, 2>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else if (ext_dense)  // light model / float32 colours: float32 store only
         hipLaunchKernelGGL((scatter_kernel<0, 1>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else if (fmt)
         hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     else
         hipLaunchKernelGGL((scatter_kernel<0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, keep, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_plan(L, ws, fmt, s);   // the fit waves' item streams over the store just written (fit.hip)
 }

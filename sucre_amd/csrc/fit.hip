@@ -304,43 +304,56 @@ __host__ __device__ __forceinline__ uint32_t item_bits(uint32_t nA, uint32_t nB,
 }
 
 // kMode 0: J plane, chunks, moments (J-parameter iteration, 9 stores at a strip's end); 1: J plane, chunks
-// (closed-form iteration and update_J, 3 stores).  One thread per wave of the fit launch.
-template <int kMode>
-__global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, int fmt, uint32_t W,
-                                                   uint32_t stride, PlanItem *__restrict__ plan,
-                                                   uint32_t *__restrict__ count, uint64_t comp_off, uint64_t state_off) {
-    const uint32_t wid = blockIdx.x * 256u + threadIdx.x;
+// (closed-form iteration and update_J, 3 stores).  One thread per (fit wave, strip of that wave): it finds where its
+// strip's items start in the wave's list from the level counts of the wave's earlier strips (at most a handful) and
+// writes them, waits included.  The wait of item i: the items issued after it (item i is consumed after the items up to
+// i + kAhead were issued: two instructions each), plus the previous strip's stores if they were issued after it -- which
+// is the case for the first kAhead items of every strip but the wave's first.  (The first version replayed the issue
+// order serially, one thread per wave over all its strips: 90 + 60 us per image for the two modes.)
+__device__ __forceinline__ uint32_t strip_items(uint32_t levels, int mode) { return 1u + ((levels + 3u) >> 2) + (mode == 0 ? 1u : 0u); }
+
+__global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, int fmt, uint32_t W0, uint32_t W1,
+                                                   uint32_t Kmax, uint32_t stride0, uint32_t stride1, PlanItem *__restrict__ plan0,
+                                                   PlanItem *__restrict__ plan1, uint32_t *__restrict__ count0,
+                                                   uint32_t *__restrict__ count1, uint64_t comp_off, uint64_t state_off) {
+    const int mode = blockIdx.y;   // both plans in one launch
+    const uint32_t W = mode ? W1 : W0, stride = mode ? stride1 : stride0;
+    PlanItem *plan = mode ? plan1 : plan0;
+    uint32_t *count = mode ? count1 : count0;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t wid = idx / Kmax, k = idx - wid * Kmax;
     if (wid >= W) return;
     const WaveDeal d = make_deal(wid, W, (uint32_t)n_strips);
-    PlanItem *out = plan + (size_t)wid * stride;
+    if (k == 0u && d.K == 0u) count[wid] = 0u;
+    if (k >= d.K) return;
+    uint32_t start = 0u, n = 0u;   // first item of strip k in the wave's list; items of the whole list
+    for (uint32_t kk = 0; kk < d.K; ++kk) {
+        const uint32_t c = strip_items(meta[d.strip(kk)].levels, mode);
+        if (kk < k) start += c;
+        n += c;
+    }
+    if (k == 0u) count[wid] = n;
+    const uint32_t strip = d.strip(k);
+    const StripMeta m = meta[strip];
+    const uint32_t nch = (m.levels + 3u) >> 2;
     const uint32_t lb = (uint32_t)level_bytes(fmt);
-    uint32_t n = 0;
-    for (uint32_t k = 0; k < d.K; ++k) {
-        const uint32_t strip = d.strip(k);
-        const StripMeta m = meta[strip];
-        const uint32_t nch = (m.levels + 3u) >> 2;
-        const uint64_t st = state_off + (uint64_t)strip * (kStateFloats * 4);
-        out[n++] = PlanItem{(uint32_t)(st >> 6), item_bits(32u, 16u, kItemJ, 0u, kMode != 0 && nch == 0u), strip, 0u};
-        for (uint32_t g = 0; g < nch; ++g) {
-            const uint32_t r = min((uint32_t)kGroupLv, m.levels - g * kGroupLv);
-            const uint64_t src = comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb;
-            const uint32_t kind = r < (uint32_t)kGroupLv ? kItemTail : ((g + 1u) * kGroupLv <= m.full ? kItemChunk : kItemChunkMasked);
-            out[n++] = PlanItem{(uint32_t)(src >> 6), item_bits((fmt ? 8u : 16u) * r, 12u * r, kind, r, kMode != 0 && g + 1u == nch),
-                                strip, 0u};
-        }
-        if (kMode == 0) out[n++] = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_bits(64u, 32u, kItemMoments, 0u, true), strip, 0u};
-    }
-    count[wid] = n;
-    // the wait of every item: replay the issue order (item i is consumed after items up to i + kAhead were issued)
-    constexpr uint32_t kStores = kMode == 0 ? 9u : 3u;
-    uint32_t store_after = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t st = state_off + (uint64_t)strip * (kStateFloats * 4);
+    const uint32_t kStores = mode == 0 ? 9u : 3u;
+    PlanItem *out = plan + (size_t)wid * stride;
+    auto put = [&](uint32_t pos, uint32_t src64, uint32_t bits) {
+        const uint32_t i = start + pos;
         const uint32_t issued = min(n, i + 1u + (uint32_t)kAhead);
-        const uint32_t vm = 2u * (issued - 1u - i) + (i < store_after ? kStores : 0u);
-        const uint32_t bits = out[i].bits;
-        out[i].bits = bits | (vm << 24);
-        if (bits & 0x80000000u) store_after = issued;
+        const uint32_t vm = 2u * (issued - 1u - i) + ((k > 0u && pos < (uint32_t)kAhead) ? kStores : 0u);
+        out[i] = PlanItem{src64, bits | (vm << 24), strip, 0u};
+    };
+    put(0u, (uint32_t)(st >> 6), item_bits(32u, 16u, kItemJ, 0u, mode != 0 && nch == 0u));
+    for (uint32_t g = 0; g < nch; ++g) {
+        const uint32_t r = min((uint32_t)kGroupLv, m.levels - g * kGroupLv);
+        const uint64_t src = comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb;
+        const uint32_t kind = r < (uint32_t)kGroupLv ? kItemTail : ((g + 1u) * kGroupLv <= m.full ? kItemChunk : kItemChunkMasked);
+        put(1u + g, (uint32_t)(src >> 6), item_bits((fmt ? 8u : 16u) * r, 12u * r, kind, r, mode != 0 && g + 1u == nch));
     }
+    if (mode == 0) put(1u + nch, (uint32_t)((st + 3 * kStripPx * 4) >> 6), item_bits(64u, 32u, kItemMoments, 0u, true));
 }
 
 __device__ __forceinline__ uint32_t item_kind(uint32_t bits) { return (bits >> 16) & 7u; }
@@ -1058,12 +1071,12 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s)
 hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
     auto *meta = reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta);
     const uint32_t W0 = (uint32_t)L.fit_blocks[0] * 4u, W1 = (uint32_t)L.fit_blocks[1] * 4u;
-    hipLaunchKernelGGL(plan_kernel<0>, dim3((W0 + 255) / 256), dim3(256), 0, s, meta, L.n_strips, fmt, W0, (uint32_t)L.plan_stride[0],
-                       reinterpret_cast<PlanItem *>(ws + L.off_plan[0]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[0]),
-                       (uint64_t)L.off_comp, (uint64_t)L.off_state);
-    hipLaunchKernelGGL(plan_kernel<1>, dim3((W1 + 255) / 256), dim3(256), 0, s, meta, L.n_strips, fmt, W1, (uint32_t)L.plan_stride[1],
-                       reinterpret_cast<PlanItem *>(ws + L.off_plan[1]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[1]),
-                       (uint64_t)L.off_comp, (uint64_t)L.off_state);
+    const uint32_t Wmin = W0 < W1 ? W0 : W1, Wmax = W0 < W1 ? W1 : W0;
+    const uint32_t Kmax = ((uint32_t)L.n_strips + Wmin - 1u) / Wmin;   // strips of the busiest wave (of either mode)
+    hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips, fmt, W0, W1, Kmax,
+                       (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], reinterpret_cast<PlanItem *>(ws + L.off_plan[0]),
+                       reinterpret_cast<PlanItem *>(ws + L.off_plan[1]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[0]),
+                       reinterpret_cast<uint32_t *>(ws + L.off_plan_count[1]), (uint64_t)L.off_comp, (uint64_t)L.off_state);
     return hipGetLastError();
 }
 

@@ -68,8 +68,9 @@ struct Layout {
     size_t off_cnt;         // uint16 [n_tiles][n_views]   matches of view k inside the tile
     size_t off_comp;        // uint8  compact store: strip s at lvoff[s] * level_bytes(fmt), see StripMeta
     size_t off_pcount;      // uint16 [n_tiles*256]        observations of every pixel over the kept views
-    size_t off_pmask;       // uint64 [n_tiles*256][mask_words]  which views observe the pixel (bit k = view k)
+    size_t off_pmask;       // uint64 [n_tiles*256][mask_words]  which kept views observe the pixel (bit k = view k)
     int mask_words;
+    size_t off_vbits;       // uint64 [n_tiles][n_views][4]  which pixels of the tile view k observes: word j, bit l = slot 4 l + j
     size_t off_blockhist;   // uint32 [256 bins][n_tiles]  counting-sort histograms (bin-major), scanned in place
     size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
     size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)
@@ -117,6 +118,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_pcount = take(nt * kTilePx * sizeof(uint16_t));
     L->mask_words = (n_views + 63) / 64;
     L->off_pmask = take(nt * kTilePx * (size_t)L->mask_words * sizeof(uint64_t));
+    L->off_vbits = take(nt * nv * 4 * sizeof(uint64_t));
     L->off_blockhist = take(256 * nt * sizeof(uint32_t));
     L->off_bin_totals = take(512 * sizeof(uint32_t));
     L->off_perm = take(nt * kTilePx * sizeof(uint32_t));

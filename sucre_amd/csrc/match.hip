@@ -22,32 +22,12 @@ __device__ __forceinline__ float dot3(const float *a, float x, float y, float z)
     return acc;
 }
 
-// A pinhole camera matrix and its inverse have the form [[a, 0, b], [0, c, d], [0, 0, 1]] (sfm.py:62-78; torch's LU
-// inverse of an upper-triangular matrix keeps the zeros exact).  For such a matrix the FMA chain of dot3() loses its
-// terms with a zero coefficient without changing a bit of any finite result: fma(0, y, acc) = acc and 0 * x = 0 exactly
-// (only the sign of a zero can differ, which no comparison, truncation or product downstream sees), and a non-finite
-// x, y or z still makes c0 or c1 non-finite, so the bound test rejects the point in both forms.  9 -> 4 operations per
-// product; the flag is wave-uniform (one scalar branch).
-__host__ __device__ __forceinline__ bool pinhole_form(const float *M) {
-    return M[1] == 0.f && M[3] == 0.f && M[6] == 0.f && M[7] == 0.f && M[8] == 1.f;
-}
-
-__device__ __forceinline__ void mul3(const float *M, bool pin, float x, float y, float z, float out[3]) {
-    if (pin) {
-        out[0] = __builtin_fmaf(M[2], z, M[0] * x);
-        out[1] = __builtin_fmaf(M[5], z, M[4] * y);
-        out[2] = z;
-    } else {
-        out[0] = dot3(M + 0, x, y, z);
-        out[1] = dot3(M + 3, x, y, z);
-        out[2] = dot3(M + 6, x, y, z);
-    }
-}
-
 // sfm.py:90-93
-__device__ __forceinline__ void unproject(const float *Kinv, bool pin, float u, float v, float d, float out[3]) {
+__device__ __forceinline__ void unproject(const float *Kinv, float u, float v, float d, float out[3]) {
     const float x = d * (u + 0.5f), y = d * (v + 0.5f), z = d * 1.0f;
-    mul3(Kinv, pin, x, y, z, out);
+    out[0] = dot3(Kinv + 0, x, y, z);
+    out[1] = dot3(Kinv + 3, x, y, z);
+    out[2] = dot3(Kinv + 6, x, y, z);
 }
 
 // sfm.py:49-55
@@ -59,151 +39,62 @@ __device__ __forceinline__ void rigid(const float *R, const float *t, const floa
 
 // sfm.py:103-107,116-117: world point -> continuous pixel; true when Tensor.long() of it lies inside WxH.
 // trunc(x) in [0, W-1]  <=>  -1 < x < W ; NaN and +-inf fail both comparisons like INT64_MIN fails the bound test.
-__device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, bool pin, float Wf, float Hf,
+__device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, float Wf, float Hf,
                                         const float wP[3], float *px, float *py) {
-    float cP[3], c[3];
+    float cP[3];
     rigid(Rinv, tinv, wP, cP);
-    mul3(K, pin, cP[0], cP[1], cP[2], c);
-    *px = c[0] / c[2];
-    *py = c[1] / c[2];
+    const float c0 = dot3(K + 0, cP[0], cP[1], cP[2]);
+    const float c1 = dot3(K + 3, cP[0], cP[1], cP[2]);
+    const float c2 = dot3(K + 6, cP[0], cP[1], cP[2]);
+    *px = c0 / c2;
+    *py = c1 / c2;
     return (*px > -1.0f) && (*px < Wf) && (*py > -1.0f) && (*py < Hf);
 }
 
-// Which of a pair's four camera-matrix products take the short form (wave-uniform).
-struct PinFlags { bool K1, Kinv1, K2, Kinv2; };
+// The views' pixel pointers come out of a table in memory, so the compiler cannot know their address space and would
+// gather through flat loads (which also count against the LDS counter); they are device-memory pointers by contract.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *global_ptr(const T *p) {
+    return (const __attribute__((address_space(1))) T *)p;
+}
 
 // The fused two-way test for one target pixel whose world point is wP: returns true and the matched pixel of
 // view 2 (linear index q, camera-frame point c2) iff p1 -> p2 -> p1 closes (see the file header).
 __device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H1f, const sucre_view_t *vw,
-                                            float W2f, float H2f, const PinFlags pf, const float wP[3], int u1, int v1,
-                                            size_t *q_out, float c2[3]) {
+                                            float W2f, float H2f, const float wP[3], int u1, int v1, size_t *q_out,
+                                            float c2[3]) {
     float px, py;
-    if (!project(vw->Rinv, vw->tinv, vw->K, pf.K2, W2f, H2f, wP, &px, &py)) return false;
+    if (!project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP, &px, &py)) return false;
     const int u2 = (int)px, v2 = (int)py;
     const size_t q = (size_t)v2 * vw->W + u2;
-    const float d2 = vw->depth[q];
+    const float d2 = global_ptr(vw->depth)[q];
     if (!(d2 > 0.0f)) return false;
     float w2[3], qx, qy;
-    unproject(vw->Kinv, pf.Kinv2, (float)u2, (float)v2, d2, c2);
+    unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
     rigid(vw->R, vw->t, c2, w2);
-    if (!project(c1.Rinv, c1.tinv, c1.K, pf.K1, W1f, H1f, w2, &qx, &qy)) return false;
+    if (!project(c1.Rinv, c1.tinv, c1.K, W1f, H1f, w2, &qx, &qy)) return false;
     if ((int)qx != u1 || (int)qy != v1) return false;
     *q_out = q;
     return true;
 }
 
 constexpr int kViewsPerGroup = 16;
-constexpr uint16_t kCulled = 0xffffu;   // cnt[tile][view] left by tile_cull_kernel: no pixel of the tile can land in the view
-
-// ---------------------------------------------------------------------------------------------------------------
-// Tile-level rejection (before match_kernel): 35 % of the (tile, view) pairs of a survey image hold no match at all
-// because the tile's patch of seabed lies outside the view.  Every world point a tile can produce lies in the convex
-// hull of its frustum slab: the tile's pixel rectangle [u0, u0+16] x [v0, v0+16] (the pixel centres sit inside) cut at
-// the tile's smallest and largest valid depth -- 8 corners (unproject scales the ray by the z-depth, sfm.py:90-93; the
-// third row of a pinhole K and of its inverse is (0, 0, 1), checked by the launcher).  A view accepts a camera-frame
-// point c = K (Rinv P + tinv) iff -1 < c0/c2 < W and -1 < c1/c2 < H (match_one_way, sfm.py:115-119; no z > 0 test, so the
-// mirrored cone c2 < 0 accepts too).  If all 8 corners lie on one side of the view's camera plane, at least 1 % of their
-// distance from the view away from it, and all of them violate one and the same half-space of that side's cone -- with
-// kCullMargin pixels of slack, evaluated in float64 from the very float32 matrices match_kernel uses -- then no pixel of
-// the tile can pass match_kernel's float32 bound test (its rounding error is <= 1e-3 px x |cP| / |c2| <= 0.1 px there,
-// far below the slack), the pair has no match, and match_kernel skips it.  Exactly the argument of sfm.Image.overlapping_views, one
-// level down.  One wave per tile (the tile's depth range by shuffles), one lane per view; the views' cameras are staged
-// through LDS once per workgroup of 16 tiles.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr double kCullMargin = 2.0;
-constexpr int kCullTilesPerBlock = 8;
-constexpr int kCullStage = 256;           // views staged per round
-constexpr int kCullWords = 25;            // Rinv[9] tinv[3] K[9] W H + pad: odd stride in LDS = conflict-free per-lane reads
-
-__global__ __launch_bounds__(256) void tile_cull_kernel(uint16_t *__restrict__ cnt, const float *__restrict__ depth1,
-                                                        const CamDev c1, const sucre_view_t *__restrict__ views,
-                                                        int n_views, int k0, int k1, int tiles_x, int n_tiles) {
-    __shared__ float cam[kCullStage][kCullWords];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int base = k0; base < k1; base += kCullStage) {
-        const int nv = min(kCullStage, k1 - base);
-        __syncthreads();   // the previous round's readers are done
-        for (int i = threadIdx.x; i < nv * 23; i += 256) {
-            const int v = i / 23, f = i - v * 23;
-            const sucre_view_t *vw = views + base + v;
-            float x;
-            if (f < 9) x = vw->Rinv[f];
-            else if (f < 12) x = vw->tinv[f - 9];
-            else if (f < 21) x = vw->K[f - 12];
-            else x = f == 21 ? (float)vw->W : (float)vw->H;
-            cam[v][f] = x;
-        }
-        __syncthreads();
-        for (int ti = wave; ti < kCullTilesPerBlock; ti += 4) {
-            const int tile = blockIdx.x * kCullTilesPerBlock + ti;
-            if (tile >= n_tiles) break;   // wave-uniform
-            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-            const int v1 = ty * kTile + (lane >> 2), u1b = tx * kTile + (lane & 3) * 4;
-            float dmin = __builtin_inff(), dmax = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float d = 0.0f;
-                if (v1 < c1.H && u1b + j < c1.W) d = depth1[(size_t)v1 * c1.W + u1b + j];
-                if (d > 0.0f) { dmin = fminf(dmin, d); dmax = fmaxf(dmax, d); }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                dmin = fminf(dmin, __shfl_xor(dmin, off, 64));
-                dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
-            }
-            const bool empty = !(dmax > 0.0f);   // no valid pixel: nothing can match
-            // the 8 hull corners in the world frame (float64; the same for every lane)
-            double P[8][3];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const double x = (double)(tx * kTile + ((c & 1) ? kTile : 0)), y = (double)(ty * kTile + ((c & 2) ? kTile : 0));
-                const double d = (double)((c & 4) ? dmax : dmin);
-                const double rx = (double)c1.Kinv[0] * x + (double)c1.Kinv[1] * y + (double)c1.Kinv[2];
-                const double ry = (double)c1.Kinv[3] * x + (double)c1.Kinv[4] * y + (double)c1.Kinv[5];
-                const double cx = d * rx, cy = d * ry, cz = d;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    P[c][r] = (double)c1.R[3 * r] * cx + (double)c1.R[3 * r + 1] * cy + (double)c1.R[3 * r + 2] * cz + (double)c1.t[r];
-            }
-            for (int v = lane; v < nv; v += 64) {
-                const float *cm = cam[v];
-                const double Wm = (double)cm[21] + kCullMargin, Hm = (double)cm[22] + kCullMargin, one = 1.0 + kCullMargin;
-                // per half-space: did every corner violate it (a <= 0 on the front cone, a >= 0 on the mirrored one)?
-                bool allneg[4] = {true, true, true, true}, allpos[4] = {true, true, true, true};
-                bool front = true, back = true;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    double q[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        q[r] = (double)cm[3 * r] * P[c][0] + (double)cm[3 * r + 1] * P[c][1] + (double)cm[3 * r + 2] * P[c][2] + (double)cm[9 + r];
-                    const double c0 = (double)cm[12] * q[0] + (double)cm[13] * q[1] + (double)cm[14] * q[2];
-                    const double c1_ = (double)cm[15] * q[0] + (double)cm[16] * q[1] + (double)cm[17] * q[2];
-                    const double c2 = (double)cm[18] * q[0] + (double)cm[19] * q[1] + (double)cm[20] * q[2];
-                    const double guard = 0.01 * (fabs(q[0]) + fabs(q[1]) + fabs(q[2]));   // >= 1 % of the point's distance from the view
-                    front = front && c2 > guard;
-                    back = back && c2 < -guard;
-                    const double a[4] = {c0 + one * c2, Wm * c2 - c0, c1_ + one * c2, Hm * c2 - c1_};
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) { allneg[h] = allneg[h] && a[h] <= 0.0; allpos[h] = allpos[h] && a[h] >= 0.0; }
-                }
-                const bool miss_front = allneg[0] || allneg[1] || allneg[2] || allneg[3];
-                const bool miss_back = allpos[0] || allpos[1] || allpos[2] || allpos[3];
-                // c2 is the camera-frame depth only for a pinhole K (third row (0, 0, 1)): other views are never culled
-                const bool pin = cm[18] == 0.f && cm[19] == 0.f && cm[20] == 1.f;
-                const bool cull = empty || (pin && ((front && miss_front) || (back && miss_back)));
-                cnt[(size_t)tile * n_views + base + v] = cull ? kCulled : (uint16_t)0;
-            }
-        }
-    }
-}
-
 // One 16x16 tile x up to 16 views per workgroup; wave w takes the views k = w (mod 4) of the group, four pixels per
-// lane.  By-product: which views observe each pixel, as bit k of the pixel's mask in `pmask` (the compaction's input; it
-// used to re-read every dense range for it).  (A phased form -- the four forward projections, then the four depth
-// gathers together, then the backward projections, then the colour gathers -- was tried for the memory-level parallelism:
-// 112 VGPRs, 4 waves/SIMD instead of 7, 917 us against 812: the kernel is VALU-bound, occupancy hides its gathers.)
+// lane.  By-product: which pixels of the tile view k observes, as the four ballots of the lanes' pixels (`vbits`, 32 bytes
+// per (tile, view)): the compaction derives every pixel's view mask from them instead of re-reading every dense range.
+//
+// What did NOT pay here, each measured against the round-2 kernel on the same box (tools/exp/ab_match.sh; 1080p x 65
+// views, 837-870 us): (a) a tile-level cull before matching -- a pre-pass projecting the 8 corners of every tile's
+// frustum slab into every view and skipping the pairs that provably miss (34 % of all pairs, against 35 % that have no
+// match): +-0 on this kernel plus 22 us for the pre-pass, because a missing pair already costs only its forward
+// projection and the kernel's time is in the pairs that match; (b) the pinhole form of K and K^-1 (zeros dropped from
+// the FMA chains, exact for every finite input; -9 % VALU instructions): +1 %; (c) the four pixels of a lane in phases
+// (forward projections, the four depth gathers together, backward projections, colour gathers together) for
+// memory-level parallelism: 112 VGPRs, 4 waves/SIMD instead of 7, +5 %; (d) global_load instead of flat_load gathers:
+// +-0 (kept: it is what the pointers are); (e) per-pixel view masks combined in the kernel -- the four waves' bits
+// through LDS behind a barrier: +6 % (the fast waves wait); one wave per 16 views, no barrier: +11 % (32 K long waves
+// quantise badly over the SIMDs).  The kernel sits at ~70 % VALU occupancy on its dependent gather -> IEEE-division
+// chains, and bit parity with torch fixes those chains.
 //
 // kExt: extension planes are written (`ext`: the camera points, or float32 colours with SUCRE_EXT_COLOUR).
 // kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
@@ -215,21 +106,17 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
                                                     size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext,
                                                     int ext_mode, uint8_t *__restrict__ ext2,
-                                                    uint64_t *__restrict__ pmask, int mask_words) {
-    __shared__ uint32_t lmask[kTilePx];
+                                                    uint64_t *__restrict__ vbits) {
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    lmask[threadIdx.x] = 0u;
-    __syncthreads();
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int v1 = ty * kTile + (lane >> 2);
     const int u1b = tx * kTile + (lane & 3) * 4;
     const float W1f = (float)c1.W, H1f = (float)c1.H;
-    const bool pin1 = pinhole_form(c1.K), pin1inv = pinhole_form(c1.Kinv);
 
     float wP[4][3];
     bool ok1[4];
@@ -240,25 +127,16 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         if (v1 < c1.H && u1 < c1.W) d = depth1[(size_t)v1 * c1.W + u1];
         ok1[j] = d > 0.0f;
         float cP[3];
-        unproject(c1.Kinv, pin1inv, (float)u1, (float)v1, d, cP);
+        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
         rigid(c1.R, c1.t, cP, wP[j]);
     }
 
-    // groups are aligned to absolute multiples of 16 views, so a group's bits are one uint16 of every pixel's mask
-    const int kb = (k0 & ~(kViewsPerGroup - 1)) + blockIdx.y * kViewsPerGroup;
-    const int ks = max(kb, k0), ke = min(kb + kViewsPerGroup, k1);
-    uint64_t bits = 0ull;   // pixel j's bit of view k at 16 j + (k - kb)
+    const int kb = k0 + blockIdx.y * kViewsPerGroup;
+    const int ke = min(kb + kViewsPerGroup, k1);
     for (int k = kb + wave; k < ke; k += 4) {
-        if (k < ks) continue;
-        uint16_t *cntp = cnt + (size_t)tile * n_views + k;
-        if (__builtin_amdgcn_readfirstlane((int)*cntp) == (int)kCulled) {   // tile_cull_kernel: nothing of this tile lands in view k
-            if (lane == 0) *cntp = 0;
-            continue;
-        }
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
         const uint8_t *__restrict__ rgb2 = vw->rgb;
         const float W2f = (float)vw->W, H2f = (float)vw->H;
-        const PinFlags pf = {pin1, pin1inv, pinhole_form(vw->K), pinhole_form(vw->Kinv)};
         float zo[4], cx[kExt ? 4 : 1], cy[kExt ? 4 : 1], cz[kExt ? 4 : 1];
         float fr[kBoth ? 4 : 1], fg[kBoth ? 4 : 1], fb[kBoth ? 4 : 1];
         uint32_t r4 = 0, g4 = 0, b4 = 0;
@@ -272,17 +150,17 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             float f2[3] = {0.f, 0.f, 0.f};
             if (m) {
                 size_t q;
-                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, pf, wP[j], u1b + j, v1, &q, c2);
+                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
                     if (kBoth) {                          // float32 colour image, camera point kept as well
-                        const float *pf = reinterpret_cast<const float *>(rgb2) + q * 3;
+                        const auto *pf = global_ptr(reinterpret_cast<const float *>(rgb2)) + q * 3;
                         f2[0] = pf[0]; f2[1] = pf[1]; f2[2] = pf[2];
                     } else if (kExt && ext_mode == SUCRE_EXT_COLOUR) {  // float32 colour image (resized inputs): the planes carry I
-                        const float *pf = reinterpret_cast<const float *>(rgb2) + q * 3;
+                        const auto *pf = global_ptr(reinterpret_cast<const float *>(rgb2)) + q * 3;
                         c2[0] = pf[0]; c2[1] = pf[1]; c2[2] = pf[2];
                     } else {
-                        const uint8_t *p = rgb2 + q * 3;
+                        const auto *p = global_ptr(rgb2) + q * 3;
                         r = p[0]; g = p[1]; b = p[2];
                     }
                 }
@@ -293,17 +171,18 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             r4 |= r << (8 * j);
             g4 |= g << (8 * j);
             b4 |= b << (8 * j);
-            bits |= (uint64_t)(m ? 1u : 0u) << (16 * j + (k - kb));
-            total += __builtin_popcountll(__ballot(m));
+            const unsigned long long bal = __ballot(m);
+            total += __builtin_popcountll(bal);
+            if (lane == j) vbits[((size_t)tile * n_views + k) * 4 + j] = bal;   // word j, bit l: slot 4 l + j
         }
-        if (lane == 0) *cntp = (uint16_t)total;
+        if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
             *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
             c[0] = r4; c[64] = g4; c[128] = b4;
             if (kExt) {  // extension planes: the camera-frame point cP of every observation (light model,
-                        // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
+                         // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
                 uint8_t *e = ext + ((size_t)tile * n_views + k) * kExtChunk;
                 *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(cx[0], cx[1], cx[2], cx[3]);
                 *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(cy[0], cy[1], cy[2], cy[3]);
@@ -316,20 +195,6 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                 *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(fb[0], fb[1], fb[2], fb[3]);
             }
         }
-    }
-    // the group's 16 mask bits of every pixel: the four waves hold disjoint bits of the same words
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t mine = (uint32_t)(bits >> (16 * j)) & 0xffffu;
-        if (mine) atomicOr(&lmask[lane * 4 + j], mine);
-    }
-    __syncthreads();
-    if (ks < ke) {
-        const uint32_t covered = ((1u << (ke - kb)) - 1u) & ~((1u << (ks - kb)) - 1u);   // bits of the views [ks, ke)
-        uint16_t *mp = reinterpret_cast<uint16_t *>(pmask + ((size_t)tile * kTilePx + threadIdx.x) * mask_words) + (kb >> 4);
-        const uint32_t mine = lmask[threadIdx.x];
-        // a group only partly inside [k0, k1) keeps the bits other calls own (the bits >= n_views are never read)
-        *mp = (uint16_t)(covered == 0xffffu ? mine : ((*mp & ~covered) | mine));
     }
 }
 
@@ -347,10 +212,9 @@ __global__ __launch_bounds__(256) void match_map_kernel(const float *__restrict_
         const sucre_view_t *vw = views + k;
         float cP[3], wP[3], c2[3];
         size_t q;
-        const PinFlags pf = {pinhole_form(c1.K), pinhole_form(c1.Kinv), pinhole_form(vw->K), pinhole_form(vw->Kinv)};
-        unproject(c1.Kinv, pf.Kinv1, (float)u1, (float)v1, d, cP);
+        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
         rigid(c1.R, c1.t, cP, wP);
-        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, (float)vw->W, (float)vw->H, pf, wP, u1, v1, &q, c2))
+        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, (float)vw->W, (float)vw->H, wP, u1, v1, &q, c2))
             out = (int32_t)q;
     }
     map[idx] = out;
@@ -364,7 +228,7 @@ __global__ __launch_bounds__(256) void project_points_kernel(const CamDev cam, c
     if (i >= n) return;
     const float p[3] = {wP[i], wP[n + i], wP[2 * n + i]};
     float px, py;
-    const bool inside = project(cam.Rinv, cam.tinv, cam.K, pinhole_form(cam.K), (float)cam.W, (float)cam.H, p, &px, &py);
+    const bool inside = project(cam.Rinv, cam.tinv, cam.K, (float)cam.W, (float)cam.H, p, &px, &py);
     pix[i] = inside ? (int32_t)py * cam.W + (int32_t)px : -1;
 }
 
@@ -527,21 +391,25 @@ __global__ __launch_bounds__(256) void export_view_ext_kernel(const uint8_t *__r
     for (int pl = 0; pl < 3; ++pl) out[((size_t)pl * H + v) * W + u] = val[pl];
 }
 
-// After an import: the tile's match count of view k and bit k of every pixel's view mask (what match_kernel leaves
-// behind for the views it fills).
+// After an import: the tile's match count of view k and the view's pixel bits (what match_kernel leaves behind for the
+// views it fills): thread t holds slot t = 4 l + j, so word j collects bit l from the threads 4 l + j.
 __global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                          int n_views, int k, size_t tile_stride, size_t view_stride,
-                                                         uint64_t *__restrict__ pmask, int mask_words) {
-    __shared__ int part[4];
-    const int tile = blockIdx.x;
-    const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[threadIdx.x];
-    uint64_t *w = pmask + ((size_t)tile * kTilePx + threadIdx.x) * mask_words + (k >> 6);
-    const uint64_t bit = 1ull << (k & 63);
-    *w = z > 0.0f ? (*w | bit) : (*w & ~bit);
-    const int c = __builtin_popcountll(__ballot(z > 0.0f));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+                                                         uint64_t *__restrict__ vbits) {
+    __shared__ uint32_t word[4][2];
+    const int tile = blockIdx.x, t = threadIdx.x;
+    if (t < 8) word[t >> 1][t & 1] = 0u;
     __syncthreads();
-    if (threadIdx.x == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
+    const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[t];
+    const int l = t >> 2, j = t & 3;
+    if (z > 0.0f) atomicOr(&word[j][l >> 5], 1u << (l & 31));
+    __syncthreads();
+    if (t < 4) vbits[((size_t)tile * n_views + k) * 4 + t] = ((uint64_t)word[t][1] << 32) | word[t][0];
+    if (t == 0) {
+        int c = 0;
+        for (int i = 0; i < 4; ++i) c += __builtin_popcount(word[i][0]) + __builtin_popcount(word[i][1]);
+        cnt[(size_t)tile * n_views + k] = (uint16_t)c;
+    }
 }
 
 hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s) {
@@ -561,7 +429,7 @@ hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t
         hipLaunchKernelGGL(import_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws + L.off_obs, k,
                            L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n, ext_dense, L.n_views, ext, ext2_dense);
     hipLaunchKernelGGL(count_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
-                       L.obs_tile_stride, L.obs_view_stride, reinterpret_cast<uint64_t *>(ws + L.off_pmask), L.mask_words);
+                       L.obs_tile_stride, L.obs_view_stride, reinterpret_cast<uint64_t *>(ws + L.off_vbits));
     return hipGetLastError();
 }
 
@@ -579,34 +447,15 @@ hipError_t launch_project_points(const sucre_view_t &view, const float *wP, long
     return hipGetLastError();
 }
 
-// The tile-level cull needs pinhole cameras (third row of K and of its inverse = (0, 0, 1): the hull argument of
-// tile_cull_kernel); anything else is matched without it.
-static bool pinhole(const sucre_view_t &v) {
-    return v.K[6] == 0.f && v.K[7] == 0.f && v.K[8] == 1.f && v.Kinv[6] == 0.f && v.Kinv[7] == 0.f && v.Kinv[8] == 1.f;
-}   // (weaker than pinhole_form: the hull argument only needs the third rows)
-
-__global__ __launch_bounds__(256) void clear_cnt_kernel(uint16_t *__restrict__ cnt, int n_views, int k0, int k1, int n_tiles) {
-    const int i = blockIdx.x * 256 + threadIdx.x, w = k1 - k0;
-    if (i < n_tiles * w) cnt[(size_t)(i / w) * n_views + k0 + i % w] = 0;
-}
-
 hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target, const sucre_view_t *views_dev,
                         int k0, int k1, hipStream_t s, uint8_t *ext, int ext_mode, uint8_t *ext2) {
     const int tiles_per_xcd = (L.n_tiles + 7) / 8;
-    const int g0 = k0 / kViewsPerGroup, g1 = (k1 + kViewsPerGroup - 1) / kViewsPerGroup;   // groups aligned to multiples of 16 views
-    const dim3 grid(8 * tiles_per_xcd, g1 - g0);
+    const dim3 grid(8 * tiles_per_xcd, (k1 - k0 + kViewsPerGroup - 1) / kViewsPerGroup);
     auto *cnt = reinterpret_cast<uint16_t *>(ws + L.off_cnt);
-    auto *pmask = reinterpret_cast<uint64_t *>(ws + L.off_pmask);
-    if (pinhole(target))   // (the views' own K only enters through c = K cP, which needs no such form)
-        hipLaunchKernelGGL(tile_cull_kernel, dim3((L.n_tiles + kCullTilesPerBlock - 1) / kCullTilesPerBlock), dim3(256), 0, s, cnt,
-                           target.depth, to_cam(target), views_dev, L.n_views, k0, k1, L.tiles_x, L.n_tiles);
-    else
-        hipLaunchKernelGGL(clear_cnt_kernel, dim3((unsigned)(((size_t)L.n_tiles * (k1 - k0) + 255) / 256)), dim3(256), 0, s, cnt,
-                           L.n_views, k0, k1, L.n_tiles);
+    auto *vbits = reinterpret_cast<uint64_t *>(ws + L.off_vbits);
     auto launch = [&](auto kernel, int mode) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, ws + L.off_obs, cnt, target.depth, to_cam(target), views_dev, L.n_views, k0,
-                           k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, mode, ext2, pmask,
-                           L.mask_words);
+                           k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, mode, ext2, vbits);
     };
     if (ext2) launch(match_kernel<true, true>, SUCRE_EXT_POINTS_COLOUR);
     else if (ext) launch(match_kernel<false, true>, ext_mode);
