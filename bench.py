@@ -333,7 +333,8 @@ def main():
         union += hi - lo
         timed_region_iter_ms = union / (n_fits * T)
     else:
-        timed_region_iter_ms = sum(a.elapsed_time(b) for a, b in fit_events) / n_fits / T / (len(jobs) if group_restos is not None else 1)
+        # (a shared-water group: one launch per iteration walks every image of the rank -- the launch is the unit)
+        timed_region_iter_ms = sum(a.elapsed_time(b) for a, b in fit_events) / n_fits / T
 
     # Roofline pass: the dominant kernel by itself.  `--solo-images` more restorations of the same image, strictly one
     # at a time on slot 0 (nothing else on the GPU), HIP events on the stream the kernels are launched on: one pair
@@ -366,22 +367,32 @@ def main():
     obs_passes = 2 if (args.use_closed_form and args.light_model) else 1  # light + closed form: J pass, then gradient pass
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
     obs_bytes = 5 if args.obs_format == 'u16mm' else OBS_BYTES   # c = 5 B/obs for config 5
-    algo_bytes = (obs_bytes + (12 if args.light_model else 0)) * n_obs + state_bytes  # A_fit / T
+    launch_obs = sum(r.n_obs() for r in group_restos) if group_restos is not None else n_obs   # observations one launch streams
+    launch_images = len(group_restos) if group_restos is not None else 1
+    algo_bytes = (obs_bytes + (12 if args.light_model else 0)) * launch_obs + state_bytes * launch_images  # A_fit / T
     achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
     counts = resto.view_counts().cpu().numpy()
     cover = counts / float(W * H)
     # A_match = 4 HW + sum_k (4 H_k W_k + 3 n_k + c n_k)   (every view here has the target's size)
     match_bytes = 4 * H * W + int(sum(4 * H * W + (3 + OBS_BYTES) * int(n) for n in counts))
 
-    # committed rocprofv3 evidence for the same workload (profiles/rNN_traffic.json, newest round first)
+    # committed rocprofv3 evidence for the same mode and workload (profiles/rNN_<mode>_traffic.json from tools/profile.sh,
+    # newest round first; the mode names are tools/profile.sh's)
+    if args.shared_water and args.batch_images > 1:
+        tag = f'shared{args.batch_images}'
+    else:
+        tag = ('light_closed' if args.use_closed_form else 'light') if args.light_model else ('closed' if args.use_closed_form else 'jparam')
+        if args.obs_format == 'u16mm':
+            tag = 'u16mm_4k' if (tag, W, H) == ('jparam', 3840, 2160) else tag + '_u16mm'
     traffic = prof = None
-    if (not args.use_closed_form and not args.light_model and args.obs_format == 'f32'
-            and (W, H, n_views, T) == (1920, 1080, 65, 200)):
-        for tf in sorted((ROOT / 'profiles').glob('r*_traffic.json'), reverse=True):
-            rec = json.loads(tf.read_text())
-            if rec.get('n_obs') == n_obs:   # same workload as the profiled one
-                traffic, prof = rec['hbm_bytes_per_launch'], (tf.name, rec)
-                break
+    candidates = sorted((ROOT / 'profiles').glob(f'r*_{tag}_traffic.json'), reverse=True)
+    if tag == 'jparam':
+        candidates += sorted((ROOT / 'profiles').glob('r[0-9][0-9]_traffic.json'), reverse=True)   # rounds 1-2: one mode, no tag
+    for tf in candidates:
+        rec = json.loads(tf.read_text())
+        if rec.get('n_obs') == n_obs and 'hbm_bytes_per_launch' in rec:   # same workload as the profiled one
+            traffic, prof = rec['hbm_bytes_per_launch'], (tf.name, rec)
+            break
 
     if world > 1:
         seen = torch.ones(1, dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else 'cpu')
@@ -393,7 +404,8 @@ def main():
         ranks_seen, names = 1, [f'rank 0: {torch.cuda.get_device_name(device)} (cuda:{device.index})']
 
     if rank == 0:
-        kernel = 'light_grad_kernel' if args.light_model else ('fit_closed_kernel' if args.use_closed_form else 'fit_grad_kernel')
+        kernel = ('group_iter_kernel' if group_restos is not None else 'light_grad_kernel' if args.light_model
+                  else 'fit_closed_kernel' if args.use_closed_form else 'fit_grad_kernel')
         roof = {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'frac_of_achievable': achieved / HBM_ACHIEVABLE_GBS, 'achievable_peak': HBM_ACHIEVABLE_GBS,
@@ -437,7 +449,10 @@ def main():
             out['roofline_match'] = {'bound': 'hbm', 'kernel': 'match_kernel + finalize (view_count, compaction: pixel_count .. scatter_kernel)',
                                      'achieved': match_bytes / (match_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                      'frac': match_bytes / (match_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     'algorithmic_bytes': match_bytes, 'ms': match_ms, 'traffic': None,
+                                     'algorithmic_bytes': match_bytes, 'ms': match_ms,
+                                     'traffic': prof[1].get('match_stage_hbm_bytes') if prof is not None else None,
+                                     'traffic_source': (f'profiles/{prof[0]}: sum over the stage\'s kernels of 2 x FETCH_SIZE + WRITE_SIZE'
+                                                        if prof is not None and 'match_stage_hbm_bytes' in prof[1] else None),
                                      'measured': 'HIP events around sucre_match_views + sucre_finalize_matches of the same solo images'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(scene, n_obs, n_views, T, args.cpu_views, args.cpu_iters)

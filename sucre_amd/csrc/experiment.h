@@ -1,0 +1,35 @@
+// Build-time knobs of the experiments recorded in DESIGN.md section 4.2 (tools/exp/*.sh build them as
+//   make VARIANT=<name> EXTRA="-D..."  ->  sucre_amd/libsucre_hip_<name>.so,   selected at run time with SUCRE_HIP_LIB).
+// The product build defines none of them; tests/test_host_logic.py compiles every one so that they cannot rot.
+// They are variants of ONE code path (same kernels, same ABI), never alternative back ends.
+#pragma once
+
+// Ablations of the fit kernels: the arithmetic of a chunk compiled out (the data are still touched), the LDS-DMA copies
+// compiled out (the ring keeps whatever LDS holds).  Results are meaningless; only the launch time is read.
+#ifdef SUCRE_EXP_NOCOMPUTE
+constexpr bool kExpNoCompute = true;
+#else
+constexpr bool kExpNoCompute = false;
+#endif
+#ifdef SUCRE_EXP_NOLOAD
+constexpr bool kExpNoLoad = true;
+#else
+constexpr bool kExpNoLoad = false;
+#endif
+
+// Waves per SIMD the fit kernels are compiled for (= workgroups per CU of their persistent grids).
+#ifndef SUCRE_FIT_WAVES
+#define SUCRE_FIT_WAVES 5
+#endif
+#ifndef SUCRE_CLOSED_WAVES
+#define SUCRE_CLOSED_WAVES 4
+#endif
+
+// Slots of a wave's LDS-DMA ring (prefetch depth + 1) and the cache policy of its copies (" nt": items are read once per
+// launch -- measured 20 % faster than the default policy; next to it " sc0", " sc1", " sc0 sc1": equal).
+#ifndef SUCRE_RING
+#define SUCRE_RING 3
+#endif
+#ifndef SUCRE_DMA_POLICY
+#define SUCRE_DMA_POLICY " nt"
+#endif

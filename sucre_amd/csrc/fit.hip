@@ -24,7 +24,9 @@
 //   dL/dbeta  = +2 s sum_p J sum_k r a z    dL/dgamma = -2 s B sum r g z        (per channel)
 #include <cstddef>
 
+#include "experiment.h"
 #include "fit_math.h"
+#include "handoff.h"
 
 namespace sucre {
 
@@ -81,10 +83,10 @@ __device__ __forceinline__ void chunk_exps(const float (&zz)[kGroupLv], const Wa
 template <bool kMasked>
 __device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], const uint32_t (&cc)[3], const Water &w,
                                                  const float (&J)[3], Acc &acc) {
-#ifdef SUCRE_EXP_NOCOMPUTE  // experiment build only: touch the data, skip the model
-    acc.cost += (zz[0] + zz[1]) + (zz[2] + zz[3]) + (float)(cc[0] ^ cc[1] ^ cc[2]);
-    return;
-#endif
+    if (kExpNoCompute) {  // ablation build only (experiment.h): touch the data, skip the model
+        acc.cost += (zz[0] + zz[1]) + (zz[2] + zz[3]) + (float)(cc[0] ^ cc[1] ^ cc[2]);
+        return;
+    }
     Exps e;
     chunk_exps(zz, w, e);
 #pragma unroll
@@ -204,9 +206,6 @@ __device__ __forceinline__ void accumulate_level(float z, const uint32_t (&k)[3]
 // order; cdna_hip_programming.md 5.7).  What may still be outstanding when item q is needed: the items issued after
 // it (two instructions each) and, if they were issued after it, the stores of the previous strip's end.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef SUCRE_RING
-#define SUCRE_RING 3
-#endif
 // waves per SIMD the fit kernels are compiled for (register budget 512 / waves) = workgroups per CU of their
 // persistent grids: kFitWaves / kClosedWaves (layout.h)
 constexpr int kRing = SUCRE_RING;
@@ -224,18 +223,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a flat LDS address = LDS offset
 }
 
-#ifndef SUCRE_DMA_POLICY
-#define SUCRE_DMA_POLICY " nt"  // items are read once per launch: streaming policy (measured -20 % vs default)
-#endif
 
 __device__ __forceinline__ uint64_t lane_mask(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 
 // src (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address).  EXEC is all ones on entry (whole
 // waves run this code) and is restored inside the statement; M0 is written in the statement that reads it.
 __device__ __forceinline__ void dma_item(const uint8_t *src, uint32_t slot, uint32_t lane, uint32_t nA, uint32_t nB) {
-#ifdef SUCRE_EXP_NOLOAD  // experiment build only: the ring keeps whatever LDS holds
-    return;
-#endif
+    if (kExpNoLoad) return;  // ablation build only (experiment.h): the ring keeps whatever LDS holds
     unsigned keep;
     const uint32_t voffA = lane * 16u, voffB = voffA + nA * 16u;
     const uint32_t slotB = slot + nA * 16u;
@@ -507,30 +501,6 @@ __device__ __forceinline__ void reduce_total(const double *gpart, int n_groups, 
     __syncthreads();
 }
 
-// Arrival on a counter: EVERY wave of the workgroup drains its own hand-off stores (vmcnt is per wave; reduce_group's
-// results are stored by all four waves), the workgroup meets, and only then one lane signals with a relaxed
-// agent-scope fetch_add.  Returns true in the workgroup that arrived last, which has then done its agent acquire and
-// re-armed the counter.  (Until round 2 only the signalling wave drained: the other waves' group sums could still be
-// in flight when the top-level last arriver read them -- seen as run-to-run differences of the beta gradient, the
-// last values each wave stores, once two processes shared the GPU.)
-__device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned expected, int *flag) {
-    const int t = threadIdx.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-        const unsigned got = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (got == expected - 1u) ? 1 : 0;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-
 // torch.optim.Adam step on B, beta, gamma (sucre.py:148) from the reduced sums, by lanes 0..8 of one wave;
 // logs cost + parameters (sucre.py:149-152) into one trace row.  All lanes of the wave must call it.
 __device__ __forceinline__ void water_step(const double *__restrict__ sums, float *__restrict__ pstate,
@@ -648,15 +618,9 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
                 sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
                 adam_update(Jc, m, v, gscale * acc.pa[c], co);
-#ifdef SUCRE_STATE_SC1
-                __hip_atomic_store(st + c * kStripPx + lane, Jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(st + (3 + c) * kStripPx + lane, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(st + (6 + c) * kStripPx + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
                 st[c * kStripPx + lane] = Jc;
                 st[(3 + c) * kStripPx + lane] = m;
                 st[(6 + c) * kStripPx + lane] = v;
-#endif
             }
         });
 }
@@ -681,9 +645,6 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
-#ifdef SUCRE_EXP_CLOCK  // experiment build only: shader clock held during the launch (MI355X_MICROARCH.md, DVFS item 6)
-    const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     // a store compacted in the other format is not read at all; the logged cost turns NaN instead
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
@@ -697,16 +658,6 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     float sBeta[3] = {0.f, 0.f, 0.f};
     grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, n_items, ws, state, wave, lane, w, gscale, co, acc, sBeta);
 
-#ifdef SUCRE_EXP_CLOCK
-    if (t == 0 && blockIdx.x == 7) {   // stamps go to the two padding slots of `sums`, which nothing reads
-        sums[10] = (double)(__builtin_amdgcn_s_memtime() - clk0);
-        sums[11] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);
-    }
-    if (lane == 0 && trace_row) {      // every wave's life, behind the row (the experiment passes a larger buffer)
-        trace_row[16 + 2 * (blockIdx.x * 4 + wave)] = (double)rt0;
-        trace_row[17 + 2 * (blockIdx.x * 4 + wave)] = (double)__builtin_amdgcn_s_memrealtime();
-    }
-#endif
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
                          sBeta[0], sBeta[1], sBeta[2], acc.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);

@@ -3,6 +3,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "experiment.h"
+
 namespace sucre {
 
 constexpr int kTile = 16;            // tile edge in pixels
@@ -38,13 +40,8 @@ constexpr int kNumSums = 10;         // sB[3], sGZ[3], sBeta[3], cost
 constexpr int kSumsPad = 12;
 constexpr int kGroup = 32;           // tiles per reduction group (two-level last-arriver reduction)
 constexpr int kTicketStride = 16;    // uint32 words between tickets: every counter on its own 64-byte line
-#ifndef SUCRE_FIT_WAVES
-#define SUCRE_FIT_WAVES 5   // 82-94 VGPRs: at 6 waves (80) the kernels spill, and scratch traffic both counts in the
-                            // hand-counted vmcnt waits and made results depend on what else ran on the GPU (round 2)
-#endif
-#ifndef SUCRE_CLOSED_WAVES
-#define SUCRE_CLOSED_WAVES 4
-#endif
+// (SUCRE_FIT_WAVES / SUCRE_CLOSED_WAVES: experiment.h.  5: 82-94 VGPRs -- at 6 waves (80) the kernels spill, and scratch
+// traffic both counts in the hand-counted vmcnt waits and made results depend on what else ran on the GPU, round 2)
 constexpr int kFitWaves = SUCRE_FIT_WAVES;        // waves per SIMD of fit_grad_kernel / group_iter_kernel (<= 96 VGPRs)
 constexpr int kClosedWaves = SUCRE_CLOSED_WAVES;  // ... of fit_closed_kernel (27 accumulators per lane: 118 VGPRs)
 constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (kFitWaves per CU x 256 CUs: all resident
@@ -108,11 +105,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     L->off_obs = take(nt * nv * kChunk);
-#ifdef SUCRE_OBS_VIEW_MAJOR
-    L->obs_tile_stride = kChunk; L->obs_view_stride = nt * kChunk;      // [view][tile]
-#else
     L->obs_tile_stride = nv * kChunk; L->obs_view_stride = kChunk;      // [tile][view]
-#endif
     L->off_cnt = take(nt * nv * sizeof(uint16_t));
     L->off_comp = take(nt * nv * kChunk);
     L->off_pcount = take(nt * kTilePx * sizeof(uint16_t));

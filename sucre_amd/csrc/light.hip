@@ -10,10 +10,10 @@
 // plus the 19 parameters (B, beta, gamma, cam2light[6], sigma[4]), their Adam moments, and the reduction buffers.
 // Everything of the default path (J planes, compact store, perm, levels) is reused from the main workspace.
 //
-// One iteration = light_grad_kernel (persistent waves on strips like fit_grad_kernel; 26 sums) -> light_reduce_kernel
-// (fixed-order float64) -> light_step_kernel (chain rule through Sigma^-1 and through the matrix exponential --
-// six 8x8 block exponentials evaluated in parallel in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1).
-// This mode is built for correctness first: plain loads instead of the LDS-DMA ring.
+// One iteration = light_grad_kernel (persistent waves on strips like fit_grad_kernel; 26 sums) -> light_tail_kernel (one
+// workgroup: fixed-order float64 reduction, chain rule through Sigma^-1 and through the matrix exponential -- six 8x8
+// block exponentials evaluated in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1, log row).
+// Plain loads instead of the LDS-DMA ring: the kernel is VALU-bound (~150 instructions per observation).
 #include "fit_math.h"
 
 namespace sucre {
@@ -51,11 +51,12 @@ static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1)
     return true;
 }
 
-// ---- small dense linear algebra in LDS: nmat independent 8x8 float64 products, one thread per output element ------
+// ---- small dense linear algebra in LDS: nmat independent 8x8 float64 products, one thread per output element (a
+//      workgroup of 64 w threads takes w matrices at a time) --------------------------------------------------------------
 __device__ __forceinline__ void block_mul(const double (*A)[64], const double (*B)[64], double (*C)[64], int nmat,
                                           double post_scale) {
-    const int m = threadIdx.x >> 6, e = threadIdx.x & 63, r = e >> 3, c = e & 7;
-    if (m < nmat) {
+    const int e = threadIdx.x & 63, r = e >> 3, c = e & 7;
+    for (int m = threadIdx.x >> 6; m < nmat; m += blockDim.x >> 6) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += A[m][r * 8 + k] * B[m][k * 8 + c];
@@ -64,10 +65,10 @@ __device__ __forceinline__ void block_mul(const double (*A)[64], const double (*
     __syncthreads();
 }
 
-// E[m] = exp(S0[m]) for nmat 8x8 matrices: scaling by 2^-6, degree-12 Taylor, six squarings.  512 threads.
+// E[m] = exp(S0[m]) for nmat 8x8 matrices: scaling by 2^-6, degree-12 Taylor, six squarings.
 __device__ __forceinline__ void block_exp(double (*S)[64], double (*T)[64], double (*E)[64], double (*P)[64], int nmat) {
-    const int m = threadIdx.x >> 6, e = threadIdx.x & 63;
-    if (m < nmat) {
+    const int e = threadIdx.x & 63, m0 = threadIdx.x >> 6, dm = blockDim.x >> 6;
+    for (int m = m0; m < nmat; m += dm) {
         S[m][e] *= 1.0 / 64.0;
         const double id = (e % 9 == 0) ? 1.0 : 0.0;
         T[m][e] = id;
@@ -76,12 +77,12 @@ __device__ __forceinline__ void block_exp(double (*S)[64], double (*T)[64], doub
     __syncthreads();
     for (int k = 1; k <= 12; ++k) {
         block_mul(T, S, P, nmat, 1.0 / k);
-        if (m < nmat) { T[m][e] = P[m][e]; E[m][e] += P[m][e]; }
+        for (int m = m0; m < nmat; m += dm) { T[m][e] = P[m][e]; E[m][e] += P[m][e]; }
         __syncthreads();
     }
     for (int q = 0; q < 6; ++q) {
         block_mul(E, E, P, nmat, 1.0);
-        if (m < nmat) E[m][e] = P[m][e];
+        for (int m = m0; m < nmat; m += dm) E[m][e] = P[m][e];
         __syncthreads();
     }
 }
@@ -217,6 +218,99 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
         }
     }
     return c;
+}
+
+// The 26 sums over the workgroups' partials, float64, fixed order (thread t adds the workgroups t, t + 256, ..., then a
+// fixed-shape shuffle tree, then the four waves in order); all loads are issued before any is waited for.  256 threads.
+__device__ __forceinline__ void light_reduce(const float *partials, int n_blocks, double *sums, double (*w4)[4]) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double x[kLightSums];
+#pragma unroll
+    for (int q = 0; q < kLightSums; ++q) x[q] = 0.0;
+    for (int b = t; b < n_blocks; b += 256) {
+#pragma unroll
+        for (int q = 0; q < kLightSums; ++q)
+            x[q] += (double)partials[(size_t)q * n_blocks + b];
+    }
+#pragma unroll
+    for (int q = 0; q < kLightSums; ++q) {
+        double y = x[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) y += __shfl_down(y, off, 64);
+        if (lane == 0) w4[q][wave] = y;
+    }
+    __syncthreads();
+    if (t < kLightSums) sums[t] = ((w4[t][0] + w4[t][1]) + w4[t][2]) + w4[t][3];
+    __syncthreads();
+}
+
+// Gradients of the 19 parameters from the sums (LDS), Adam, next geometry, log row.  Any multiple of 64 threads >= 64.
+struct LightLds {
+    double S[6][64], T[6][64], E[6][64], P[6][64];
+    double grad[kLightParams];
+    double sums[kLightSums];
+    double w4[kLightSums][4];
+};
+
+__device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *geom, const uint64_t *__restrict__ n_obs_total,
+                                           const AdamCoef &co, double *__restrict__ trace_row) {
+    double (*S)[64] = lds.S, (*T)[64] = lds.T, (*E)[64] = lds.E, (*P)[64] = lds.P;
+    const double *sums = lds.sums;
+    double *grad = lds.grad;
+    const int tid = threadIdx.x;
+    const double f = -2.0 * (double)((1.0f / 3.0f) / (float)(*n_obs_total));   // dL/dIhat = f * r
+    // block matrices [[A, G_i], [0, A]]: the upper-right block of the exponential is D exp(A)[G_i]
+    for (int i = tid; i < 384; i += blockDim.x) S[i >> 6][i & 63] = 0.0;
+    __syncthreads();
+    if (tid < 6) {
+        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i) xi[i] = pstate[9 + i];
+        ei[tid] = 1.0;
+        hat_into(xi, S[tid], 0, 0);
+        hat_into(xi, S[tid], 4, 4);
+        hat_into(ei, S[tid], 0, 4);
+    }
+    __syncthreads();
+    block_exp(S, T, E, P, 6);
+    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp[G_i]>
+        double s = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * E[tid][r * 8 + 4 + c];
+            s += sums[19 + r] * E[tid][r * 8 + 7];
+        }
+        grad[9 + tid] = f * s;
+    }
+    if (tid == 6) {  // water parameters (same combinations as water_step of the default path)
+        for (int c = 0; c < 3; ++c) {
+            grad[c] = f * sums[c];
+            grad[3 + c] = -f * sums[6 + c];
+            grad[6 + c] = f * (double)pstate[c] * sums[3 + c];
+        }
+    }
+    if (tid == 7) {  // sigma: M = Sigma^-1, Sigma = sigma^T sigma;  dSigma = -M^T dM M^T;  dsigma = sigma (dSigma + dSigma^T)
+        const double M[4] = {geom[12], geom[13], geom[14], geom[15]};
+        const double dM[4] = {f * sums[22], f * sums[23], f * sums[23], f * sums[25]};  // lane 24 is not accumulated (symmetry)
+        const double Mt[4] = {M[0], M[2], M[1], M[3]};
+        double T1[4], dS[4];
+        T1[0] = Mt[0] * dM[0] + Mt[1] * dM[2]; T1[1] = Mt[0] * dM[1] + Mt[1] * dM[3];
+        T1[2] = Mt[2] * dM[0] + Mt[3] * dM[2]; T1[3] = Mt[2] * dM[1] + Mt[3] * dM[3];
+        dS[0] = -(T1[0] * Mt[0] + T1[1] * Mt[2]); dS[1] = -(T1[0] * Mt[1] + T1[1] * Mt[3]);
+        dS[2] = -(T1[2] * Mt[0] + T1[3] * Mt[2]); dS[3] = -(T1[2] * Mt[1] + T1[3] * Mt[3]);
+        const double sym[4] = {2 * dS[0], dS[1] + dS[2], dS[1] + dS[2], 2 * dS[3]};
+        const double sg[4] = {pstate[15], pstate[16], pstate[17], pstate[18]};
+        grad[15] = sg[0] * sym[0] + sg[1] * sym[2]; grad[16] = sg[0] * sym[1] + sg[1] * sym[3];
+        grad[17] = sg[2] * sym[0] + sg[3] * sym[2]; grad[18] = sg[2] * sym[1] + sg[3] * sym[3];
+    }
+    __syncthreads();
+    if (tid < kLightParams) {
+        float p = pstate[tid], m = pstate[kLightParams + tid], v = pstate[2 * kLightParams + tid];
+        adam_update(p, m, v, (float)grad[tid], co);
+        pstate[tid] = p; pstate[kLightParams + tid] = m; pstate[2 * kLightParams + tid] = v;
+        if (trace_row) trace_row[1 + tid] = (double)p;
+    }
+    if (tid == 32 && trace_row) trace_row[0] = sums[9];
+    __syncthreads();   // (workgroup scope is enough for the read-back below; an agent-scope fence here wrote the L2 back: +50 us)
+    light_geometry(pstate, geom, S, T, E, P);
 }
 
 // kClosed: J is re-solved in closed form at the top of the iteration (sucre.py:141, 66-77 with absorption = l a,
@@ -390,83 +484,18 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
     if (t < kLightSums) partials[(size_t)t * n_blocks + blockIdx.x] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
 }
 
-// sums[q] = sum over workgroups, float64, fixed order.
-__global__ __launch_bounds__(256) void light_reduce_kernel(const float *__restrict__ partials, int n_blocks,
-                                                           double *__restrict__ sums) {
-    __shared__ double w4[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int q = 0; q < kLightSums; ++q) {
-        double x = 0.0;
-        for (int b = t; b < n_blocks; b += 256) x += (double)partials[(size_t)q * n_blocks + b];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) w4[wave] = x;
-        __syncthreads();
-        if (t == 0) sums[q] = ((w4[0] + w4[1]) + w4[2]) + w4[3];
-        __syncthreads();
-    }
-}
-
-// Gradients of the 19 parameters from the sums, Adam, next geometry, log row.  512 threads.
-__global__ __launch_bounds__(512) void light_step_kernel(const double *__restrict__ sums, float *pstate, float *geom,
-                                                         const uint64_t *__restrict__ n_obs_total, const AdamCoef co,
-                                                         double *__restrict__ trace_row) {
-    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
-    __shared__ double grad[kLightParams];
-    const int tid = threadIdx.x;
-    const double f = -2.0 * (double)((1.0f / 3.0f) / (float)(*n_obs_total));   // dL/dIhat = f * r
-    // block matrices [[A, G_i], [0, A]]: the upper-right block of the exponential is D exp(A)[G_i]
-    if (tid < 384) S[tid >> 6][tid & 63] = 0.0;
-    __syncthreads();
-    if (tid < 6) {
-        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 6; ++i) xi[i] = pstate[9 + i];
-        ei[tid] = 1.0;
-        hat_into(xi, S[tid], 0, 0);
-        hat_into(xi, S[tid], 4, 4);
-        hat_into(ei, S[tid], 0, 4);
-    }
-    __syncthreads();
-    block_exp(S, T, E, P, 6);
-    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp[G_i]>
-        double s = 0.0;
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * E[tid][r * 8 + 4 + c];
-            s += sums[19 + r] * E[tid][r * 8 + 7];
-        }
-        grad[9 + tid] = f * s;
-    }
-    if (tid == 6) {  // water parameters (same combinations as water_step of the default path)
-        for (int c = 0; c < 3; ++c) {
-            grad[c] = f * sums[c];
-            grad[3 + c] = -f * sums[6 + c];
-            grad[6 + c] = f * (double)pstate[c] * sums[3 + c];
-        }
-    }
-    if (tid == 7) {  // sigma: M = Sigma^-1, Sigma = sigma^T sigma;  dSigma = -M^T dM M^T;  dsigma = sigma (dSigma + dSigma^T)
-        const double M[4] = {geom[12], geom[13], geom[14], geom[15]};
-        const double dM[4] = {f * sums[22], f * sums[23], f * sums[23], f * sums[25]};  // lane 24 is not accumulated (symmetry)
-        const double Mt[4] = {M[0], M[2], M[1], M[3]};
-        double T1[4], dS[4];
-        T1[0] = Mt[0] * dM[0] + Mt[1] * dM[2]; T1[1] = Mt[0] * dM[1] + Mt[1] * dM[3];
-        T1[2] = Mt[2] * dM[0] + Mt[3] * dM[2]; T1[3] = Mt[2] * dM[1] + Mt[3] * dM[3];
-        dS[0] = -(T1[0] * Mt[0] + T1[1] * Mt[2]); dS[1] = -(T1[0] * Mt[1] + T1[1] * Mt[3]);
-        dS[2] = -(T1[2] * Mt[0] + T1[3] * Mt[2]); dS[3] = -(T1[2] * Mt[1] + T1[3] * Mt[3]);
-        const double sym[4] = {2 * dS[0], dS[1] + dS[2], dS[1] + dS[2], 2 * dS[3]};
-        const double sg[4] = {pstate[15], pstate[16], pstate[17], pstate[18]};
-        grad[15] = sg[0] * sym[0] + sg[1] * sym[2]; grad[16] = sg[0] * sym[1] + sg[1] * sym[3];
-        grad[17] = sg[2] * sym[0] + sg[3] * sym[2]; grad[18] = sg[2] * sym[1] + sg[3] * sym[3];
-    }
-    __syncthreads();
-    if (tid < kLightParams) {
-        float p = pstate[tid], m = pstate[kLightParams + tid], v = pstate[2 * kLightParams + tid];
-        adam_update(p, m, v, (float)grad[tid], co);
-        pstate[tid] = p; pstate[kLightParams + tid] = m; pstate[2 * kLightParams + tid] = v;
-        if (trace_row) trace_row[1 + tid] = (double)p;
-    }
-    if (tid == 32 && trace_row) trace_row[0] = sums[9];
-    __syncthreads();
-    light_geometry(pstate, geom, S, T, E, P);
+// The iteration's tail, one workgroup: the 26 sums, the step on the 19 parameters, the next geometry, the log row.
+// (Folding it into the gradient launch as a last-arriver tail, like fit.hip does, was measured: -29 us per iteration with
+// J as a parameter but +9 us in closed-form mode, whose two-pass kernel came out 5 % slower with the tail's code and
+// 14 KB of LDS in it; as its own launch it costs ~20 us + one launch gap in both modes.  Round 2 had two launches here,
+// a reduction that waited for every load before issuing the next (49 us) and the step (14 us).)
+__global__ __launch_bounds__(256) void light_tail_kernel(const float *partials, int n_blocks, double *sums, float *pstate,
+                                                         float *geom, const uint64_t *__restrict__ n_obs_total,
+                                                         const AdamCoef co, double *trace_row) {
+    __shared__ LightLds lds;
+    light_reduce(partials, n_blocks, lds.sums, lds.w4);
+    if (threadIdx.x < kLightSums) sums[threadIdx.x] = lds.sums[threadIdx.x];
+    light_step(lds, pstate, geom, n_obs_total, co, trace_row);
 }
 
 struct LightParams19 { float v[kLightParams]; };
@@ -556,15 +585,12 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
                              double *trace_row, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
-    float *pstate = reinterpret_cast<float *>(lws + X.off_params);
-    float *geom = reinterpret_cast<float *>(lws + X.off_geom);
-    float *partials = reinterpret_cast<float *>(lws + X.off_partials);
-    double *sums = reinterpret_cast<double *>(lws + X.off_sums);
-    auto *nobs = reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total);
     if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, co, flags, s);
     else launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
-    hipLaunchKernelGGL(light_reduce_kernel, dim3(1), dim3(256), 0, s, partials, L.n_blocks, sums);
-    hipLaunchKernelGGL(light_step_kernel, dim3(1), dim3(512), 0, s, sums, pstate, geom, nobs, co, trace_row);
+    hipLaunchKernelGGL(light_tail_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const float *>(lws + X.off_partials), L.n_blocks,
+                       reinterpret_cast<double *>(lws + X.off_sums), reinterpret_cast<float *>(lws + X.off_params),
+                       reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total), co,
+                       trace_row);
     return hipGetLastError();
 }
 
