@@ -155,12 +155,14 @@ __device__ __forceinline__ void closed_terms(float z, float a, float g, uint32_t
                                              float &q0, float &q1, float &q2, float &q3, float &q4, float &q5,
                                              float &q6, float &q7, float &q8) {
     const float omg = 1.0f - g;
-    const float y = unit_from_u8(k) - Bc * omg;
+    // I = k/255 folded into y: one rounding instead of two and two VALU operations fewer, like the J-parameter loop (the
+    // kernel is VALU-bound: 94 % busy at 79 instructions per observation, profiles/r03_closed_summary.txt)
+    const float y = __builtin_fmaf((float)k, kInv255, -(Bc * omg));
     float p = __builtin_fmaf(-Jp, a, y);
     p = valid ? p : 0.0f;  // a padding slot contributes nothing (its Jp a is not zero)
     const float za = z * a, zg = z * g;  // a padding slot has z = 0, g = 1: it only touches D (masked below)
     q0 = __builtin_fmaf(p, a, q0);
-    q1 += valid ? a * a : 0.0f;
+    q1 = __builtin_fmaf(a, valid ? a : 0.0f, q1);   // one operation (the file is built with -ffp-contract=off)
     q2 = __builtin_fmaf(p, omg, q2);
     q3 = __builtin_fmaf(a, omg, q3);
     q4 = __builtin_fmaf(p, za, q4);

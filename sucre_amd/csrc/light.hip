@@ -145,8 +145,8 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
                                               const float (&M)[4]) {
     LightObs o;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-        o.lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], R[a * 3] * cP[0])) + tl[a];
+    for (int a = 0; a < 3; ++a)   // (every a*b+c of this kernel is an explicit FMA: the library is built with -ffp-contract=off)
+        o.lP[a] = __builtin_fmaf(R[a * 3 + 2], cP[2], __builtin_fmaf(R[a * 3 + 1], cP[1], __builtin_fmaf(R[a * 3], cP[0], tl[a])));
     // hardware reciprocal / reciprocal square root (1 ulp): this path is held to a tolerance, not to bit parity,
     // and the IEEE sequences were a quarter of the kernel's instructions
     o.iz = __builtin_amdgcn_rcpf(o.lP[2]);
@@ -156,7 +156,7 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
     o.w1 = __builtin_fmaf(M[2], o.lp0, M[3] * o.lp1);
     const float q = __builtin_fmaf(o.lp0, o.w0, o.lp1 * o.w1);
     o.l = fast_exp2(q * (-0.5f * kLog2e));
-    const float n2 = o.lP[0] * o.lP[0] + o.lP[1] * o.lP[1] + o.lP[2] * o.lP[2];
+    const float n2 = __builtin_fmaf(o.lP[2], o.lP[2], __builtin_fmaf(o.lP[1], o.lP[1], o.lP[0] * o.lP[0]));
     o.inl = __builtin_amdgcn_rsqf(n2);
     o.nl = n2 * o.inl;
     o.z = zc + o.nl;
@@ -442,19 +442,20 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 const float kf2 = kf + kf;
                 const float dlp0 = kf2 * o.w0;
                 const float dlp1 = kf2 * o.w1;
-                const float iz = o.iz, inl = o.inl;
+                const float iz = o.iz, dzi = dz * o.inl;
                 float dlP[3];
-                dlP[0] = dz * o.lP[0] * inl + dlp0 * iz;
-                dlP[1] = dz * o.lP[1] * inl + dlp1 * iz;
-                dlP[2] = dz * o.lP[2] * inl - (dlp0 * o.lP[0] + dlp1 * o.lP[1]) * iz * iz;
+                dlP[0] = __builtin_fmaf(dzi, o.lP[0], dlp0 * iz);
+                dlP[1] = __builtin_fmaf(dzi, o.lP[1], dlp1 * iz);
+                dlP[2] = __builtin_fmaf(dzi, o.lP[2], -(__builtin_fmaf(dlp0, o.lp0, dlp1 * o.lp1) * iz));   // lP.xy iz = lp
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     acc.s[19 + a] += dlP[a];
 #pragma unroll
                     for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
                 }
-                acc.s[22] = __builtin_fmaf(kf * o.lp0, o.lp0, acc.s[22]);
-                acc.s[23] = __builtin_fmaf(kf * o.lp0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
+                const float k0 = kf * o.lp0;
+                acc.s[22] = __builtin_fmaf(k0, o.lp0, acc.s[22]);
+                acc.s[23] = __builtin_fmaf(k0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
                 acc.s[25] = __builtin_fmaf(kf * o.lp1, o.lp1, acc.s[25]);
             }
         }

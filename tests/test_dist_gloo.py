@@ -96,3 +96,40 @@ def test_shared_water_with_one_image_reduces_to_reference_fit():
     J, params, trace = oracle.fit(32, 48, samples, J0, num_iter=T)
     assert np.abs(be.pstate[:9] - params).max() < 1e-6
     assert helpers.rms_per_channel(be.images[0].J, J).max() < 1e-6
+
+
+def test_bench_launcher_reports_a_failed_rank_and_stops_the_others(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts its own ranks; a rank that fails (here: no GPU in this
+    container, so every rank stops at its 'needs a GPU' assertion after the gloo rendezvous) must make the launcher exit
+    non-zero promptly -- also when the failure is a signal (negative return code) -- instead of reporting the best rank's
+    code or waiting in a collective."""
+    import os
+    import subprocess
+    import sys
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('needs a machine without a GPU (on a GPU box tests/test_gpu_dist.py runs the launcher for real)')
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--timeout-s', '120'],
+                         env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 1 and time.time() - t0 < 100
+    assert 'stopping the other ranks' in out.stderr and 'needs a GPU' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]     # no JSON line from a failed job
+    # per-rank progress lines on stderr name the stage a rank is in
+    assert 'bench.py rank 0: rendezvous' in out.stderr and 'bench.py rank 1: rendezvous' in out.stderr
+
+
+def test_bench_watchdog_names_the_stage_and_exits(tmp_path):
+    """Every rank gives itself --timeout-s: a stuck rank says where it is and exits with code 3 (no re-exec)."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    code = ('import sys, time; sys.argv = ["bench.py"]; sys.path.insert(0, %r); import bench; '
+            'bench.STAGE[0] = "barrier before the timed region"; bench.watchdog(5, 0.5); time.sleep(30)') % str(root)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3
+    assert "rank 5: no result after 0 s, stuck in stage 'barrier before the timed region'" in out.stderr

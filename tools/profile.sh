@@ -31,6 +31,9 @@ for MODE in $MODES; do
     STEPS="--steps 2 --warmup 1"; [ $MODE = u16mm_4k ] && STEPS="--steps 1 --warmup 1 --solo-images 1"
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $STEPS --no-cpu-baseline --images-in-flight 1 $M > $OUT/bench_trace.log 2>&1
     PMC="--steps 1 --warmup 0 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M"
+    # (shared4: with --warmup 0 bench.py's set-up pass fits ONE image through the group kernel; --warmup 1 skips it, so that
+    # every group_iter_kernel dispatch in the averages walks all four images)
+    [ $MODE = shared4 ] && PMC="--steps 1 --warmup 1 --no-cpu-baseline --images-in-flight 1 --num-iter 10 $M"
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > $OUT/bench_pmc_fetch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > $OUT/bench_pmc_sq.log 2>&1
