@@ -25,6 +25,7 @@ struct LightLayout {
     size_t off_ext_dense, off_ext_comp;   // dense: float [chunk][3][256]; compact: kExtLevelBytes per level of a strip
     size_t off_params;                    // float [19] params, [19] exp_avg, [19] exp_avg_sq
     size_t off_geom;                      // float [16]: R[9], t[3], M[4] = Sigma^-1 (row-major)
+    size_t off_dexp;                      // double [6][12]: d exp(hat xi)[G_i], rows 0..2 of the 4x4 derivative (with the geometry)
     size_t off_partials;                  // float [26][n_blocks]
     size_t off_sums;                      // double [26]
     size_t off_ext2_dense, off_ext2_comp; // second set of planes (float32 colours next to camera points); only with ext_sets = 2
@@ -40,6 +41,7 @@ static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1)
     X->off_ext_comp = take(chunks * kExtChunk);
     X->off_params = take(3 * kLightParams * sizeof(float));
     X->off_geom = take(16 * sizeof(float));
+    X->off_dexp = take(72 * sizeof(double));
     X->off_partials = take((size_t)kLightSums * L.n_blocks * sizeof(float));
     X->off_sums = take(kLightSums * sizeof(double));
     X->off_ext2_dense = X->off_ext2_comp = 0;
@@ -93,24 +95,36 @@ __device__ __forceinline__ void hat_into(const double xi[6], double *A /*8x8 blo
         for (int c = 0; c < 4; ++c) A[(row0 + r) * 8 + col0 + c] = h[r * 4 + c];
 }
 
-// geom (R, t, M) from the parameters; 512 threads, uses matrix 0 of the LDS buffers.
-__device__ __forceinline__ void light_geometry(const float *params, float *geom, double (*S)[64], double (*T)[64],
+// geom (R, t, M) and the directional derivatives of the exponential from the parameters.  The six block matrices
+// [[A, G_i], [0, A]], A = hat(cam2light), G_i = the i-th generator: every exponential has exp(A) on its diagonal (-> R, t)
+// and D exp(A)[G_i] as its upper-right block (-> dexp, what the NEXT step's chain rule needs: the step that follows a
+// gradient pass differentiates at the parameters the pass ran with, i.e. the ones this call sees).  One batch of six 8x8
+// exponentials serves both; until round 3 the step evaluated its own six and the geometry a seventh.
+__device__ __forceinline__ void light_geometry(const float *params, float *geom, double *dexp, double (*S)[64], double (*T)[64],
                                                double (*E)[64], double (*P)[64]) {
-    if (threadIdx.x < 64) S[0][threadIdx.x] = 0.0;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 384; i += blockDim.x) S[i >> 6][i & 63] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double xi[6];
+    if (tid < 6) {
+        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) xi[i] = params[9 + i];
-        hat_into(xi, S[0], 0, 0);
+        ei[tid] = 1.0;
+        hat_into(xi, S[tid], 0, 0);
+        hat_into(xi, S[tid], 4, 4);
+        hat_into(ei, S[tid], 0, 4);
     }
     __syncthreads();
-    block_exp(S, T, E, P, 1);
-    if (threadIdx.x < 12) {
-        const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+    block_exp(S, T, E, P, 6);
+    if (tid < 12) {
+        const int r = tid / 4, c = tid % 4;
         if (c < 3) geom[r * 3 + c] = (float)E[0][r * 8 + c];
         else geom[9 + r] = (float)E[0][r * 8 + 3];
     }
-    if (threadIdx.x == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
+    if (tid >= 64 && tid < 64 + 72) {
+        const int i = (tid - 64) / 12, e = (tid - 64) % 12, r = e / 4, c = e % 4;
+        dexp[i * 12 + e] = E[i][r * 8 + 4 + c];
+    }
+    if (tid == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
         const float *sg = params + 15;
         const float S00 = sg[0] * sg[0] + sg[2] * sg[2], S01 = sg[0] * sg[1] + sg[2] * sg[3];
         const float S11 = sg[1] * sg[1] + sg[3] * sg[3];
@@ -120,17 +134,17 @@ __device__ __forceinline__ void light_geometry(const float *params, float *geom,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void light_init_kernel(float *pstate, float *geom, const float *p0) {
+__global__ __launch_bounds__(512) void light_init_kernel(float *pstate, float *geom, double *dexp, const float *p0) {
     __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
     if (threadIdx.x < 3 * kLightParams) pstate[threadIdx.x] = threadIdx.x < kLightParams ? p0[threadIdx.x] : 0.f;
     __syncthreads();
-    light_geometry(pstate, geom, S, T, E, P);
+    light_geometry(pstate, geom, dexp, S, T, E, P);
 }
 
 // geometry of whatever parameters are stored now (the caller may have written them since the last step)
-__global__ __launch_bounds__(512) void light_geometry_kernel(const float *pstate, float *geom) {
+__global__ __launch_bounds__(512) void light_geometry_kernel(const float *pstate, float *geom, double *dexp) {
     __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
-    light_geometry(pstate, geom, S, T, E, P);
+    light_geometry(pstate, geom, dexp, S, T, E, P);
 }
 
 // ---- gradient pass ---------------------------------------------------------------------------------------------------
@@ -252,31 +266,19 @@ struct LightLds {
     double w4[kLightSums][4];
 };
 
-__device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *geom, const uint64_t *__restrict__ n_obs_total,
-                                           const AdamCoef &co, double *__restrict__ trace_row) {
+__device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *geom, double *dexp,
+                                           const uint64_t *__restrict__ n_obs_total, const AdamCoef &co,
+                                           double *__restrict__ trace_row) {
     double (*S)[64] = lds.S, (*T)[64] = lds.T, (*E)[64] = lds.E, (*P)[64] = lds.P;
     const double *sums = lds.sums;
     double *grad = lds.grad;
     const int tid = threadIdx.x;
     const double f = -2.0 * (double)((1.0f / 3.0f) / (float)(*n_obs_total));   // dL/dIhat = f * r
-    // block matrices [[A, G_i], [0, A]]: the upper-right block of the exponential is D exp(A)[G_i]
-    for (int i = tid; i < 384; i += blockDim.x) S[i >> 6][i & 63] = 0.0;
-    __syncthreads();
-    if (tid < 6) {
-        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 6; ++i) xi[i] = pstate[9 + i];
-        ei[tid] = 1.0;
-        hat_into(xi, S[tid], 0, 0);
-        hat_into(xi, S[tid], 4, 4);
-        hat_into(ei, S[tid], 0, 4);
-    }
-    __syncthreads();
-    block_exp(S, T, E, P, 6);
-    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp[G_i]>
+    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp(hat xi)[G_i]>, the derivative left behind with the geometry
         double s = 0.0;
         for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * E[tid][r * 8 + 4 + c];
-            s += sums[19 + r] * E[tid][r * 8 + 7];
+            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * dexp[tid * 12 + r * 4 + c];
+            s += sums[19 + r] * dexp[tid * 12 + r * 4 + 3];
         }
         grad[9 + tid] = f * s;
     }
@@ -310,7 +312,7 @@ __device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *
     }
     if (tid == 32 && trace_row) trace_row[0] = sums[9];
     __syncthreads();   // (workgroup scope is enough for the read-back below; an agent-scope fence here wrote the L2 back: +50 us)
-    light_geometry(pstate, geom, S, T, E, P);
+    light_geometry(pstate, geom, dexp, S, T, E, P);
 }
 
 // kClosed: J is re-solved in closed form at the top of the iteration (sucre.py:141, 66-77 with absorption = l a,
@@ -491,12 +493,12 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
 // 14 KB of LDS in it; as its own launch it costs ~20 us + one launch gap in both modes.  Round 2 had two launches here,
 // a reduction that waited for every load before issuing the next (49 us) and the step (14 us).)
 __global__ __launch_bounds__(256) void light_tail_kernel(const float *partials, int n_blocks, double *sums, float *pstate,
-                                                         float *geom, const uint64_t *__restrict__ n_obs_total,
+                                                         float *geom, double *dexp, const uint64_t *__restrict__ n_obs_total,
                                                          const AdamCoef co, double *trace_row) {
     __shared__ LightLds lds;
     light_reduce(partials, n_blocks, lds.sums, lds.w4);
     if (threadIdx.x < kLightSums) sums[threadIdx.x] = lds.sums[threadIdx.x];
-    light_step(lds, pstate, geom, n_obs_total, co, trace_row);
+    light_step(lds, pstate, geom, dexp, n_obs_total, co, trace_row);
 }
 
 struct LightParams19 { float v[kLightParams]; };
@@ -550,7 +552,7 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     float *scratch = reinterpret_cast<float *>(lws + X.off_sums);  // 19 floats staged in the (still unused) sums area
     hipLaunchKernelGGL(light_params_upload_kernel, dim3(1), dim3(64), 0, s, scratch, p);
     hipLaunchKernelGGL(light_init_kernel, dim3(1), dim3(512), 0, s, pstate, reinterpret_cast<float *>(lws + X.off_geom),
-                       scratch);
+                       reinterpret_cast<double *>(lws + X.off_dexp), scratch);
     return hipGetLastError();
 }
 
@@ -577,7 +579,7 @@ hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, uns
     LightLayout X;
     make_light_layout(L, &X);
     hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(512), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
-                       reinterpret_cast<float *>(lws + X.off_geom));
+                       reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp));
     launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, flags, s);
     return hipGetLastError();
 }
@@ -590,8 +592,8 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
     else launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
     hipLaunchKernelGGL(light_tail_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const float *>(lws + X.off_partials), L.n_blocks,
                        reinterpret_cast<double *>(lws + X.off_sums), reinterpret_cast<float *>(lws + X.off_params),
-                       reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total), co,
-                       trace_row);
+                       reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp),
+                       reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total), co, trace_row);
     return hipGetLastError();
 }
 
