@@ -50,10 +50,10 @@ constexpr float kInv255 = (float)(1.0 / 255.0);
 // ---------------------------------------------------------------------------------------------------------------
 // Arithmetic of one chunk: four levels of this lane's pixel.
 //
-// The loop is VALU-bound next to the stream (tools/probes/loop_probe.hip): 13 plain instructions (~1.1 ns per
-// wave-instruction per SIMD) and 2 v_exp_f32 (~4.5 ns each, not overlapped with anything) per observation-channel.
-// The 24 exponentials of a chunk are issued back to back, their arguments before them and their uses after them:
-// interleaved with their dependent arithmetic they cost 6.7 ns each (measured: 337 -> 296 ns per chunk per SIMD).
+// The loop is VALU-bound next to the stream: 13 plain instructions (2.34 cycles per wave-instruction per SIMD at five
+// waves per SIMD) and 2 v_exp_f32 (4.0 cycles each back to back, not overlapped with anything: tools/probes/exp_probe.hip)
+// per observation-channel.  The 24 exponentials of a chunk are issued back to back, their arguments before them and their
+// uses after them: interleaved with their dependent arithmetic the loop was 14 % slower (337 -> 296 ns per chunk per SIMD).
 // ---------------------------------------------------------------------------------------------------------------
 struct Acc {
     float pa[3];   // this pixel: sum r a
