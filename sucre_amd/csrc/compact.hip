@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__rest
     const int tile = blockIdx.x, t = threadIdx.x;
     hist[t] = 0;
     keep_words(view_keep, n_views, mask_words, keep);
-    const int l = t >> 2, j = t & 3;   // slot t = 4 l + j: bit l of word j
+    const int l = t & 63, j = t >> 6;   // slot t = 64 j + l: bit l of word j
     uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     uint32_t c = 0;
     for (int base = 0; base < n_views; base += kBitsStage) {

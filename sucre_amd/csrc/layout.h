@@ -67,7 +67,7 @@ struct Layout {
     size_t off_pcount;      // uint16 [n_tiles*256]        observations of every pixel over the kept views
     size_t off_pmask;       // uint64 [n_tiles*256][mask_words]  which kept views observe the pixel (bit k = view k)
     int mask_words;
-    size_t off_vbits;       // uint64 [n_tiles][n_views][4]  which pixels of the tile view k observes: word j, bit l = slot 4 l + j
+    size_t off_vbits;       // uint64 [n_tiles][n_views][4]  which pixels of the tile view k observes: word j, bit l = slot 64 j + l
     size_t off_blockhist;   // uint32 [256 bins][n_tiles]  counting-sort histograms (bin-major), scanned in place
     size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
     size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)

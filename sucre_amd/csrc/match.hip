@@ -81,7 +81,7 @@ __device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H
 constexpr int kViewsPerGroup = 16;
 // One 16x16 tile x up to 16 views per workgroup; wave w takes the views k = w (mod 4) of the group, four pixels per
 // lane.  By-product: which pixels of the tile view k observes, as the four ballots of the lanes' pixels (`vbits`, 32 bytes
-// per (tile, view)): the compaction derives every pixel's view mask from them instead of re-reading every dense range.
+// per (tile, view): word j, bit l = slot 64 j + l): the compaction derives every pixel's view mask from them instead of re-reading every dense range.
 //
 // What did NOT pay here, each measured against the round-2 kernel on the same box (tools/exp/ab_match.sh; 1080p x 65
 // views, 837-870 us): (a) a tile-level cull before matching -- a pre-pass projecting the 8 corners of every tile's
@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                                                     size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext,
                                                     int ext_mode, uint8_t *__restrict__ ext2,
                                                     uint64_t *__restrict__ vbits) {
+    // A wave's results of one view pass through LDS on their way out: the lanes COMPUTE on rows of the tile (see below) but
+    // the dense chunk is stored four adjacent slots per lane (one 16-byte + three 4-byte stores per lane, as the readers expect)
+    __shared__ __attribute__((aligned(16))) float lz[4][kTilePx];
+    __shared__ __attribute__((aligned(16))) uint8_t lc[4][3 * kTilePx];
+    __shared__ __attribute__((aligned(16))) float le[kExt ? 4 : 1][kExt ? 3 : 1][kExt ? kTilePx : 1];
+    __shared__ __attribute__((aligned(16))) float lf[kBoth ? 4 : 1][kBoth ? 3 : 1][kBoth ? kTilePx : 1];
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD one contiguous band of tiles so the
     // depth2 / rgb2 gathers of neighbouring tiles share that XCD's L2 (speed only, never correctness).
     const int tile = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
@@ -114,15 +120,19 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int v1 = ty * kTile + (lane >> 2);
-    const int u1b = tx * kTile + (lane & 3) * 4;
+    // Lane l works on the pixels (row 4 j + l / 16, column l % 16), j = 0..3, i.e. slot 64 j + l: sixteen adjacent lanes
+    // hold sixteen adjacent pixels of a row, so a gather instruction touches 4 short row segments of the view instead of
+    // 16 (the kernel's gathers -- 64 scattered lanes through the texture addresser -- are what it is bound by: with four
+    // adjacent pixels per lane every gather spread over 16 rows; round 3, -x % on the kernel, tools/exp/ab_match.sh).
+    const int u1 = tx * kTile + (lane & 15);
+    const int v1b = ty * kTile + (lane >> 4);
     const float W1f = (float)c1.W, H1f = (float)c1.H;
 
     float wP[4][3];
     bool ok1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int u1 = u1b + j;
+        const int v1 = v1b + 4 * j;
         float d = 0.0f;
         if (v1 < c1.H && u1 < c1.W) d = depth1[(size_t)v1 * c1.W + u1];
         ok1[j] = d > 0.0f;
@@ -137,9 +147,6 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
         const uint8_t *__restrict__ rgb2 = vw->rgb;
         const float W2f = (float)vw->W, H2f = (float)vw->H;
-        float zo[4], cx[kExt ? 4 : 1], cy[kExt ? 4 : 1], cz[kExt ? 4 : 1];
-        float fr[kBoth ? 4 : 1], fg[kBoth ? 4 : 1], fb[kBoth ? 4 : 1];
-        uint32_t r4 = 0, g4 = 0, b4 = 0;
         int total = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             float f2[3] = {0.f, 0.f, 0.f};
             if (m) {
                 size_t q;
-                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1b + j, v1, &q, c2);
+                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1, v1b + 4 * j, &q, c2);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
                     if (kBoth) {                          // float32 colour image, camera point kept as well
@@ -160,40 +167,49 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                         const auto *pf = global_ptr(reinterpret_cast<const float *>(rgb2)) + q * 3;
                         c2[0] = pf[0]; c2[1] = pf[1]; c2[2] = pf[2];
                     } else {
-                        const auto *p = global_ptr(rgb2) + q * 3;
-                        r = p[0]; g = p[1]; b = p[2];
+                        // one (unaligned) 4-byte gather instead of a 2-byte and a 1-byte one; the image's last pixel
+                        // reads the dword that ENDS at its blue byte, so nothing past the buffer is touched
+                        const bool last = q + 1 == (size_t)vw->H * vw->W;
+                        typedef uint32_t __attribute__((aligned(1))) u32_any;
+                        uint32_t rgbw = *(const __attribute__((address_space(1))) u32_any *)(rgb2 + q * 3 - (last ? 1 : 0));
+                        rgbw = last ? rgbw >> 8 : rgbw;
+                        r = rgbw & 255u; g = (rgbw >> 8) & 255u; b = (rgbw >> 16) & 255u;
                     }
                 }
             }
-            zo[j] = z;
-            if (kExt) { cx[j] = m ? c2[0] : 0.f; cy[j] = m ? c2[1] : 0.f; cz[j] = m ? c2[2] : 0.f; }
-            if (kBoth) { fr[j] = m ? f2[0] : 0.f; fg[j] = m ? f2[1] : 0.f; fb[j] = m ? f2[2] : 0.f; }
-            r4 |= r << (8 * j);
-            g4 |= g << (8 * j);
-            b4 |= b << (8 * j);
+            const int slot = 64 * j + lane;
+            lz[wave][slot] = z;
+            lc[wave][slot] = (uint8_t)r; lc[wave][kTilePx + slot] = (uint8_t)g; lc[wave][2 * kTilePx + slot] = (uint8_t)b;
+            if (kExt) { le[wave][0][slot] = m ? c2[0] : 0.f; le[wave][1][slot] = m ? c2[1] : 0.f; le[wave][2][slot] = m ? c2[2] : 0.f; }
+            if (kBoth) { lf[wave][0][slot] = m ? f2[0] : 0.f; lf[wave][1][slot] = m ? f2[1] : 0.f; lf[wave][2][slot] = m ? f2[2] : 0.f; }
             const unsigned long long bal = __ballot(m);
             total += __builtin_popcountll(bal);
-            if (lane == j) vbits[((size_t)tile * n_views + k) * 4 + j] = bal;   // word j, bit l: slot 4 l + j
+            if (lane == j) vbits[((size_t)tile * n_views + k) * 4 + j] = bal;   // word j, bit l: slot 64 j + l
         }
         if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: LDS
+            __builtin_amdgcn_wave_barrier();                          // operations of one wave complete in order
             uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;
-            *reinterpret_cast<float4 *>(chunk + lane * 16) = make_float4(zo[0], zo[1], zo[2], zo[3]);
+            *reinterpret_cast<float4 *>(chunk + lane * 16) = *reinterpret_cast<const float4 *>(&lz[wave][lane * 4]);
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
-            c[0] = r4; c[64] = g4; c[128] = b4;
+            const uint32_t *cw = reinterpret_cast<const uint32_t *>(&lc[wave][0]) + lane;
+            c[0] = cw[0]; c[64] = cw[64]; c[128] = cw[128];
             if (kExt) {  // extension planes: the camera-frame point cP of every observation (light model,
                          // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
                 uint8_t *e = ext + ((size_t)tile * n_views + k) * kExtChunk;
-                *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(cx[0], cx[1], cx[2], cx[3]);
-                *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(cy[0], cy[1], cy[2], cy[3]);
-                *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(cz[0], cz[1], cz[2], cz[3]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<float4 *>(e + pl * kChunkZ + lane * 16) = *reinterpret_cast<const float4 *>(&le[wave][pl][lane * 4]);
             }
             if (kBoth) {
                 uint8_t *e = ext2 + ((size_t)tile * n_views + k) * kExtChunk;
-                *reinterpret_cast<float4 *>(e + lane * 16) = make_float4(fr[0], fr[1], fr[2], fr[3]);
-                *reinterpret_cast<float4 *>(e + kChunkZ + lane * 16) = make_float4(fg[0], fg[1], fg[2], fg[3]);
-                *reinterpret_cast<float4 *>(e + 2 * kChunkZ + lane * 16) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<float4 *>(e + pl * kChunkZ + lane * 16) = *reinterpret_cast<const float4 *>(&lf[wave][pl][lane * 4]);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // ... and the next view's writes come after these reads
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -392,24 +408,20 @@ __global__ __launch_bounds__(256) void export_view_ext_kernel(const uint8_t *__r
 }
 
 // After an import: the tile's match count of view k and the view's pixel bits (what match_kernel leaves behind for the
-// views it fills): thread t holds slot t = 4 l + j, so word j collects bit l from the threads 4 l + j.
+// views it fills): thread t holds slot t, wave w's ballot is word w.
 __global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                          int n_views, int k, size_t tile_stride, size_t view_stride,
                                                          uint64_t *__restrict__ vbits) {
-    __shared__ uint32_t word[4][2];
+    __shared__ int part[4];
     const int tile = blockIdx.x, t = threadIdx.x;
-    if (t < 8) word[t >> 1][t & 1] = 0u;
-    __syncthreads();
     const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[t];
-    const int l = t >> 2, j = t & 3;
-    if (z > 0.0f) atomicOr(&word[j][l >> 5], 1u << (l & 31));
-    __syncthreads();
-    if (t < 4) vbits[((size_t)tile * n_views + k) * 4 + t] = ((uint64_t)word[t][1] << 32) | word[t][0];
-    if (t == 0) {
-        int c = 0;
-        for (int i = 0; i < 4; ++i) c += __builtin_popcount(word[i][0]) + __builtin_popcount(word[i][1]);
-        cnt[(size_t)tile * n_views + k] = (uint16_t)c;
+    const unsigned long long bal = __ballot(z > 0.0f);
+    if ((t & 63) == 0) {
+        vbits[((size_t)tile * n_views + k) * 4 + (t >> 6)] = bal;
+        part[t >> 6] = __builtin_popcountll(bal);
     }
+    __syncthreads();
+    if (t == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
 }
 
 hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s) {

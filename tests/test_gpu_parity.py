@@ -689,3 +689,21 @@ def test_shared_water_closed_form_vs_tied_reference_modules(form):
         J = r.J().cpu().numpy()
         assert np.array_equal(np.isnan(J), np.isnan(g[key]))
         assert helpers.rms_per_channel(J, g[key]).max() < 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_randomised_scene_sweep_small(monkeypatch):
+    """A short run of tools/parity_sweep.py inside the suite (the full 920-scene sweep stays a tool): twelve random small
+    scenes -- odd sizes, 2-14 views, steep relief, strong twist noise, up to 30 % invalid pixels, far views -- with match
+    maps bit-identical to the oracle's and the fit within the sweep's bars in both store formats and both J modes, the
+    light model included; closed-form knee scenes are held to the cost of iteration 0 there (and pinned against the
+    reference's own spread by test_knee_scenes_engine_within_reference_self_spread)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    path = Path(__file__).resolve().parent.parent / 'tools' / 'parity_sweep.py'
+    spec = importlib.util.spec_from_file_location('parity_sweep', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, 'argv', ['parity_sweep.py', '12', '4242', '200', '150'])
+    mod.main()
