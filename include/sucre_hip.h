@@ -83,7 +83,9 @@ extern "C" {
  */
 typedef struct sucre_view {
     const float *depth;   /* device, (H,W) float32 metres, <=0 = invalid   loader.py:166-170 */
-    const uint8_t *rgb;   /* device, (H,W,3) uint8                         loader.py:156-163 */
+    const uint8_t *rgb;   /* device, (H,W,3) uint8                         loader.py:156-163
+                             NULL in a NEIGHBOUR view of sucre_match_views / sucre_match_views_light / sucre_match_map:
+                             `depth` then points to the view's sucre_pack_view records (depth and colour in one gather) */
     int32_t H, W;
     float K[9];
     float Kinv[9];
@@ -129,6 +131,15 @@ int sucre_match_views(void *ws, int H, int W, int n_views, const sucre_view_t *t
  */
 int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const sucre_view_t *views_dev, int k,
                     int32_t *map_dev, void *stream);
+
+/*
+ * Optional, per neighbour view and once per scene: depth map and uint8 colour image interleaved into H*W 8-byte records
+ * {float32 depth, r, g, b, 0} at packed_dev (8-byte aligned, H*W*8 bytes).  A view of `views_dev` whose `rgb` is NULL and
+ * whose `depth` points to such records is matched with ONE gather per landing pixel instead of two (the match kernel is
+ * bound by its gathers); the values are the same, so are the results.  The target keeps the plain form (its depth map and
+ * colour image are read as such: sfm.py:129, sucre.py:47).  Not for float32 colour images (SUCRE_EXT_COLOUR modes).
+ */
+int sucre_pack_view(const float *depth_dev, const uint8_t *rgb_dev, int H, int W, void *packed_dev, void *stream);
 
 /*
  * Image.project_to_view + the truncation and bound test of Image.match_one_way (sfm.py:103-107, 115-117) for an

@@ -113,6 +113,13 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
     return check_hip(launch_match_map(L, *target, views_dev, k, map_dev, static_cast<hipStream_t>(stream)), "sucre_match_map");
 }
 
+int sucre_pack_view(const float *depth_dev, const uint8_t *rgb_dev, int H, int W, void *packed_dev, void *stream) {
+    if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return fail(SUCRE_ERR_ARG, "invalid image size %dx%d", W, H);
+    if (!depth_dev || !rgb_dev || !packed_dev) return fail(SUCRE_ERR_ARG, "depth_dev / rgb_dev / packed_dev is NULL");
+    if (!aligned(packed_dev, 8)) return fail(SUCRE_ERR_ARG, "packed_dev must be 8-byte aligned");
+    return check_hip(launch_pack_view(depth_dev, rgb_dev, H, W, packed_dev, static_cast<hipStream_t>(stream)), "sucre_pack_view");
+}
+
 int sucre_project_points(const sucre_view_t *view, const float *wP_dev, int64_t n, int32_t *pix_dev, void *stream) {
     if (!view) return fail(SUCRE_ERR_ARG, "view is NULL");
     if (view->H <= 0 || view->W <= 0 || view->H > 32767 || view->W > 32767)

@@ -60,14 +60,23 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T *global_ptr
 
 // The fused two-way test for one target pixel whose world point is wP: returns true and the matched pixel of
 // view 2 (linear index q, camera-frame point c2) iff p1 -> p2 -> p1 closes (see the file header).
-__device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H1f, const sucre_view_t *vw,
+// `packed`: the view's `depth` pointer holds sucre_pack_view's 8-byte records {float32 depth, r, g, b, 0} (its `rgb`
+// pointer is NULL): depth and colour of the landing pixel arrive with ONE gather -- *rgbw gets the colour word.
+__device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H1f, const sucre_view_t *vw, bool packed,
                                             float W2f, float H2f, const float wP[3], int u1, int v1, size_t *q_out,
-                                            float c2[3]) {
+                                            float c2[3], uint32_t *rgbw) {
     float px, py;
     if (!project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP, &px, &py)) return false;
     const int u2 = (int)px, v2 = (int)py;
     const size_t q = (size_t)v2 * vw->W + u2;
-    const float d2 = global_ptr(vw->depth)[q];
+    float d2;
+    if (packed) {
+        const unsigned long long rec = global_ptr(reinterpret_cast<const unsigned long long *>(vw->depth))[q];
+        d2 = __uint_as_float((uint32_t)rec);
+        *rgbw = (uint32_t)(rec >> 32);
+    } else {
+        d2 = global_ptr(vw->depth)[q];
+    }
     if (!(d2 > 0.0f)) return false;
     float w2[3], qx, qy;
     unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
     for (int k = kb + wave; k < ke; k += 4) {
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
         const uint8_t *__restrict__ rgb2 = vw->rgb;
+        const bool packed = rgb2 == nullptr;   // wave-uniform: sucre_pack_view records behind vw->depth
         const float W2f = (float)vw->W, H2f = (float)vw->H;
         int total = 0;
 #pragma unroll
@@ -157,7 +167,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             float f2[3] = {0.f, 0.f, 0.f};
             if (m) {
                 size_t q;
-                m = match_pixel(c1, W1f, H1f, vw, W2f, H2f, wP[j], u1, v1b + 4 * j, &q, c2);
+                uint32_t rgbw = 0;
+                m = match_pixel(c1, W1f, H1f, vw, packed, W2f, H2f, wP[j], u1, v1b + 4 * j, &q, c2, &rgbw);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
                     if (kBoth) {                          // float32 colour image, camera point kept as well
@@ -167,12 +178,14 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
                         const auto *pf = global_ptr(reinterpret_cast<const float *>(rgb2)) + q * 3;
                         c2[0] = pf[0]; c2[1] = pf[1]; c2[2] = pf[2];
                     } else {
-                        // one (unaligned) 4-byte gather instead of a 2-byte and a 1-byte one; the image's last pixel
-                        // reads the dword that ENDS at its blue byte, so nothing past the buffer is touched
-                        const bool last = q + 1 == (size_t)vw->H * vw->W;
-                        typedef uint32_t __attribute__((aligned(1))) u32_any;
-                        uint32_t rgbw = *(const __attribute__((address_space(1))) u32_any *)(rgb2 + q * 3 - (last ? 1 : 0));
-                        rgbw = last ? rgbw >> 8 : rgbw;
+                        if (!packed) {
+                            // one (unaligned) 4-byte gather instead of a 2-byte and a 1-byte one; the image's last pixel
+                            // reads the dword that ENDS at its blue byte, so nothing past the buffer is touched
+                            const bool last = q + 1 == (size_t)vw->H * vw->W;
+                            typedef uint32_t __attribute__((aligned(1))) u32_any;
+                            rgbw = *(const __attribute__((address_space(1))) u32_any *)(rgb2 + q * 3 - (last ? 1 : 0));
+                            rgbw = last ? rgbw >> 8 : rgbw;
+                        }
                         r = rgbw & 255u; g = (rgbw >> 8) & 255u; b = (rgbw >> 16) & 255u;
                     }
                 }
@@ -180,8 +193,8 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             const int slot = 64 * j + lane;
             lz[wave][slot] = z;
             lc[wave][slot] = (uint8_t)r; lc[wave][kTilePx + slot] = (uint8_t)g; lc[wave][2 * kTilePx + slot] = (uint8_t)b;
-            if (kExt) { le[wave][0][slot] = m ? c2[0] : 0.f; le[wave][1][slot] = m ? c2[1] : 0.f; le[wave][2][slot] = m ? c2[2] : 0.f; }
-            if (kBoth) { lf[wave][0][slot] = m ? f2[0] : 0.f; lf[wave][1][slot] = m ? f2[1] : 0.f; lf[wave][2][slot] = m ? f2[2] : 0.f; }
+            if constexpr (kExt) { le[wave][0][slot] = m ? c2[0] : 0.f; le[wave][1][slot] = m ? c2[1] : 0.f; le[wave][2][slot] = m ? c2[2] : 0.f; }
+            if constexpr (kBoth) { lf[wave][0][slot] = m ? f2[0] : 0.f; lf[wave][1][slot] = m ? f2[1] : 0.f; lf[wave][2][slot] = m ? f2[2] : 0.f; }
             const unsigned long long bal = __ballot(m);
             total += __builtin_popcountll(bal);
             if (lane == j) vbits[((size_t)tile * n_views + k) * 4 + j] = bal;   // word j, bit l: slot 64 j + l
@@ -195,14 +208,14 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             uint32_t *c = reinterpret_cast<uint32_t *>(chunk + kChunkZ) + lane;  // planar R | G | B, 256 B each
             const uint32_t *cw = reinterpret_cast<const uint32_t *>(&lc[wave][0]) + lane;
             c[0] = cw[0]; c[64] = cw[64]; c[128] = cw[128];
-            if (kExt) {  // extension planes: the camera-frame point cP of every observation (light model,
-                         // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
+            if constexpr (kExt) {  // extension planes: the camera-frame point cP of every observation (light model,
+                                   // loader.py:113) or its float32 colour (SUCRE_EXT_COLOUR)
                 uint8_t *e = ext + ((size_t)tile * n_views + k) * kExtChunk;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     *reinterpret_cast<float4 *>(e + pl * kChunkZ + lane * 16) = *reinterpret_cast<const float4 *>(&le[wave][pl][lane * 4]);
             }
-            if (kBoth) {
+            if constexpr (kBoth) {
                 uint8_t *e = ext2 + ((size_t)tile * n_views + k) * kExtChunk;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -230,7 +243,8 @@ __global__ __launch_bounds__(256) void match_map_kernel(const float *__restrict_
         size_t q;
         unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
         rigid(c1.R, c1.t, cP, wP);
-        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, (float)vw->W, (float)vw->H, wP, u1, v1, &q, c2))
+        uint32_t rgbw;
+        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, vw->rgb == nullptr, (float)vw->W, (float)vw->H, wP, u1, v1, &q, c2, &rgbw))
             out = (int32_t)q;
     }
     map[idx] = out;
@@ -451,6 +465,21 @@ static CamDev to_cam(const sucre_view_t &v) {
     for (int i = 0; i < 3; ++i) { c.t[i] = v.t[i]; c.tinv[i] = v.tinv[i]; }
     c.H = v.H; c.W = v.W;
     return c;
+}
+
+// {float32 depth, r, g, b, 0} per pixel: what a packed view's `depth` pointer holds (sucre_pack_view).
+__global__ __launch_bounds__(256) void pack_view_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ rgb,
+                                                        long long n, uint2 *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = rgb + i * 3;
+    out[i] = make_uint2(__float_as_uint(depth[i]), (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
+}
+
+hipError_t launch_pack_view(const float *depth, const uint8_t *rgb, int H, int W, void *packed, hipStream_t s) {
+    const long long n = (long long)H * W;
+    hipLaunchKernelGGL(pack_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, depth, rgb, n, static_cast<uint2 *>(packed));
+    return hipGetLastError();
 }
 
 hipError_t launch_project_points(const sucre_view_t &view, const float *wP, long long n, int32_t *pix, hipStream_t s) {

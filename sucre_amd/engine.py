@@ -29,14 +29,55 @@ class DeviceView:
     t: torch.Tensor       # (3,1) float32, cpu
     name: str = ''
 
-    def to_struct(self) -> _lib.SucreView:
-        """sucre_view_t of this view (cached: the matrices are derived once per view, not once per target image)."""
-        cached = self.__dict__.get('_struct')
-        if cached is not None and cached[0] == (self.depth.data_ptr(), self.rgb.data_ptr()):
+    def to_struct(self, packed: bool = False) -> _lib.SucreView:
+        """sucre_view_t of this view (cached: the matrices are derived once per view, not once per target image).
+        ``packed``: the neighbour-view form whose ``depth`` points to the view's ``sucre_pack_view`` records and whose
+        ``rgb`` is NULL (see ``packed_records``)."""
+        slot = '_struct_packed' if packed else '_struct'
+        key = (self.depth.data_ptr(), self.rgb.data_ptr())
+        cached = self.__dict__.get(slot)
+        if cached is not None and cached[0] == key:
             return cached[1]
-        s = self._build_struct()
-        self.__dict__['_struct'] = ((self.depth.data_ptr(), self.rgb.data_ptr()), s)
+        if packed:
+            H, W = self.depth.shape
+            s = camera_struct(self.K, self.R, self.t, H, W, self.packed_records().data_ptr(), 0)
+        else:
+            s = self._build_struct()
+        self.__dict__[slot] = (key, s)
         return s
+
+    def packed_records(self) -> torch.Tensor:
+        """Depth map and uint8 colours interleaved into 8-byte records {float32 depth, r, g, b, 0} (``sucre_pack_view``),
+        built once per view on a side stream: as a neighbour the view is then matched with one gather per landing pixel
+        instead of two (csrc/match.hip is bound by its gathers).  Consumers on any stream call ``wait_packed`` first."""
+        key = (self.depth.data_ptr(), self.rgb.data_ptr())
+        cached = self.__dict__.get('_packed')
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        assert self.rgb.dtype == torch.uint8, 'packed records hold uint8 colours'
+        H, W = self.depth.shape
+        dev = self.depth.device
+        out = torch.empty(H * W * 8, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            side = _pack_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))   # the pixels may have been produced on the caller's stream
+            with torch.cuda.stream(side):
+                _lib.check(_lib.load().sucre_pack_view(C.c_void_p(self.depth.data_ptr()), C.c_void_p(self.rgb.data_ptr()), H, W,
+                                                       C.c_void_p(out.data_ptr()), _stream_ptr()))
+                done = torch.cuda.Event()
+                done.record()
+        self.__dict__['_packed'] = (key, out, done)
+        self.__dict__['_packed_pending'] = True
+        return out
+
+    def wait_packed(self) -> None:
+        """Makes the current stream wait for this view's records (nothing once they are known to be complete)."""
+        if self.__dict__.get('_packed_pending'):
+            done = self.__dict__['_packed'][2]
+            if done.query():
+                self.__dict__['_packed_pending'] = False
+            else:
+                torch.cuda.current_stream(self.depth.device).wait_event(done)
 
     def as_float_colour(self) -> 'DeviceView':
         """This view with float32 colours (float32(float64(k)/255), loader.py:157-163): used when other views of the
@@ -88,6 +129,19 @@ def project_points(view: _lib.SucreView, wP: torch.Tensor) -> torch.Tensor:
                                                     _stream_ptr()))
     return out
 
+
+_PACK_STREAMS: dict = {}
+
+
+def _pack_stream(dev) -> 'torch.cuda.Stream':
+    key = str(dev)
+    if key not in _PACK_STREAMS:
+        _PACK_STREAMS[key] = torch.cuda.Stream(dev)
+    return _PACK_STREAMS[key]
+
+
+# engine knob: neighbour views as 8-byte {depth, colour} records (one gather per landing pixel; +8 bytes per pixel and view)
+PACKED_VIEWS = os.environ.get('SUCRE_PACKED_VIEWS', '1') != '0'
 
 MAX_VIEWS = 4096   # kMaxViews of csrc/layout.h: views of one restoration (after the overlap cull of sfm.Image.match_images)
 
@@ -169,7 +223,12 @@ class Restoration:
         assert 1 <= len(views) <= self.capacity, (len(views), self.capacity)
         self.n_views = len(views)   # the workspace layout is a function of (H, W, n_views) and grows with n_views
         tgt = target.to_struct()
-        table = (_lib.SucreView * self.n_views)(*[v.to_struct() for v in views])
+        packed = PACKED_VIEWS and not self.float_colour   # (float32 colour images keep the two-gather form)
+        table = (_lib.SucreView * self.n_views)(*[v.to_struct(packed) for v in views])
+        if packed:
+            with torch.cuda.device(self.device):
+                for v in views:
+                    v.wait_packed()
         nbytes = C.sizeof(table)
         if self._views_copied is not None:
             self._views_copied.synchronize()   # the previous table has left the staging buffer (it was the first thing

@@ -235,7 +235,9 @@ class Image:
             if dev.type == 'cuda':  # the cache is shared by every stream (engine.in_flight_slot, decode threads):
                 torch.cuda.current_stream(dev).synchronize()   # publish it only once the upload has landed
             self._device_view = (dev, view)
-            PIXEL_CACHE.insert(self, view.depth.numel() * 4 + view.rgb.numel() * view.rgb.element_size(), dev)
+            # (+ 8 bytes per pixel for the packed {depth, colour} records a uint8 view gets when it is first matched against)
+            packed = view.depth.numel() * 8 if (view.rgb.dtype == torch.uint8 and dev.type == 'cuda') else 0
+            PIXEL_CACHE.insert(self, view.depth.numel() * 4 + view.rgb.numel() * view.rgb.element_size() + packed, dev)
             return view
 
     def release_device(self) -> None:

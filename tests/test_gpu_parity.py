@@ -707,3 +707,34 @@ def test_randomised_scene_sweep_small(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, 'argv', ['parity_sweep.py', '12', '4242', '200', '150'])
     mod.main()
+
+
+def test_packed_neighbour_views_change_nothing(golden, monkeypatch):
+    """Neighbour views as sucre_pack_view records ({depth, r, g, b, 0}: one gather per landing pixel) against the plain
+    two-pointer form: counts, every stored range and colour, the explicit match maps and the fitted J are the same bits."""
+    from sucre_amd import engine
+    sc = golden.scene
+    out = {}
+    for packed in (True, False):
+        monkeypatch.setattr(engine, 'PACKED_VIEWS', packed)
+        views = engine.device_views_from_scene(sc, 'cuda')
+        r = engine.Restoration(sc.height, sc.width, len(views))
+        r.match(views[sc.target], views)
+        stores = [tuple(t.cpu().numpy() for t in r.export_view(k)) for k in range(len(views))]
+        maps = [r.match_map(k).cpu().numpy() for k in range(len(views))]
+        r.fit_init(views[sc.target])
+        trace = r.fit(7).cpu().numpy()
+        out[packed] = (r.view_counts().cpu().numpy(), stores, maps, trace, r.J().cpu().numpy())
+        if packed:
+            assert all('_packed' in v.__dict__ for v in views)
+            rec = views[0].packed_records().cpu().numpy().view(np.uint32).reshape(sc.height, sc.width, 2)
+            assert np.array_equal(rec[..., 0].view(np.float32), views[0].depth.cpu().numpy())
+            rgb = views[0].rgb.cpu().numpy().astype(np.uint32)
+            assert np.array_equal(rec[..., 1], rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16))
+    a, b = out[True], out[False]
+    assert np.array_equal(a[0], b[0])
+    for (za, ca), (zb, cb) in zip(a[1], b[1]):
+        assert np.array_equal(za, zb) and np.array_equal(ca, cb)
+    for ma, mb in zip(a[2], b[2]):
+        assert np.array_equal(ma, mb)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4], equal_nan=True)
