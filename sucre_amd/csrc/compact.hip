@@ -245,8 +245,10 @@ __device__ __forceinline__ void store_group(uint8_t *strip, float *const (&estri
         } else {
             *reinterpret_cast<float4 *>(ch + lane * 16) = make_float4(q.z[0], q.z[1], q.z[2], q.z[3]);
         }
-        uint32_t *cp = reinterpret_cast<uint32_t *>(ch + zb * kStripPx * kGroupLv) + lane;
-        cp[0] = q.c[0]; cp[kStripPx] = q.c[1]; cp[2 * kStripPx] = q.c[2];
+        // the lane's three colour words side by side: one 12-byte store (three 4-byte stores to three planes until round 3:
+        // the kernel's stores go 64 scattered lanes at a time through the same texture addresser as its loads)
+        uint32_t *cp = reinterpret_cast<uint32_t *>(ch + zb * kStripPx * kGroupLv) + 3 * lane;
+        cp[0] = q.c[0]; cp[1] = q.c[1]; cp[2] = q.c[2];
 #pragma unroll
         for (int set = 0; set < kExt; ++set) {
             float *e = estrip[set] + (size_t)g * (kGroupLv * kExtLevelBytes / 4);

@@ -392,8 +392,8 @@ __device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&
         zz[0] = (float)(q.x & 0xffffu) * kMPerMm; zz[1] = (float)(q.x >> 16) * kMPerMm;
         zz[2] = (float)(q.y & 0xffffu) * kMPerMm; zz[3] = (float)(q.y >> 16) * kMPerMm;
     }
-    const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + (kFmt ? 2 : 4) * kStripPx * kGroupLv) + lane;
-    cc[0] = cp[0]; cc[1] = cp[kStripPx]; cc[2] = cp[2 * kStripPx];
+    const uint32_t *cp = reinterpret_cast<const uint32_t *>(sp + (kFmt ? 2 : 4) * kStripPx * kGroupLv) + 3 * lane;
+    cc[0] = cp[0]; cc[1] = cp[1]; cc[2] = cp[2];   // R, G, B words of the lane's four levels, side by side (layout.h)
 }
 
 // Level j of a short chunk (r < 4 levels, rows of r) in a ring slot.

@@ -21,9 +21,9 @@ __host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt ? kChunk16 :
 constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
 // Compact store (what the fit streams): the count-sorted pixels are cut into STRIPS of 64 consecutive pixels -- one
 // pixel per lane of the wave that owns the strip.  A strip with n levels is stored as ceil(n/4) chunks of 64 pixels x
-// r levels, r = 4 except in the last one (r = n - 4 g): [z: 64 x r ranges, pixel-major][R: 64 x r bytes][G][B], i.e.
-// kLevelBytes x r bytes.  A full chunk has the size of a dense one (1792 B / 1280 B) and a lane reads its pixel's
-// four levels as one float4 (uint2) + three dwords.
+// r levels, r = 4 except in the last one (r = n - 4 g).  A full chunk: [z: 64 x 4 ranges, pixel-major][64 x {R word, G word,
+// B word}: byte j of a word = level j] -- the size of a dense one (1792 B / 1280 B); a lane reads its pixel's four levels
+// as one float4 (uint2) + three adjacent dwords.  The short last chunk: [z: 64 x r][R: 64 x r bytes][G][B], kLevelBytes x r.
 constexpr int kStripPx = 64;
 constexpr int kStripsPerTile = kTilePx / kStripPx;
 constexpr int kGroupLv = 4;                       // levels per full chunk

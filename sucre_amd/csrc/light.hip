@@ -210,12 +210,12 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
     LightChunk c;
     if (r == kGroupLv) {
         const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + 4 * kStripPx * kGroupLv) + lane;
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + 4 * kStripPx * kGroupLv) + 3 * lane;
         const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
         const float4 y4 = *reinterpret_cast<const float4 *>(ex + kStripPx * kGroupLv + lane * 4);
         const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kStripPx * kGroupLv + lane * 4);
         c = LightChunk{{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
-                       {cp[0], cp[kStripPx], cp[2 * kStripPx]}};
+                       {cp[0], cp[1], cp[2]}};
     } else {
         c.cc[0] = c.cc[1] = c.cc[2] = 0u;
         const uint8_t *cb = ch + 4 * kStripPx * r;
