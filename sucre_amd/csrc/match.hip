@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         const bool packed = rgb2 == nullptr;   // wave-uniform: sucre_pack_view records behind vw->depth
         const float W2f = (float)vw->W, H2f = (float)vw->H;
         int total = 0;
+        unsigned long long bal[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool m = ok1[j];
@@ -195,10 +196,11 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             lc[wave][slot] = (uint8_t)r; lc[wave][kTilePx + slot] = (uint8_t)g; lc[wave][2 * kTilePx + slot] = (uint8_t)b;
             if constexpr (kExt) { le[wave][0][slot] = m ? c2[0] : 0.f; le[wave][1][slot] = m ? c2[1] : 0.f; le[wave][2][slot] = m ? c2[2] : 0.f; }
             if constexpr (kBoth) { lf[wave][0][slot] = m ? f2[0] : 0.f; lf[wave][1][slot] = m ? f2[1] : 0.f; lf[wave][2][slot] = m ? f2[2] : 0.f; }
-            const unsigned long long bal = __ballot(m);
-            total += __builtin_popcountll(bal);
-            if (lane == j) vbits[((size_t)tile * n_views + k) * 4 + j] = bal;   // word j, bit l: slot 64 j + l
+            bal[j] = __ballot(m);   // word j, bit l: slot 64 j + l
+            total += __builtin_popcountll(bal[j]);
         }
+        if (lane < 4)   // the four ballots in ONE store instruction (lane j holds word j)
+            vbits[((size_t)tile * n_views + k) * 4 + lane] = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
         if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: LDS
