@@ -22,12 +22,32 @@ __device__ __forceinline__ float dot3(const float *a, float x, float y, float z)
     return acc;
 }
 
+// A pinhole camera matrix and its inverse have the form [[a, 0, b], [0, c, d], [0, 0, 1]] (sfm.py:62-78; torch's LU
+// inverse of an upper-triangular matrix keeps the zeros exact).  For such a matrix the FMA chain of dot3() loses its
+// terms with a zero coefficient without changing a bit of any finite result: fma(0, y, acc) = acc and 0 * x = 0 exactly
+// (only the sign of a zero can differ, which no comparison, truncation or product downstream sees), and a non-finite
+// x, y or z still makes c0 or c1 non-finite, so the bound test rejects the point in both forms.  9 -> 4 operations per
+// product; the flag is wave-uniform (one scalar branch).
+__host__ __device__ __forceinline__ bool pinhole_form(const float *M) {
+    return M[1] == 0.f && M[3] == 0.f && M[6] == 0.f && M[7] == 0.f && M[8] == 1.f;
+}
+
+__device__ __forceinline__ void mul3(const float *M, bool pin, float x, float y, float z, float out[3]) {
+    if (pin) {
+        out[0] = __builtin_fmaf(M[2], z, M[0] * x);
+        out[1] = __builtin_fmaf(M[5], z, M[4] * y);
+        out[2] = z;
+    } else {
+        out[0] = dot3(M + 0, x, y, z);
+        out[1] = dot3(M + 3, x, y, z);
+        out[2] = dot3(M + 6, x, y, z);
+    }
+}
+
 // sfm.py:90-93
-__device__ __forceinline__ void unproject(const float *Kinv, float u, float v, float d, float out[3]) {
+__device__ __forceinline__ void unproject(const float *Kinv, bool pin, float u, float v, float d, float out[3]) {
     const float x = d * (u + 0.5f), y = d * (v + 0.5f), z = d * 1.0f;
-    out[0] = dot3(Kinv + 0, x, y, z);
-    out[1] = dot3(Kinv + 3, x, y, z);
-    out[2] = dot3(Kinv + 6, x, y, z);
+    mul3(Kinv, pin, x, y, z, out);
 }
 
 // sfm.py:49-55
@@ -39,15 +59,13 @@ __device__ __forceinline__ void rigid(const float *R, const float *t, const floa
 
 // sfm.py:103-107,116-117: world point -> continuous pixel; true when Tensor.long() of it lies inside WxH.
 // trunc(x) in [0, W-1]  <=>  -1 < x < W ; NaN and +-inf fail both comparisons like INT64_MIN fails the bound test.
-__device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, float Wf, float Hf,
+__device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, bool pin, float Wf, float Hf,
                                         const float wP[3], float *px, float *py) {
-    float cP[3];
+    float cP[3], c[3];
     rigid(Rinv, tinv, wP, cP);
-    const float c0 = dot3(K + 0, cP[0], cP[1], cP[2]);
-    const float c1 = dot3(K + 3, cP[0], cP[1], cP[2]);
-    const float c2 = dot3(K + 6, cP[0], cP[1], cP[2]);
-    *px = c0 / c2;
-    *py = c1 / c2;
+    mul3(K, pin, cP[0], cP[1], cP[2], c);
+    *px = c[0] / c[2];
+    *py = c[1] / c[2];
     return (*px > -1.0f) && (*px < Wf) && (*py > -1.0f) && (*py < Hf);
 }
 
@@ -63,10 +81,10 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T *global_ptr
 // `packed`: the view's `depth` pointer holds sucre_pack_view's 8-byte records {float32 depth, r, g, b, 0} (its `rgb`
 // pointer is NULL): depth and colour of the landing pixel arrive with ONE gather -- *rgbw gets the colour word.
 __device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H1f, const sucre_view_t *vw, bool packed,
-                                            float W2f, float H2f, const float wP[3], int u1, int v1, size_t *q_out,
-                                            float c2[3], uint32_t *rgbw) {
+                                            float W2f, float H2f, bool pin, const float wP[3], int u1, int v1,
+                                            size_t *q_out, float c2[3], uint32_t *rgbw) {
     float px, py;
-    if (!project(vw->Rinv, vw->tinv, vw->K, W2f, H2f, wP, &px, &py)) return false;
+    if (!project(vw->Rinv, vw->tinv, vw->K, pin, W2f, H2f, wP, &px, &py)) return false;
     const int u2 = (int)px, v2 = (int)py;
     const size_t q = (size_t)v2 * vw->W + u2;
     float d2;
@@ -79,9 +97,9 @@ __device__ __forceinline__ bool match_pixel(const CamDev &c1, float W1f, float H
     }
     if (!(d2 > 0.0f)) return false;
     float w2[3], qx, qy;
-    unproject(vw->Kinv, (float)u2, (float)v2, d2, c2);
+    unproject(vw->Kinv, pin, (float)u2, (float)v2, d2, c2);
     rigid(vw->R, vw->t, c2, w2);
-    if (!project(c1.Rinv, c1.tinv, c1.K, W1f, H1f, w2, &qx, &qy)) return false;
+    if (!project(c1.Rinv, c1.tinv, c1.K, pin, W1f, H1f, w2, &qx, &qy)) return false;
     if ((int)qx != u1 || (int)qy != v1) return false;
     *q_out = q;
     return true;
@@ -109,7 +127,7 @@ constexpr int kViewsPerGroup = 16;
 // kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
 // `ext`, the float32 colour to `ext2` (light model on resized images).
 template <bool kBoth, bool kExt>
-__global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                     const float *__restrict__ depth1, const CamDev c1,
                                                     const sucre_view_t *__restrict__ views, int n_views, int k0,
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
@@ -136,6 +154,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
     const int u1 = tx * kTile + (lane & 15);
     const int v1b = ty * kTile + (lane >> 4);
     const float W1f = (float)c1.W, H1f = (float)c1.H;
+    const bool pin1 = pinhole_form(c1.K) && pinhole_form(c1.Kinv);
 
     float wP[4][3];
     bool ok1[4];
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         if (v1 < c1.H && u1 < c1.W) d = depth1[(size_t)v1 * c1.W + u1];
         ok1[j] = d > 0.0f;
         float cP[3];
-        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
+        unproject(c1.Kinv, pin1, (float)u1, (float)v1, d, cP);
         rigid(c1.R, c1.t, cP, wP[j]);
     }
 
@@ -157,6 +176,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
         const uint8_t *__restrict__ rgb2 = vw->rgb;
         const bool packed = rgb2 == nullptr;   // wave-uniform: sucre_pack_view records behind vw->depth
         const float W2f = (float)vw->W, H2f = (float)vw->H;
+        const bool pin = pin1 && pinhole_form(vw->K) && pinhole_form(vw->Kinv);   // the pair's four matrices: one scalar branch
         int total = 0;
         unsigned long long bal[4];
 #pragma unroll
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(256) void match_kernel(uint8_t *__restrict__ obs, u
             if (m) {
                 size_t q;
                 uint32_t rgbw = 0;
-                m = match_pixel(c1, W1f, H1f, vw, packed, W2f, H2f, wP[j], u1, v1b + 4 * j, &q, c2, &rgbw);
+                m = match_pixel(c1, W1f, H1f, vw, packed, W2f, H2f, pin, wP[j], u1, v1b + 4 * j, &q, c2, &rgbw);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
                     if (kBoth) {                          // float32 colour image, camera point kept as well
@@ -243,10 +263,11 @@ __global__ __launch_bounds__(256) void match_map_kernel(const float *__restrict_
         const sucre_view_t *vw = views + k;
         float cP[3], wP[3], c2[3];
         size_t q;
-        unproject(c1.Kinv, (float)u1, (float)v1, d, cP);
+        const bool pin = pinhole_form(c1.K) && pinhole_form(c1.Kinv) && pinhole_form(vw->K) && pinhole_form(vw->Kinv);
+        unproject(c1.Kinv, pin, (float)u1, (float)v1, d, cP);
         rigid(c1.R, c1.t, cP, wP);
         uint32_t rgbw;
-        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, vw->rgb == nullptr, (float)vw->W, (float)vw->H, wP, u1, v1, &q, c2, &rgbw))
+        if (match_pixel(c1, (float)c1.W, (float)c1.H, vw, vw->rgb == nullptr, (float)vw->W, (float)vw->H, pin, wP, u1, v1, &q, c2, &rgbw))
             out = (int32_t)q;
     }
     map[idx] = out;
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256) void project_points_kernel(const CamDev cam, c
     if (i >= n) return;
     const float p[3] = {wP[i], wP[n + i], wP[2 * n + i]};
     float px, py;
-    const bool inside = project(cam.Rinv, cam.tinv, cam.K, (float)cam.W, (float)cam.H, p, &px, &py);
+    const bool inside = project(cam.Rinv, cam.tinv, cam.K, pinhole_form(cam.K), (float)cam.W, (float)cam.H, p, &px, &py);
     pix[i] = inside ? (int32_t)py * cam.W + (int32_t)px : -1;
 }
 
