@@ -18,9 +18,9 @@ def main(fixture: str, reps: int, T: int) -> None:
     sc = golden.scene
     views = engine.device_views_from_scene(sc, 'cuda')
     r = engine.Restoration(sc.height, sc.width, len(views))
-    r.match(views[sc.target], views)
     out = []
     for rep in range(reps):
+        r.match(views[sc.target], views)     # matching, compaction and plans are redone every time: they are under test too
         r.fit_init(views[sc.target])
         if rep % 2 == 0:
             t = r.fit(T)

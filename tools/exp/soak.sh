@@ -1,8 +1,8 @@
 #!/bin/bash
 # Soak: three processes fitting the same image at the same time, many repetitions each; every digest of every process
-# must be the digest of a run alone on the GPU (tests/concurrency_worker.py).  usage: tools/exp/soak.sh [reps] [T]
+# must be the digest of a run alone on the GPU (tests/concurrency_worker.py).  usage: tools/exp/soak.sh [reps] [T] [fixture]
 REPS=${1:-200}; T=${2:-40}
-FIX=$(basename $(ls tests/golden/*.npz | head -1) .npz)
+FIX=${3:-relief_96x64_n6}
 REF=$(python3 tests/concurrency_worker.py $FIX 2 $T | grep ^DIGESTS | cut -d' ' -f2)
 for i in 1 2 3; do python3 tests/concurrency_worker.py $FIX $REPS $T > /tmp/soak_$i.log 2>&1 & done
 wait
