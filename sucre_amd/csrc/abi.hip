@@ -125,7 +125,8 @@ int sucre_project_points(const sucre_view_t *view, const float *wP_dev, int64_t 
     if (view->H <= 0 || view->W <= 0 || view->H > 32767 || view->W > 32767)
         return fail(SUCRE_ERR_ARG, "invalid sensor size %dx%d", view->W, view->H);
     if (n < 0) return fail(SUCRE_ERR_RANGE, "negative point count %lld", (long long)n);
-    if (n > 0 && (!wP_dev || !pix_dev)) return fail(SUCRE_ERR_ARG, "wP_dev / pix_dev is NULL");
+    if (n == 0) return SUCRE_OK;   // nothing to launch
+    if (!wP_dev || !pix_dev) return fail(SUCRE_ERR_ARG, "wP_dev / pix_dev is NULL");
     return check_hip(launch_project_points(*view, wP_dev, (long long)n, pix_dev, static_cast<hipStream_t>(stream)),
                      "sucre_project_points");
 }

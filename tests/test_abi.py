@@ -73,6 +73,17 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.sucre_match_views(ws, 48, 64, 3, C.byref(tgt), ws, 0, 4, None) == -2
     tgt.H = 47
     assert lib.sucre_match_views(ws, 48, 64, 3, C.byref(tgt), ws, 0, 3, None) == -1 and b'laid out' in lib.sucre_last_error()
+    # round 3 entry points
+    cam = _lib.SucreView()
+    assert lib.sucre_project_points(None, ws, 4, ws, None) == -1 and b'view is NULL' in lib.sucre_last_error()
+    assert lib.sucre_project_points(C.byref(cam), ws, 4, ws, None) == -1 and b'sensor size' in lib.sucre_last_error()
+    cam.H, cam.W = 48, 64
+    assert lib.sucre_project_points(C.byref(cam), ws, -1, ws, None) == -2
+    assert lib.sucre_project_points(C.byref(cam), None, 4, ws, None) == -1
+    assert lib.sucre_project_points(C.byref(cam), None, 0, None, None) == 0          # nothing to do, nothing launched
+    assert lib.sucre_pack_view(ws, ws, 0, 64, ws, None) == -1 and b'image size' in lib.sucre_last_error()
+    assert lib.sucre_pack_view(ws, None, 48, 64, ws, None) == -1 and b'NULL' in lib.sucre_last_error()
+    assert lib.sucre_pack_view(ws, ws, 48, 64, C.c_void_p(260), None) == -1 and b'8-byte aligned' in lib.sucre_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
