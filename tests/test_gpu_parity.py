@@ -441,18 +441,30 @@ def test_light_model_closed_form_vs_oracle(golden):
 
 
 def test_light_model_closed_form_vs_reference_golden(golden):
-    """100 iterations against the reference. This mode is chaotic in the reference itself on the relief fixture
-    (two batch orders differ by 2.8e-3 in the water parameters, 1.8e-2 RMS in red J; tests/test_oracle_golden.py),
-    so: tight over the first 50 iterations and in G/B, bounded by that self-noise elsewhere."""
+    """100 iterations against the reference.  This mode is chaotic in the reference itself on the relief fixture: its
+    runs at batch size 1 and 5 (tests/golden/light_closed_spread.npz, gen_golden_extras.py) drift apart by 2e-5 in the
+    parameters over the first 50 iterations and by 2.8e-3 after 100 (1.8e-2 RMS in red J).  The bars are therefore the
+    reference's OWN spread: at every iteration the engine lies within 3x the spread the two reference runs have reached
+    by then (plus 1e-4, the distance between the analytic and the autograd gradient on parameters that sit at Adam's
+    eps) of one of them; the cost of iteration 0 has no step behind it and is tight."""
     r, J, params, trace = _fit_light_engine(golden.scene, 100, closed=True)
-    rt = golden['trace_light_closed']
-    assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-5
-    assert np.abs(trace[:50, 1:] - rt[:50, 1:]).max() < 5e-4
-    assert np.abs(trace[:50, 0] / rt[:50, 0] - 1).max() < 5e-4
-    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 1e-2
-    Jr = golden['J_light_closed_100']
-    rms = helpers.rms_per_channel(J, Jr)
-    assert np.array_equal(np.isnan(J), np.isnan(Jr)) and rms[1:].max() < 2e-4 and rms[0] < 5e-2
+    sp = np.load(helpers.GOLDEN_DIR / 'light_closed_spread.npz')
+    t5, t1 = golden['trace_light_closed'], sp[f'{golden.name}_trace_bs1']
+    J5, J1 = golden['J_light_closed_100'], sp[f'{golden.name}_J_bs1']
+    assert abs(trace[0, 0] / t5[0, 0] - 1) < 1e-5
+    spread = np.maximum.accumulate(np.abs(t1[:, 1:] - t5[:, 1:]).max(axis=1))
+    d = np.minimum(np.abs(trace[:, 1:] - t5[:, 1:]).max(axis=1), np.abs(trace[:, 1:] - t1[:, 1:]).max(axis=1))
+    cspread = np.maximum.accumulate(np.abs(t1[:, 0] / t5[:, 0] - 1))
+    dc = np.minimum(np.abs(trace[:, 0] / t5[:, 0] - 1), np.abs(trace[:, 0] / t1[:, 0] - 1))
+    print(f'{golden.name}: parameters: engine {d[:50].max():.2e} / {d.max():.2e}, reference spread {spread[49]:.2e} / {spread[-1]:.2e} '
+          f'(first 50 / all 100 iterations); cost: engine {dc[:50].max():.2e} / {dc.max():.2e}, spread {cspread[49]:.2e} / {cspread[-1]:.2e}')
+    assert np.all(d <= 3 * spread + 1e-4), (d / (3 * spread + 1e-4)).max()
+    assert np.all(dc <= 3 * cspread + 1e-4), (dc / (3 * cspread + 1e-4)).max()
+    assert np.array_equal(np.isnan(J), np.isnan(J5))
+    Jspread = helpers.rms_per_channel(J1, J5)
+    rms = np.minimum(helpers.rms_per_channel(J, J5), helpers.rms_per_channel(J, J1))
+    print(f'   J: engine {rms}, reference spread {Jspread}')
+    assert np.all(rms <= 3 * Jspread + 2e-5), (rms, Jspread)
 
 
 def test_closed_form_does_not_depend_on_the_starting_J(golden):
