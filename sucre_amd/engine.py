@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -35,12 +36,16 @@ class DeviceView:
         ``rgb`` is NULL (see ``packed_records``)."""
         slot = '_struct_packed' if packed else '_struct'
         key = (self.depth.data_ptr(), self.rgb.data_ptr())
+        if packed and self.__dict__.get('_packed') is not None:
+            key = key + (self.__dict__['_packed'][1].data_ptr(),)   # the struct points into THESE records
         cached = self.__dict__.get(slot)
         if cached is not None and cached[0] == key:
             return cached[1]
         if packed:
             H, W = self.depth.shape
-            s = camera_struct(self.K, self.R, self.t, H, W, self.packed_records().data_ptr(), 0)
+            records = self.packed_records()
+            key = key + (records.data_ptr(),)
+            s = camera_struct(self.K, self.R, self.t, H, W, records.data_ptr(), 0)
         else:
             s = self._build_struct()
         self.__dict__[slot] = (key, s)
@@ -55,29 +60,32 @@ class DeviceView:
         if cached is not None and cached[0] == key:
             return cached[1]
         assert self.rgb.dtype == torch.uint8, 'packed records hold uint8 colours'
-        H, W = self.depth.shape
-        dev = self.depth.device
-        out = torch.empty(H * W * 8, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            side = _pack_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))   # the pixels may have been produced on the caller's stream
-            with torch.cuda.stream(side):
-                _lib.check(_lib.load().sucre_pack_view(C.c_void_p(self.depth.data_ptr()), C.c_void_p(self.rgb.data_ptr()), H, W,
-                                                       C.c_void_p(out.data_ptr()), _stream_ptr()))
-                done = torch.cuda.Event()
-                done.record()
-        self.__dict__['_packed'] = (key, out, done)
-        self.__dict__['_packed_pending'] = True
-        return out
+        with _PACK_LOCK:   # the CLI decodes and submits on several threads: a view's records are built once and never replaced
+            cached = self.__dict__.get('_packed')   # (a struct handed to a launch points into them)
+            if cached is not None and cached[0] == key:
+                return cached[1]
+            H, W = self.depth.shape
+            dev = self.depth.device
+            out = torch.empty(H * W * 8, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                side = _pack_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))   # the pixels may have been produced on the caller's stream
+                with torch.cuda.stream(side):
+                    _lib.check(_lib.load().sucre_pack_view(C.c_void_p(self.depth.data_ptr()), C.c_void_p(self.rgb.data_ptr()), H, W,
+                                                           C.c_void_p(out.data_ptr()), _stream_ptr()))
+                    done = torch.cuda.Event()
+                    done.record()
+            self.__dict__['_packed'] = [key, out, done, True]   # one entry: records, their event and "not known complete yet"
+            return out
 
     def wait_packed(self) -> None:
         """Makes the current stream wait for this view's records (nothing once they are known to be complete)."""
-        if self.__dict__.get('_packed_pending'):
-            done = self.__dict__['_packed'][2]
-            if done.query():
-                self.__dict__['_packed_pending'] = False
+        entry = self.__dict__.get('_packed')
+        if entry is not None and entry[3]:
+            if entry[2].query():
+                entry[3] = False
             else:
-                torch.cuda.current_stream(self.depth.device).wait_event(done)
+                torch.cuda.current_stream(self.depth.device).wait_event(entry[2])
 
     def as_float_colour(self) -> 'DeviceView':
         """This view with float32 colours (float32(float64(k)/255), loader.py:157-163): used when other views of the
@@ -131,6 +139,7 @@ def project_points(view: _lib.SucreView, wP: torch.Tensor) -> torch.Tensor:
 
 
 _PACK_STREAMS: dict = {}
+_PACK_LOCK = threading.Lock()
 
 
 def _pack_stream(dev) -> 'torch.cuda.Stream':
