@@ -49,7 +49,8 @@ def test_two_processes_shared_water_hip_backend(golden, tmp_path):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('extra', [[], ['--shared-water']], ids=['per-image', 'shared-water'])
+@pytest.mark.parametrize('extra', [[], ['--shared-water'], ['--shared-water', '--batch-images', '2', '--use-closed-form']],
+                         ids=['per-image', 'shared-water', 'shared-water-group-closed'])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` with no launcher environment starts two ranks itself and rank 0 prints one JSON
     line that saw both of them."""
