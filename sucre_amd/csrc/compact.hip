@@ -80,51 +80,107 @@ __global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__rest
     if (t < num_bins(n_views)) blockhist[(size_t)t * n_tiles + tile] = hist[t];
 }
 
+// Inclusive scan of one value per lane over the wave.
+template <class T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
 // 2a. exclusive scan of every bin's column over the blocks (one workgroup per bin); totals[bin] = column sum.
+//     The column passes through LDS 8192 elements at a time: coalesced in, every thread scans a run of 32 consecutive
+//     elements (index i sits at i + i/32: the runs start in different banks), the run totals are scanned by shuffles,
+//     coalesced out.  (The first version read and rewrote the runs in global memory, one dependent load after the
+//     other, and scanned the 256 run totals on one thread: 16.6 us per image.)
+constexpr int kScanRun = 32;
+constexpr int kScanChunk = 256 * kScanRun;
+
 __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t *__restrict__ blockhist, int n_tiles,
                                                        uint32_t *__restrict__ totals) {
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t buf[kScanChunk + kScanChunk / 32];
+    __shared__ uint32_t wsum[4];
     uint32_t *col = blockhist + (size_t)blockIdx.x * n_tiles;
-    const int t = threadIdx.x;
-    const int per = (n_tiles + 255) / 256;
-    const int lo = t * per, hi = min(lo + per, n_tiles);
-    uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += col[i];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < 256; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
-        totals[blockIdx.x] = run;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t carry = 0;
+    for (int c0 = 0; c0 < n_tiles; c0 += kScanChunk) {
+        const int n = min(kScanChunk, n_tiles - c0);
+#pragma unroll
+        for (int r = 0; r < kScanRun; ++r) {
+            const int i = t + 256 * r;
+            buf[i + (i >> 5)] = i < n ? col[c0 + i] : 0u;
+        }
+        __syncthreads();
+        uint32_t v[kScanRun], s = 0;
+#pragma unroll
+        for (int r = 0; r < kScanRun; ++r) { v[r] = buf[33 * t + r]; s += v[r]; }
+        const uint32_t incl = wave_inclusive_scan(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = carry + incl - s;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+        for (int r = 0; r < kScanRun; ++r) { buf[33 * t + r] = run; run += v[r]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kScanRun; ++r) {
+            const int i = t + 256 * r;
+            if (i < n) col[c0 + i] = buf[i + (i >> 5)];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t run = part[t];
-    for (int i = lo; i < hi; ++i) { const uint32_t v = col[i]; col[i] = run; run += v; }
+    if (t == 0) totals[blockIdx.x] = carry;
 }
 
-// 2b. start of every bin in the sorted order: bins with more observations first.
-__global__ void bin_base_kernel(const uint32_t *__restrict__ totals, int bins, uint32_t *__restrict__ bin_base) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = bins - 1; b >= 0; --b) { bin_base[b] = run; run += totals[b]; }
-    }
-}
-
-// 2c. stable destination of every pixel: bin start + pixels of the same bin in earlier blocks + earlier threads
-//     of this block in the same bin.
+// 2b. stable destination of every pixel: bin start + pixels of the same bin in earlier blocks + earlier threads
+//     of this block in the same bin.  Bin starts: bins with more observations first = the suffix sums of the bins'
+//     totals, which every workgroup works out for itself (<= 256 values; a launch of its own took 5 us).  Rank inside
+//     the block: the wave walks its distinct bins (neighbouring pixels: a handful), one ballot each -- a lane's rank is
+//     the lanes below it in its bin's ballot, plus the bin's pixels in the waves before it.  (A loop over all earlier
+//     threads took 26 us per image.)
 __global__ __launch_bounds__(256) void permute_kernel(const uint16_t *__restrict__ pcount,
                                                       const uint32_t *__restrict__ blockhist,
-                                                      const uint32_t *__restrict__ bin_base, int n_views, int n_tiles,
+                                                      const uint32_t *__restrict__ totals, int n_views, int n_tiles,
                                                       uint32_t *__restrict__ perm, uint32_t *__restrict__ invperm) {
-    __shared__ int bins_of[kTilePx];
-    const int tile = blockIdx.x, t = threadIdx.x;
+    __shared__ uint32_t base[kMaxBins];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wcount[4][kMaxBins];
+    const int tile = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int bins = num_bins(n_views);
     const uint32_t src = (uint32_t)tile * kTilePx + t;
     const int b = bin_of(pcount[src], n_views);
-    bins_of[t] = b;
-    __syncthreads();
+    const uint32_t before = blockhist[(size_t)b * n_tiles + tile];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcount[w][t] = 0;
+    {   // base[b] = pixels of the bins above b: thread t takes bin bins-1-t
+        const uint32_t v = t < bins ? totals[bins - 1 - t] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - v;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        if (t < bins) base[bins - 1 - t] = run;
+    }
     uint32_t rank = 0;
-    for (int i = 0; i < t; ++i) rank += bins_of[i] == b ? 1u : 0u;  // lock-step broadcast reads
-    const uint32_t dst = bin_base[b] + blockhist[(size_t)b * n_tiles + tile] + rank;
+    unsigned long long todo = __ballot(1);
+    while (todo) {   // wave-uniform
+        const int bb = __shfl(b, __ffsll((long long)todo) - 1, 64);
+        const unsigned long long same = __ballot(b == bb);
+        if (b == bb) {
+            const unsigned long long below = same & ((1ull << lane) - 1ull);
+            rank = (uint32_t)__builtin_popcountll(below);
+            if (below == 0ull) wcount[wave][bb] = (uint32_t)__builtin_popcountll(same);
+        }
+        todo &= ~same;
+    }
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) rank += wcount[w][b];
+    const uint32_t dst = base[b] + before + rank;
     perm[dst] = src;
     invperm[src] = dst;
 }
@@ -164,24 +220,36 @@ __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__res
     const int per = (n_tiles + 1023) / 1024;
     const int lo = min(t * per, n_tiles), hi = min(lo + per, n_tiles);
     unsigned long long s = 0;
-    for (int i = lo; i < hi; ++i) s += tile_levels[i];
-    unsigned long long incl = s;   // inclusive scan over the wave
+    for (int i0 = lo; i0 < hi; i0 += 8) {   // eight loads in flight, not one after the other
+        uint32_t v[8];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+        for (int r = 0; r < 8; ++r) v[r] = i0 + r < hi ? tile_levels[i0 + r] : 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += v[r];
     }
+    const unsigned long long incl = wave_inclusive_scan(s);
     if (lane == 63) wave_base[wave] = incl;
     __syncthreads();
+    unsigned long long run = incl - s, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        const unsigned long long v = wave_base[w];
+        if (w < wave) run += v;
+        total += v;
+    }
     if (t == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 16; ++i) { const unsigned long long v = wave_base[i]; wave_base[i] = run; run += v; }
-        *total_levels = run;
+        *total_levels = total;
         *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
     }
-    __syncthreads();
-    unsigned long long run = wave_base[wave] + incl - s;
-    for (int i = lo; i < hi; ++i) { tile_off[i] = run; run += tile_levels[i]; }
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = i0 + r < hi ? tile_levels[i0 + r] : 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (i0 + r < hi) tile_off[i0 + r] = run;
+            run += v[r];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict__ meta, const uint64_t *__restrict__ tile_off,
@@ -195,6 +263,69 @@ __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict
         m->lvoff = run;
         run += m->levels;
     }
+}
+
+// 3 (fewer than 255 views).  A pixel's bin IS its count then, so the sorted order's counts follow from the bins' totals
+//     alone: bin b occupies the sorted positions [start_b, start_b + totals_b), a strip's largest count is the bin of
+//     its first pixel, its smallest the bin of its last, and the strips that START inside bin b all have b levels -- the
+//     offset of strip s is (levels of the strips starting in heavier bins) + (s - first strip of its bin) * b.  One launch,
+//     one thread per strip, a 256-entry table per workgroup: replaces strip_levels (a gather through perm), the scan of
+//     the tiles' totals and strip_offset (8 + 13 + 5 us per image).  With 255 views or more the bins are coarser than
+//     the counts and the three kernels above do the work.
+__global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__restrict__ totals, int n_views, int n_strips,
+                                                          StripMeta *__restrict__ meta, uint64_t *__restrict__ total_levels,
+                                                          int fmt) {
+    __shared__ uint32_t start[kMaxBins];              // entry i: the bin of count bins-1-i (heaviest first)
+    __shared__ uint32_t first[kMaxBins];              // first strip that starts inside the bin
+    __shared__ unsigned long long before[kMaxBins];   // levels of all strips starting in heavier bins
+    __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long wsum64[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int bins = num_bins(n_views);
+    {
+        const uint32_t v = t < bins ? totals[bins - 1 - t] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t st = incl - v;
+        for (int w = 0; w < wave; ++w) st += wsum[w];
+        const uint32_t fs = (st + kStripPx - 1) / kStripPx, fe = (st + v + kStripPx - 1) / kStripPx;
+        const unsigned long long lv = t < bins ? (unsigned long long)(fe - fs) * (unsigned)(bins - 1 - t) : 0ull;
+        const unsigned long long incl64 = wave_inclusive_scan(lv);
+        if (lane == 63) wsum64[wave] = incl64;
+        __syncthreads();
+        unsigned long long bf = incl64 - lv, total = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) bf += wsum64[w];
+            total += wsum64[w];
+        }
+        start[t] = t < bins ? st : 0xffffffffu;
+        first[t] = fs;
+        before[t] = bf;
+        if (blockIdx.x == 0 && t == 0) {
+            *total_levels = total;
+            *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
+        }
+        __syncthreads();
+    }
+    const int s = blockIdx.x * 256 + t;
+    if (s >= n_strips) return;
+    auto bin_at = [&](uint32_t p) {   // last i with start[i] <= p
+        int lo = 0, hi = kMaxBins;    // start[lo] <= p < start[hi] (start[0] = 0; entries past the bins are UINT_MAX)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (start[mid] <= p) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t p = (uint32_t)s * kStripPx;
+    const int i = bin_at(p), j = bin_at(p + kStripPx - 1);
+    const uint32_t levels = (uint32_t)(bins - 1 - i);
+    StripMeta m;
+    m.lvoff = before[i] + (unsigned long long)((uint32_t)s - first[i]) * levels;
+    m.levels = levels;
+    m.full = (uint32_t)(bins - 1 - j);
+    meta[s] = m;
 }
 
 // 3c. the compaction itself, driven from the DENSE side.  One workgroup owns one dense tile: it stages the tile's
@@ -434,7 +565,6 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     auto *pmask = reinterpret_cast<uint64_t *>(ws + L.off_pmask);
     auto *blockhist = reinterpret_cast<uint32_t *>(ws + L.off_blockhist);
     auto *totals = reinterpret_cast<uint32_t *>(ws + L.off_bin_totals);
-    auto *bin_base = totals + kMaxBins;
     auto *perm = reinterpret_cast<uint32_t *>(ws + L.off_perm);
     auto *invperm = reinterpret_cast<uint32_t *>(ws + L.off_invperm);
     auto *meta = reinterpret_cast<StripMeta *>(ws + L.off_strip_meta);
@@ -442,16 +572,20 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(ws + L.off_vbits),
                        pmask, L.mask_words, keep, L.n_views, L.n_tiles, pcount, blockhist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), dim3(256), 0, s, blockhist, L.n_tiles, totals);
-    hipLaunchKernelGGL(bin_base_kernel, dim3(1), dim3(64), 0, s, totals, bins, bin_base);
-    hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, bin_base, L.n_views,
+    hipLaunchKernelGGL(permute_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, blockhist, totals, L.n_views,
                        L.n_tiles, perm, invperm);
-    // the counting sort is done with its histograms: their space holds the sorted tiles' totals and offsets
-    auto *tile_levels = blockhist;
-    auto *tile_off = reinterpret_cast<uint64_t *>(blockhist + align_up((size_t)L.n_tiles, 2));
-    hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels);
-    hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(1024), 0, s, tile_levels, L.n_tiles, tile_off,
-                       reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
-    hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles);
+    if (L.n_views < kMaxBins - 1) {
+        hipLaunchKernelGGL(strip_table_kernel, dim3((L.n_strips + 255) / 256), dim3(256), 0, s, totals, L.n_views, L.n_strips,
+                           meta, reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+    } else {
+        // the counting sort is done with its histograms: their space holds the sorted tiles' totals and offsets
+        auto *tile_levels = blockhist;
+        auto *tile_off = reinterpret_cast<uint64_t *>(blockhist + align_up((size_t)L.n_tiles, 2));
+        hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels);
+        hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(1024), 0, s, tile_levels, L.n_tiles, tile_off,
+                           reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+        hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles);
+    }
     const dim3 grid(L.n_tiles), block(256);
     const uint8_t *obs = ws + L.off_obs;
     uint8_t *comp = ws + L.off_comp;

@@ -77,6 +77,7 @@ struct Layout {
     size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [1]: observation format of the compact store (SUCRE_OBS_*)
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]
+    size_t off_view_partial;// uint32 [ceil(n_tiles / 32)][n_views]  match counts of 32 tiles per view (finalize)
     size_t off_n_obs;       // uint64 [1]
     size_t off_n_obs_total; // uint64 [1]
     size_t off_params;      // float  [9] params, [9] exp_avg, [9] exp_avg_sq
@@ -121,6 +122,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_total_chunks = take(sizeof(uint64_t));
     L->off_view_count = take(nv * sizeof(uint64_t));
     L->off_view_keep = take(nv * sizeof(uint32_t));
+    L->off_view_partial = take((nt + 31) / 32 * nv * sizeof(uint32_t));
     L->off_n_obs = take(sizeof(uint64_t));
     L->off_n_obs_total = take(sizeof(uint64_t));
     L->off_params = take(27 * sizeof(float));

@@ -57,6 +57,38 @@ __device__ __forceinline__ void rigid(const float *R, const float *t, const floa
     out[2] = dot3(R + 6, p[0], p[1], p[2]) + t[2];
 }
 
+// x / z and y / z as far as their users can tell.  Everything downstream of the two IEEE quotients of sfm.py:106 is a
+// comparison with an integer (-1 < d, d < W) or Tensor.long() (truncation), so a quotient may be replaced by any value
+// that lies strictly between the same two consecutive integers.  a = x * rcp(z) is within 1.5 * 2^-23 |a| of the real
+// quotient (v_rcp_f32: 1 ulp; the product: half an ulp), and the correctly rounded quotient is monotone and reaches an
+// integer n only from within half an ulp of n (<= 2^-24 (|a| + 1)): if a is farther than 2^-21 |a| + 2^-23 from every
+// integer -- more than twice those bounds together -- truncation and bound tests of a ARE those of the IEEE quotient.
+// Otherwise (a within that margin of an integer: ~0.1 % of the lanes at a = 1000; or a NaN / infinite / zero, which
+// covers a denormal or zero z) the whole wave takes the two IEEE divisions.  12 instructions instead of 22 per pair of
+// quotients, four pairs per matching pixel pair; the match sets keep equal to the reference's bit for bit
+// (SUCRE_EXACT_DIV=1 builds the plain form; tests/test_gpu_parity.py compares the two).
+#ifndef SUCRE_EXACT_DIV
+#define SUCRE_EXACT_DIV 0
+#endif
+__device__ __forceinline__ void pixel_quotients(float x, float y, float z, float *px, float *py) {
+#if SUCRE_EXACT_DIV
+    *px = x / z;
+    *py = y / z;
+#else
+    const float rc = __builtin_amdgcn_rcpf(z);
+    float ax = x * rc, ay = y * rc;
+    const float sx = __builtin_fmaf(-__builtin_fabsf(ax), 0x1p-21f, __builtin_fabsf(ax - __builtin_rintf(ax)));
+    const float sy = __builtin_fmaf(-__builtin_fabsf(ay), 0x1p-21f, __builtin_fabsf(ay - __builtin_rintf(ay)));
+    const bool unsure = !(sx > 0x1p-23f) || !(sy > 0x1p-23f);   // NaN lands here too
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
+        ax = x / z;
+        ay = y / z;
+    }
+    *px = ax;
+    *py = ay;
+#endif
+}
+
 // sfm.py:103-107,116-117: world point -> continuous pixel; true when Tensor.long() of it lies inside WxH.
 // trunc(x) in [0, W-1]  <=>  -1 < x < W ; NaN and +-inf fail both comparisons like INT64_MIN fails the bound test.
 __device__ __forceinline__ bool project(const float *Rinv, const float *tinv, const float *K, bool pin, float Wf, float Hf,
@@ -64,8 +96,7 @@ __device__ __forceinline__ bool project(const float *Rinv, const float *tinv, co
     float cP[3], c[3];
     rigid(Rinv, tinv, wP, cP);
     mul3(K, pin, cP[0], cP[1], cP[2], c);
-    *px = c[0] / c[2];
-    *py = c[1] / c[2];
+    pixel_quotients(c[0], c[1], c[2], px, py);
     return (*px > -1.0f) && (*px < Wf) && (*py > -1.0f) && (*py < Hf);
 }
 
@@ -285,36 +316,74 @@ __global__ __launch_bounds__(256) void project_points_kernel(const CamDev cam, c
     pix[i] = inside ? (int32_t)py * cam.W + (int32_t)px : -1;
 }
 
-// len(matches) per view and the min_cover rule of sfm.py:136 (Python int/int true division, strict >).
-__global__ __launch_bounds__(256) void view_count_kernel(const uint16_t *__restrict__ cnt, int n_tiles, int n_views,
-                                                         double min_cover, double hw,
-                                                         uint64_t *__restrict__ view_count,
-                                                         uint32_t *__restrict__ view_keep) {
-    __shared__ unsigned long long part[256];
-    const int k = blockIdx.x;
-    unsigned long long s = 0;
-    for (int tile = threadIdx.x; tile < n_tiles; tile += 256) s += cnt[(size_t)tile * n_views + k];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        view_count[k] = part[0];
-        view_keep[k] = ((double)part[0] / hw > min_cover) ? 1u : 0u;
+// len(matches) per view, the min_cover rule of sfm.py:136 (Python int/int true division, strict >) and
+// n_obs = len(matches_data) (loader.py:52-53: matches of the kept views), in two small launches: every workgroup of the
+// first adds up the counts of kStatTiles tiles for all views (lanes on views: the [tile][view] table is read in rows,
+// 32 loads in flight per thread), the single workgroup of the second adds the partial rows up.  (One workgroup per view
+// walking the table down a column -- 130-byte strides -- took 18 + 5 us per image.)
+constexpr int kStatTiles = 32;
+
+__global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__restrict__ cnt, int n_tiles, int n_views,
+                                                           uint32_t *__restrict__ partial) {
+    const int t0 = blockIdx.x * kStatTiles, n = min(kStatTiles, n_tiles - t0);
+    for (int k = threadIdx.x; k < n_views; k += 256) {
+        const uint16_t *p = cnt + (size_t)t0 * n_views + k;
+        uint32_t s = 0;
+        if (n == kStatTiles) {
+#pragma unroll
+            for (int i = 0; i < kStatTiles; ++i) s += p[(size_t)i * n_views];
+        } else {
+            for (int i = 0; i < n; ++i) s += p[(size_t)i * n_views];
+        }
+        partial[(size_t)blockIdx.x * n_views + k] = s;
     }
 }
 
-// n_obs = len(matches_data) (loader.py:52-53): matches of the kept views.
-__global__ __launch_bounds__(64) void n_obs_kernel(const uint32_t *__restrict__ view_keep,
-                                                   const uint64_t *__restrict__ view_count, int n_views,
-                                                   uint64_t *__restrict__ n_obs, uint64_t *__restrict__ n_obs_total) {
-    const int lane = threadIdx.x;
-    unsigned long long s = 0;
-    for (int k = lane; k < n_views; k += 64) s += view_keep[k] ? view_count[k] : 0ull;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) { *n_obs = s; *n_obs_total = s; }
+__global__ __launch_bounds__(1024) void view_total_kernel(const uint32_t *__restrict__ partial, int n_rows, int n_views,
+                                                          double min_cover, double hw, uint64_t *__restrict__ view_count,
+                                                          uint32_t *__restrict__ view_keep, uint64_t *__restrict__ n_obs,
+                                                          uint64_t *__restrict__ n_obs_total) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long wsum[16];
+    const int t = threadIdx.x;
+    int kc = 64;   // views side by side (a power of two), 1024 / kc slices of the partial rows
+    while (kc < n_views && kc < 1024) kc <<= 1;
+    const int slices = 1024 / kc, k0 = t & (kc - 1), r = t / kc;
+    unsigned long long kept = 0;
+    for (int kb = 0; kb < n_views; kb += kc) {
+        const int k = kb + k0;
+        unsigned long long s = 0;
+        if (k < n_views) {
+            int i = r;
+            for (; i + 7 * slices < n_rows; i += 8 * slices) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(i + j * slices) * n_views + k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            for (; i < n_rows; i += slices) s += partial[(size_t)i * n_views + k];
+        }
+        part[t] = s;
+        __syncthreads();
+        if (r == 0 && k < n_views) {
+            for (int j = 1; j < slices; ++j) s += part[j * kc + k0];
+            const bool keep = (double)s / hw > min_cover;
+            view_count[k] = s;
+            view_keep[k] = keep ? 1u : 0u;
+            if (keep) kept += s;
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = kept;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < 16; ++w) total += wsum[w];
+        *n_obs = total;
+        *n_obs_total = total;
+    }
 }
 
 __global__ __launch_bounds__(256) void export_view_kernel(const uint8_t *__restrict__ obs,
@@ -539,10 +608,11 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
     auto *cnt = reinterpret_cast<const uint16_t *>(ws + L.off_cnt);
     auto *vc = reinterpret_cast<uint64_t *>(ws + L.off_view_count);
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
-    hipLaunchKernelGGL(view_count_kernel, dim3(L.n_views), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, min_cover,
-                       (double)L.W * (double)L.H, vc, vk);
-    hipLaunchKernelGGL(n_obs_kernel, dim3(1), dim3(64), 0, s, vk, vc, L.n_views,
-                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
+    auto *partial = reinterpret_cast<uint32_t *>(ws + L.off_view_partial);
+    const int rows = (L.n_tiles + kStatTiles - 1) / kStatTiles;
+    hipLaunchKernelGGL(view_partial_kernel, dim3(rows), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, partial);
+    hipLaunchKernelGGL(view_total_kernel, dim3(1), dim3(1024), 0, s, partial, rows, L.n_views, min_cover,
+                       (double)L.W * (double)L.H, vc, vk, reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
                        reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_compact(L, ws, s, ext_dense, ext_comp, fmt, ext2_dense, ext2_comp);

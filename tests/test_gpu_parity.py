@@ -750,3 +750,45 @@ def test_packed_neighbour_views_change_nothing(golden, monkeypatch):
     for ma, mb in zip(a[2], b[2]):
         assert np.array_equal(ma, mb)
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4], equal_nan=True)
+
+
+def test_pixel_quotients_on_the_integer_boundaries():
+    """csrc/match.hip replaces the IEEE quotients x/z, y/z of sfm.py:106 by x * rcp(z) wherever that provably truncates
+    and bound-tests like the IEEE quotient, and falls back to the division otherwise.  Adversarial inputs: quotients
+    within a few ulps of every integer of a 4096-pixel sensor (both sides, and exactly on it), tiny / huge / zero /
+    negative / non-finite z, quotients around -1, 0 and W.  With K = R = identity and t = 0 every chain of the projection
+    is exact, so the expected pixel is numpy's float32 division, truncated (Tensor.long()) and bound-tested."""
+    from sucre_amd import engine
+    rng = np.random.default_rng(11)
+    W, H = 4096, 3000
+    n_int = np.arange(-2, W + 3, dtype=np.float64)
+    xs, ys, zs = [], [], []
+    for scale in (1.0, 0.37, 5.3, 911.0, 1e-3, 3e-30, 7e29):
+        z = (rng.uniform(0.5, 1.0, n_int.size) * scale).astype(np.float32)
+        for k in range(-6, 7):
+            # x such that x / z lands k float32 steps from the integer: the division then rounds onto it or next to it
+            q = np.nextafter(n_int.astype(np.float32), np.float32(np.inf if k > 0 else -np.inf)) if k else n_int.astype(np.float32)
+            for _ in range(abs(k) - 1 if k else 0):
+                q = np.nextafter(q, np.float32(np.inf if k > 0 else -np.inf))
+            x = (q.astype(np.float64) * z.astype(np.float64)).astype(np.float32)
+            xs.append(x); zs.append(z)
+            ys.append((rng.uniform(0, H, n_int.size) * z).astype(np.float32))
+    # general random points, plus the special values
+    zr = rng.normal(0, 3, 2_000_000).astype(np.float32)
+    xs.append((rng.uniform(-50, W + 50, zr.size) * zr).astype(np.float32)); ys.append((rng.uniform(-50, H + 50, zr.size) * zr).astype(np.float32)); zs.append(zr)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 3e38], dtype=np.float32)
+    sx, sz = np.meshgrid(np.concatenate([special, np.float32([1.0, 100.5, -3.0])]), np.concatenate([special, np.float32([1.0, 2.0])]))
+    xs.append(sx.ravel()); zs.append(sz.ravel()); ys.append(np.full(sx.size, 5.0, np.float32) * np.where(np.isfinite(sz.ravel()), sz.ravel(), 1).astype(np.float32))
+    x, y, z = (np.concatenate(a).astype(np.float32) for a in (xs, ys, zs))
+    # swap the roles of x and y for a second half, so the rows get the boundary treatment too
+    X, Y, Z = np.concatenate([x, y]), np.concatenate([y, x]), np.concatenate([z, z])
+    with np.errstate(all='ignore'):
+        px, py = X / Z, Y / Z
+        inside = (px > -1) & (px < W) & (py > -1) & (py < H) & np.isfinite(X) & np.isfinite(Y) & np.isfinite(Z)   # 0 * inf = NaN in the chains
+        expect = np.where(inside, np.trunc(np.where(inside, py, 0)).astype(np.int64) * W + np.trunc(np.where(inside, px, 0)).astype(np.int64), -1)
+    eye = torch.eye(3)
+    cam = engine.camera_struct(eye, eye, torch.zeros(3), H, W)
+    got = engine.project_points(cam, torch.from_numpy(np.stack([X, Y, Z])).cuda()).cpu().numpy()
+    bad = np.flatnonzero(got != expect)
+    assert bad.size == 0, (bad.size, X[bad[:5]], Y[bad[:5]], Z[bad[:5]], got[bad[:5]], expect[bad[:5]])
+    assert inside.sum() > 100_000 and (~inside).sum() > 100_000
