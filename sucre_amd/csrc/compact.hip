@@ -39,40 +39,51 @@ __device__ __forceinline__ void keep_words(const uint32_t *__restrict__ view_kee
     __syncthreads();
 }
 
+// 64 x 64 bit-matrix transpose across the wave: lane i holds row i, and gets column i back (bit r of the result of
+// lane c = bit c of the input of lane r).  Six butterfly stages: at distance s the lanes pair up, and the off-diagonal
+// blocks of every 2s x 2s block swap.
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
+    const int lane = threadIdx.x & 63;
+    constexpr uint64_t kLow[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull, 0x00ff00ff00ff00ffull,
+                                  0x0f0f0f0f0f0f0f0full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        const int s = 32 >> st;
+        const uint64_t m = kLow[st];
+        const uint64_t xp = __shfl_xor((unsigned long long)x, s, 64);
+        x = (lane & s) ? (((xp >> s) & m) | (x & ~m)) : ((x & m) | ((xp & m) << s));
+    }
+    return x;
+}
+
 // 1. per-pixel observation count over the kept views + per-block histogram (blockhist is bin-major), from the views'
 //    pixel bits (`vbits`: 32 bytes per (tile, view), written by whatever filled view k: match_kernel, or
 //    count_view_kernel after an import) -- the dense ranges are not read again (that pass took 129 us per image).
-//    Also writes every pixel's mask of kept views (`pmask`), which drives the scatter.
-constexpr int kBitsStage = 256;   // views whose bits are staged in LDS at a time (8 KB)
-
+//    Also writes every pixel's mask of kept views (`pmask`), which drives the scatter.  Wave j owns the pixels
+//    64 j .. 64 j + 63 (word j of the views' bits): lane i fetches word j of view 64 w + i, a bit-matrix transpose hands
+//    lane l the 64 views' bits of pixel 64 j + l = word w of its mask.  (Collecting the word bit by bit from a copy of
+//    the bits in LDS cost ~650 instructions per thread and 64 views: 39 us per image.)
 __global__ __launch_bounds__(256) void pixel_count_kernel(const uint64_t *__restrict__ vbits, uint64_t *__restrict__ pmask,
                                                           int mask_words, const uint32_t *__restrict__ view_keep,
                                                           int n_views, int n_tiles, uint16_t *__restrict__ pcount,
                                                           uint32_t *__restrict__ blockhist) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint64_t keep[kMaxViews / 64];
-    __shared__ uint64_t vb[kBitsStage][4];
     const int tile = blockIdx.x, t = threadIdx.x;
+    const int l = t & 63, j = t >> 6;   // slot t = 64 j + l: bit l of word j
+    const uint64_t *rows = vbits + (size_t)tile * n_views * 4 + j;
+    uint64_t x0 = l < n_views ? rows[(size_t)l * 4] : 0ull;   // in flight while the keep words are built
     hist[t] = 0;
     keep_words(view_keep, n_views, mask_words, keep);
-    const int l = t & 63, j = t >> 6;   // slot t = 64 j + l: bit l of word j
     uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
     uint32_t c = 0;
-    for (int base = 0; base < n_views; base += kBitsStage) {
-        const int nv = min(kBitsStage, n_views - base);
-        __syncthreads();
-        for (int i = t; i < nv * 4; i += 256) vb[i >> 2][i & 3] = vbits[((size_t)tile * n_views + base) * 4 + i];
-        __syncthreads();
-        for (int w0 = 0; w0 < nv; w0 += 64) {   // one 64-bit word of the pixel's mask
-            const int wv = (base + w0) >> 6;
-            const uint64_t kw = keep[wv];
-            uint64_t word = 0ull;
-            const int n = min(64, nv - w0);
-            for (int i = 0; i < n; ++i) word |= ((vb[w0 + i][j] >> l) & 1ull) << i;
-            word &= kw;
-            mask[wv] = word;
-            c += (uint32_t)__builtin_popcountll(word);
-        }
+    for (int wv = 0; wv < mask_words; ++wv) {
+        const int next = (wv + 1) * 64 + l;
+        const uint64_t x1 = next < n_views ? rows[(size_t)next * 4] : 0ull;
+        const uint64_t word = wave_transpose64(x0) & keep[wv];
+        mask[wv] = word;
+        c += (uint32_t)__builtin_popcountll(word);
+        x0 = x1;
     }
     pcount[(size_t)tile * kTilePx + t] = (uint16_t)c;
     atomicAdd(&hist[bin_of(c, n_views)], 1u);  // integer LDS atomics: order-independent result

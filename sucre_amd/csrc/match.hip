@@ -151,8 +151,10 @@ constexpr int kViewsPerGroup = 16;
 // memory-level parallelism: 112 VGPRs, 4 waves/SIMD instead of 7, +5 %; (d) global_load instead of flat_load gathers:
 // +-0 (kept: it is what the pointers are); (e) per-pixel view masks combined in the kernel -- the four waves' bits
 // through LDS behind a barrier: +6 % (the fast waves wait); one wave per 16 views, no barrier: +11 % (32 K long waves
-// quantise badly over the SIMDs).  The kernel sits at ~70 % VALU occupancy on its dependent gather -> IEEE-division
-// chains, and bit parity with torch fixes those chains.
+// quantise badly over the SIMDs); (f) the dense chunks written with nontemporal stores, so that they do not push the
+// views' records out of L2: -1 % (the run-to-run noise).  The final kernel is 89 % VALU-busy (profiles/r03_jparam_summary.
+// txt), and bit parity with torch fixes its chains -- except the four quotients, which only feed truncations and bound
+// tests (pixel_quotients): -2.3 %, same box.
 //
 // kExt: extension planes are written (`ext`: the camera points, or float32 colours with SUCRE_EXT_COLOUR).
 // kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
