@@ -33,3 +33,11 @@ constexpr bool kExpNoLoad = false;
 #ifndef SUCRE_DMA_POLICY
 #define SUCRE_DMA_POLICY " nt"
 #endif
+
+// match.hip: the pixel quotients x/z, y/z as two IEEE divisions everywhere (1) instead of x * rcp(z) with the divisions
+// as the fallback near integers (0, the product; same match sets by construction -- DESIGN.md section 4.1; the A/B of
+// tools/exp/ab_lib.sh exactdiv).
+#ifndef SUCRE_EXACT_DIV
+#define SUCRE_EXACT_DIV 0
+#endif
+constexpr bool kExactDiv = SUCRE_EXACT_DIV != 0;

@@ -17,6 +17,17 @@ __device__ __forceinline__ float unit_from_u8(uint32_t k) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// v_exp_f32 flushes results below 2^-126 to zero; torch.exp underflows gradually.  Nothing in a gradient can tell the
+// two apart, but the closed-form J = sum(y a) / sum(a^2) of a pixel whose every a^2 underflows is +-inf with a denormal
+// a and 0/0 = NaN with a flushed one: the solves redo such a pixel with this form (3 more instructions, never on the
+// hot path).
+__device__ __forceinline__ float gradual_exp2(float x) {
+    const bool tiny = x < -126.0f;
+    return fast_exp2(tiny ? x + 64.0f : x) * (tiny ? 0x1p-64f : 1.0f);
+}
+template <bool kGradual>
+__device__ __forceinline__ float exp2_as(float x) { return kGradual ? gradual_exp2(x) : fast_exp2(x); }
+
 // torch/optim/adam.py::_single_tensor_adam (non-capturable, no amsgrad, no weight decay), float32
 __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, const AdamCoef &co) {
     m = __builtin_fmaf(co.w1, g - m, m);

@@ -14,6 +14,7 @@
 // workgroup: fixed-order float64 reduction, chain rule through Sigma^-1 and through the matrix exponential -- six 8x8
 // block exponentials evaluated in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1, log row).
 // Plain loads instead of the LDS-DMA ring: the kernel is VALU-bound (~150 instructions per observation).
+#include <type_traits>
 #include "fit_math.h"
 
 namespace sucre {
@@ -155,6 +156,7 @@ struct LightAcc {
 // l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
 struct LightObs { float l, z, nl, inl, iz, lp0, lp1, w0, w1, lP[3]; };
 
+template <bool kGradual = false>
 __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const float (&R)[9], const float (&tl)[3],
                                               const float (&M)[4]) {
     LightObs o;
@@ -169,7 +171,7 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
     o.w0 = __builtin_fmaf(M[0], o.lp0, M[1] * o.lp1);   // M = (sigma^T sigma)^-1 is symmetric: M[1] == M[2]
     o.w1 = __builtin_fmaf(M[2], o.lp0, M[3] * o.lp1);
     const float q = __builtin_fmaf(o.lp0, o.w0, o.lp1 * o.w1);
-    o.l = fast_exp2(q * (-0.5f * kLog2e));
+    o.l = exp2_as<kGradual>(q * (-0.5f * kLog2e));
     const float n2 = __builtin_fmaf(o.lP[2], o.lP[2], __builtin_fmaf(o.lP[1], o.lP[1], o.lP[0] * o.lP[0]));
     o.inl = __builtin_amdgcn_rsqf(n2);
     o.nl = n2 * o.inl;
@@ -367,28 +369,41 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         float J[3];
         if (kClosed) {
             // closed-form J of this pixel: numerator / denominator per channel over all levels
-            float num[3] = {0.f, 0.f, 0.f}, den[3] = {0.f, 0.f, 0.f};
-            for (uint32_t g = 0; g < nch; ++g) {
-                const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
-                const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
-                ColourChunk fc;
-                if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
+            float num[3], den[3];
+            auto solve = [&](auto gradual) {
+                constexpr bool kGradual = decltype(gradual)::value;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!(kk.zz[j] > 0.0f)) continue;
-                    const float cP[3] = {kk.xx[j], kk.yy[j], kk.ww[j]};
-                    LightObs o;
-                    if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
-                    else o = light_obs(cP, kk.zz[j], R, tl, M);
+                for (int c = 0; c < 3; ++c) num[c] = den[c] = 0.f;
+                for (uint32_t g = 0; g < nch; ++g) {
+                    const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
+                    const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
+                    ColourChunk fc;
+                    if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float a = o.l * fast_exp2(o.z * nb[c]);
-                        const float b = o.l * B[c] * (1.0f - fast_exp2(o.z * ng[c]));
-                        const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
-                        num[c] = __builtin_fmaf(I - b, a, num[c]);
-                        den[c] = __builtin_fmaf(a, a, den[c]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (!(kk.zz[j] > 0.0f)) continue;
+                        const float cP[3] = {kk.xx[j], kk.yy[j], kk.ww[j]};
+                        LightObs o;
+                        if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
+                        else o = light_obs<kGradual>(cP, kk.zz[j], R, tl, M);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float a = o.l * exp2_as<kGradual>(o.z * nb[c]);
+                            const float b = o.l * B[c] * (1.0f - exp2_as<kGradual>(o.z * ng[c]));
+                            const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
+                            num[c] = __builtin_fmaf(I - b, a, num[c]);
+                            den[c] = __builtin_fmaf(a, a, den[c]);
+                        }
                     }
                 }
+            };
+            solve(std::false_type{});
+            // an observed pixel whose denominator is zero: v_exp_f32's flushed results decide between +-inf and NaN here
+            // (fit_math.h) -- the strip is solved again with gradual underflow (same bits for every other pixel)
+            const bool zero = den[0] == 0.f || den[1] == 0.f || den[2] == 0.f;
+            if (n > 0 && __any(zero)) {   // rare; an unobserved pixel (the strip where the counts reach 0) has no level 0 either
+                const LightChunk k0 = load_light_chunk(sobs, sext, 0, min((uint32_t)kGroupLv, n), lane);
+                if (__any(zero && k0.zz[0] > 0.0f)) solve(std::true_type{});
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

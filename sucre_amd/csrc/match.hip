@@ -11,6 +11,7 @@
 // The arithmetic mirrors torch CPU float32 bit for bit: a (3x3)@(3xn) matmul is the FMA chain of dot3(), the
 // divide and sqrt are IEEE (-fhip-fp32-correctly-rounded-divide-sqrt), and the file is built with
 // -ffp-contract=off so no other operation is fused.  Match sets therefore equal the reference's exactly.
+#include "experiment.h"
 #include "launch.h"
 
 namespace sucre {
@@ -66,15 +67,13 @@ __device__ __forceinline__ void rigid(const float *R, const float *t, const floa
 // Otherwise (a within that margin of an integer: ~0.1 % of the lanes at a = 1000; or a NaN / infinite / zero, which
 // covers a denormal or zero z) the whole wave takes the two IEEE divisions.  12 instructions instead of 22 per pair of
 // quotients, four pairs per matching pixel pair; the match sets keep equal to the reference's bit for bit
-// (SUCRE_EXACT_DIV=1 builds the plain form; tests/test_gpu_parity.py compares the two).
-#ifndef SUCRE_EXACT_DIV
-#define SUCRE_EXACT_DIV 0
-#endif
+// (experiment.h: SUCRE_EXACT_DIV=1 builds the plain form; test_pixel_quotients_on_the_integer_boundaries).
 __device__ __forceinline__ void pixel_quotients(float x, float y, float z, float *px, float *py) {
-#if SUCRE_EXACT_DIV
-    *px = x / z;
-    *py = y / z;
-#else
+    if (kExactDiv) {
+        *px = x / z;
+        *py = y / z;
+        return;
+    }
     const float rc = __builtin_amdgcn_rcpf(z);
     float ax = x * rc, ay = y * rc;
     const float sx = __builtin_fmaf(-__builtin_fabsf(ax), 0x1p-21f, __builtin_fabsf(ax - __builtin_rintf(ax)));
@@ -86,7 +85,6 @@ __device__ __forceinline__ void pixel_quotients(float x, float y, float z, float
     }
     *px = ax;
     *py = ay;
-#endif
 }
 
 // sfm.py:103-107,116-117: world point -> continuous pixel; true when Tensor.long() of it lies inside WxH.

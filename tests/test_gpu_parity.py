@@ -792,3 +792,29 @@ def test_pixel_quotients_on_the_integer_boundaries():
     bad = np.flatnonzero(got != expect)
     assert bad.size == 0, (bad.size, X[bad[:5]], Y[bad[:5]], Z[bad[:5]], got[bad[:5]], expect[bad[:5]])
     assert inside.sum() > 100_000 and (~inside).sum() > 100_000
+
+
+def test_light_closed_form_pixels_lit_by_almost_nothing(golden):
+    """A narrow beam (sigma = 0.05): towards the image border the light factor l = exp(-q/2) falls below 2^-126, where
+    torch.exp (sucre.py:60) underflows gradually and v_exp_f32 flushes to zero.  The closed-form J of a pixel whose every
+    absorption a = l exp(-beta z) squares to zero is sum(y a) / 0: +-inf in the reference while a is still a denormal, NaN
+    once a is zero.  The engine re-solves such strips with gradual underflow (csrc/fit_math.h): same NaN pixels, same
+    infinities with the same signs as the oracle, same values wherever the denominator is a normal number."""
+    from sucre_amd import engine
+    sc = golden.scene
+    params0 = np.concatenate([np.full(9, 0.1), np.zeros(6), [0.05, 0.0, 0.0, 0.05]])
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views), light=True)
+    r.match(views[sc.target], views)
+    r.fit_init(views[sc.target], params0=params0)
+    r.update_J()                                   # sucre.py:67-77 at the initial parameters
+    J = r.J().cpu().numpy()
+    _, samples = helpers.oracle_scene_samples(sc)
+    Jo, _, _ = oracle.fit_light(sc.height, sc.width, samples, None, params0=params0, num_iter=0, use_closed_form=True)
+    n_inf, n_nan = int(np.isinf(Jo).sum()), int(np.isnan(Jo).sum())
+    assert n_inf > 50 and n_nan > 50 and np.isfinite(Jo).sum() > 1000, (n_inf, n_nan)     # the scene exercises all three
+    assert np.array_equal(np.isnan(J), np.isnan(Jo))
+    assert np.array_equal(np.isposinf(J), np.isposinf(Jo)) and np.array_equal(np.isneginf(J), np.isneginf(Jo))
+    with np.errstate(invalid='ignore'):
+        sane = np.isfinite(Jo) & (np.abs(Jo) < 10)     # denominators that are normal numbers (a denormal one leaves |J| > 1e15)
+    assert sane.sum() > 1000 and np.abs(J[sane] - Jo[sane]).max() < 1e-4

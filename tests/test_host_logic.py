@@ -589,8 +589,8 @@ def test_png_writer_processes(tmp_path, monkeypatch):
 
 def test_experiment_variants_compile(tmp_path):
     """Every build-time knob of csrc/experiment.h (the ablations and tunables behind DESIGN.md section 4.2) still compiles
-    for gfx950 -- through the product Makefile's own rule, so the no-scratch check applies to them too.  Only fit.hip
-    reads the knobs; objects go to a scratch suffix and are removed."""
+    for gfx950 -- through the product Makefile's own rule, so the no-scratch check applies to them too.  fit.hip reads
+    the knobs (match.hip: SUCRE_EXACT_DIV); objects go to a scratch suffix and are removed."""
     import subprocess
     csrc = ROOT / 'sucre_amd' / 'csrc'
     header = (csrc / 'experiment.h').read_text()
@@ -599,7 +599,9 @@ def test_experiment_variants_compile(tmp_path):
         'tnoload': '-DSUCRE_EXP_NOLOAD',
         'tneither': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_NOLOAD',
         'tring4w4': '-DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4',
+        'texactdiv': '-DSUCRE_EXACT_DIV=1',
     }
+    objects = {'texactdiv': 'match'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here
         assert any(macro in flags for flags in variants.values()) or macro in ('SUCRE_CLOSED_WAVES', 'SUCRE_DMA_POLICY'), macro
     # no other build-time switch hides in the kernel sources
@@ -607,10 +609,11 @@ def test_experiment_variants_compile(tmp_path):
         assert not re.search(r'#\s*if(?:n?def)?\s+.*SUCRE_(EXP|STATE|OBS_VIEW)', f.read_text()), f
     try:
         for name, flags in variants.items():
-            out = subprocess.run(['make', '-C', str(csrc), f'VARIANT={name}', f'EXTRA={flags}', f'fit_{name}.o'],
+            obj = f"{objects.get(name, 'fit')}_{name}.o"
+            out = subprocess.run(['make', '-C', str(csrc), f'VARIANT={name}', f'EXTRA={flags}', obj],
                                  capture_output=True, text=True)
             assert out.returncode == 0, (name, out.stdout[-1500:], out.stderr[-1500:])
-            assert (csrc / f'fit_{name}.o').exists()
+            assert (csrc / obj).exists()
     finally:
         for name in variants:
             for f in csrc.glob(f'*_{name}.*'):

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 VAR=$1; shift
 KERNELS=${@:-match_kernel scatter fit_grad}
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --images-in-flight 1 --num-iter 20 --solo-images 2"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --images-in-flight 1 --num-iter 20 --solo-images 2 ${AB_ARGS:-}"   # AB_ARGS: e.g. "--light-model --use-closed-form"
 mkdir -p gpurun_out/ab
 for round in 1 2; do
   for which in cur $VAR; do

@@ -31,6 +31,9 @@ def main():
         kw = dict(relief=float(rng.choice([0.0, 0.15, 0.6])), spacing=float(rng.choice([0.05, 0.1, 0.25, 0.5])),
                   invalid_frac=float(rng.choice([0.0, 0.01, 0.3])), rot_sigma=float(rng.choice([0.0, 0.03, 0.15])),
                   pos_sigma=float(rng.choice([0.0, 0.1, 0.4])), far_views=int(rng.integers(0, 3)))
+        if os.environ.get('SWEEP_ONLY') and int(os.environ['SWEEP_ONLY']) != s:   # keep the generator's sequence, skip the work
+            rng.choice([3, 20, 60])
+            continue
         sc = synth.make_scene(W, H, nn, seed=seed0 + s, **kw)
         per_view, samples = helpers.oracle_scene_samples(sc)
         views = engine.device_views_from_scene(sc, 'cuda')
@@ -102,12 +105,26 @@ def main():
                 Jl = rl.J().cpu().numpy()
                 J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
                 Jo, po, to = oracle.fit_light(H, W, samples, J0, num_iter=Tl, use_closed_form=closed)
+                if os.environ.get('SWEEP_ONLY') and not np.array_equal(np.isnan(Jl), np.isnan(Jo)):
+                    d = np.isnan(Jl) != np.isnan(Jo)
+                    print('NaN masks differ at', int(d.sum()), 'of', d.size, 'engine NaNs', int(np.isnan(Jl).sum()), 'oracle NaNs', int(np.isnan(Jo).sum()),
+                          'engine there', Jl[d][:6], 'oracle there', Jo[d][:6], 'traces', trl[:, :4], to[:, :4], sep='\n')
                 assert np.array_equal(np.isnan(Jl), np.isnan(Jo)), (s, 'light nan mask', closed)
+                if not np.isfinite(to[0, 0]):   # the re-solved J of a pixel lit by almost nothing overflows float32: in both
+                    assert trl[0, 0] == to[0, 0] or (np.isnan(trl[0, 0]) and np.isnan(to[0, 0])), (s, 'light cost 0', closed, trl[0, 0], to[0, 0])
+                    worst['light_overflow'] = worst.get('light_overflow', 0) + 1
+                    continue
                 assert abs(trl[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'light cost 0', closed, trl[0, 0], to[0, 0])
                 worst['light_cost0'] = max(worst.get('light_cost0', 0.0), abs(trl[0, 0] - to[0, 0]) / max(to[0, 0], 1e-12))
                 knee = bool(np.any(np.abs(to[0, 1:10] - 0.1) / 0.05 < 0.99))
+                if os.environ.get('SWEEP_ONLY'):
+                    print('light closed' if closed else 'light', 'engine trace', trl[:, :10], 'oracle trace', to[:, :10], sep='\n')
                 if not knee:
-                    dpw = float(np.abs(trl[:, 1:10] - to[:, 1:10]).max())
+                    # (a re-solved J that overflows float32 turns the whole trajectory into NaN from the next iteration
+                    # on -- in the oracle and in the engine alike: same iterations, and the finite ones are compared)
+                    assert np.array_equal(np.isnan(trl[:, 1:10]), np.isnan(to[:, 1:10])), (s, 'light NaN iterations', closed)
+                    worst['light_nan_runs'] = worst.get('light_nan_runs', 0) + int(np.isnan(to[:, 1:10]).any())
+                    dpw = float(np.nan_to_num(np.abs(trl[:, 1:10] - to[:, 1:10])).max())
                     worst['light_water'] = max(worst.get('light_water', 0.0), dpw)
                     assert dpw < (2e-3 if closed else 2e-4), (s, 'light water params', closed, dpw, W, H, nn, kw)
         if (s + 1) % 10 == 0:
