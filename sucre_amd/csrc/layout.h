@@ -69,7 +69,7 @@ struct Layout {
     int mask_words;
     size_t off_vbits;       // uint64 [n_tiles][n_views][4]  which pixels of the tile view k observes: word j, bit l = slot 64 j + l
     size_t off_blockhist;   // uint32 [256 bins][n_tiles]  counting-sort histograms (bin-major), scanned in place
-    size_t off_bin_totals;  // uint32 [256] totals, [256] bin bases
+    size_t off_bin_totals;  // uint32 [256] pixels per bin (the bin bases are their suffix sums: permute_kernel, strip_table_kernel)
     size_t off_perm;        // uint32 [n_tiles*256]        sorted slot -> dense slot (tile*256 + slot)
     size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
     int n_strips;           // n_tiles * 4 strips of 64 sorted pixels

@@ -2,7 +2,8 @@
 """Randomised parity sweep on the GPU box: many small scenes (odd sizes, few/many views, steep relief, large twist
 noise, many invalid pixels, far views) -- matching must be bit-identical to the CPU oracle and the fit must stay
 within the test tolerances, in every mode.  Not a test (too long for the suite); run by hand:
-    python3 tools/parity_sweep.py [n_scenes] [seed0] [max_width max_height]"""
+    python3 tools/parity_sweep.py [n_scenes] [seed0] [max_width max_height]
+environment: SWEEP_MAX_NEIGHBOURS (13), SWEEP_LIGHT (1), SWEEP_ONLY=<scene index> (one scene of the sequence, with traces)"""
 import os
 import sys
 import time
@@ -27,7 +28,7 @@ def main():
     t0 = time.time()
     for s in range(n_scenes):
         W, H = int(rng.integers(33, max_w)), int(rng.integers(33, max_h))
-        nn = int(rng.integers(1, 14))
+        nn = int(rng.integers(1, int(os.environ.get('SWEEP_MAX_NEIGHBOURS', '13')) + 1))   # > 254: the quantised counting-sort bins
         kw = dict(relief=float(rng.choice([0.0, 0.15, 0.6])), spacing=float(rng.choice([0.05, 0.1, 0.25, 0.5])),
                   invalid_frac=float(rng.choice([0.0, 0.01, 0.3])), rot_sigma=float(rng.choice([0.0, 0.03, 0.15])),
                   pos_sigma=float(rng.choice([0.0, 0.1, 0.4])), far_views=int(rng.integers(0, 3)))
