@@ -571,23 +571,43 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     return hipGetLastError();
 }
 
+// Workgroups of a gradient launch: as many as are resident at once.  The strips are dealt statically over the launch's
+// waves, so a workgroup that has to wait for a slot runs its whole share after everybody else; the instantiations differ
+// in registers (4 or 5 waves per SIMD; forcing 5 spills), and a grid of kFitGrid = 5 per CU left a fifth of the
+// J-parameter kernel's work to a second round: 0.413 -> 0.372 ms per iteration.  Asked of the runtime once per instantiation.
+template <class K>
+static int resident_grid(K kernel, const Layout &L) {
+    static int per_device = 0;
+    if (per_device == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+            per_device = per_cu * cus;
+        else
+            per_device = kFitGrid;
+    }
+    return L.n_blocks < per_device ? L.n_blocks : per_device;
+}
+
 template <bool kClosed, bool kJOnly, bool kColour, bool kBoth = false>
-static void launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
-                                hipStream_t s) {
-    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour, kBoth>), dim3(L.n_blocks), dim3(256), 0, s, ws + L.off_comp,
+static int launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
+                               hipStream_t s) {
+    const int grid = resident_grid(light_grad_kernel<kClosed, kJOnly, kColour, kBoth>, L);
+    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour, kBoth>), dim3(grid), dim3(256), 0, s, ws + L.off_comp,
                        lws + X.off_ext_comp, kBoth ? light_ext2_comp(L, lws) : nullptr,
                        reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips,
                        reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(lws + X.off_partials), co);
+    return grid;
 }
 
 template <bool kClosed, bool kJOnly>
-static void launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
-                              unsigned flags, hipStream_t s) {
-    if (flags & SUCRE_FIT_EXT_BOTH) launch_light_grad_c<kClosed, kJOnly, false, true>(L, X, ws, lws, co, s);
-    else if (flags & SUCRE_FIT_EXT_COLOUR) launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
-    else launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s);
+static int launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
+                             unsigned flags, hipStream_t s) {
+    if (flags & SUCRE_FIT_EXT_BOTH) return launch_light_grad_c<kClosed, kJOnly, false, true>(L, X, ws, lws, co, s);
+    if (flags & SUCRE_FIT_EXT_COLOUR) return launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
+    return launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s);
 }
 
 hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s) {
@@ -603,9 +623,9 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
                              double *trace_row, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
-    if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, co, flags, s);
-    else launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
-    hipLaunchKernelGGL(light_tail_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const float *>(lws + X.off_partials), L.n_blocks,
+    const int grid = (flags & SUCRE_FIT_CLOSED_FORM) ? launch_light_grad<true, false>(L, X, ws, lws, co, flags, s)
+                                                     : launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
+    hipLaunchKernelGGL(light_tail_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const float *>(lws + X.off_partials), grid,
                        reinterpret_cast<double *>(lws + X.off_sums), reinterpret_cast<float *>(lws + X.off_params),
                        reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total), co, trace_row);
