@@ -618,3 +618,33 @@ def test_experiment_variants_compile(tmp_path):
         for name in variants:
             for f in csrc.glob(f'*_{name}.*'):
                 f.unlink()
+
+
+def test_persistent_kernels_fit_the_grids_they_are_launched_with():
+    """The fit kernels deal their strips statically over a launch's waves and are launched with compile-time grids
+    (csrc/layout.h: kFitGrid = 5, kClosedGrid = 4 workgroups per CU): a workgroup that is not resident from the start
+    would run its whole share in a second round (seen in the light model, which now asks the runtime).  The build's
+    resource reports must therefore show the occupancy the grids assume, and no scratch."""
+    csrc = ROOT / 'sucre_amd' / 'csrc'
+    rpt = (csrc / 'fit.rpt')
+    assert rpt.exists(), 'build first: python -c "import __graft_entry__ as g; g.build()"'
+    layout = (csrc / 'layout.h').read_text() + (csrc / 'experiment.h').read_text()
+    fit_waves = int(re.search(r'#define SUCRE_FIT_WAVES (\d+)', layout).group(1))
+    closed_waves = int(re.search(r'#define SUCRE_CLOSED_WAVES (\d+)', layout).group(1))
+    seen = {}
+    for m in re.finditer(r'Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)', rpt.read_text(), re.S):
+        name, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3))
+        assert scratch == 0, name
+        if 'fit_grad_kernel' in name:
+            need = fit_waves
+        elif 'fit_closed_kernel' in name:
+            need = closed_waves
+        elif 'group_iter_kernelILi0' in name:
+            need = fit_waves
+        elif 'group_iter_kernelILi1' in name:
+            need = closed_waves
+        else:
+            continue
+        seen[name] = occ
+        assert occ >= need, (name, occ, need)
+    assert sum('fit_grad_kernel' in n for n in seen) >= 4 and sum('group_iter_kernel' in n for n in seen) >= 4
