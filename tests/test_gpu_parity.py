@@ -818,3 +818,19 @@ def test_light_closed_form_pixels_lit_by_almost_nothing(golden):
     with np.errstate(invalid='ignore'):
         sane = np.isfinite(Jo) & (np.abs(Jo) < 10)     # denominators that are normal numbers (a denormal one leaves |J| > 1e15)
     assert sane.sum() > 1000 and np.abs(J[sane] - Jo[sane]).max() < 1e-4
+
+
+@pytest.mark.timeout(600)
+def test_randomised_group_sweep_small(monkeypatch):
+    """A short run of tools/group_sweep.py inside the suite (the 1 320-group sweep stays a tool): nine random shared-water
+    groups of 1-6 images of different sizes and view counts, both store formats, J-parameter and closed-form, six through
+    the single-launch group path and three through the split grad / sum / step path, against the oracle's lock-step fit."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    path = Path(__file__).resolve().parent.parent / 'tools' / 'group_sweep.py'
+    spec = importlib.util.spec_from_file_location('group_sweep', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, 'argv', ['group_sweep.py', '9', '515', '160', '120'])
+    mod.main()
