@@ -3,7 +3,7 @@
 noise, many invalid pixels, far views) -- matching must be bit-identical to the CPU oracle and the fit must stay
 within the test tolerances, in every mode.  Not a test (too long for the suite); run by hand:
     python3 tools/parity_sweep.py [n_scenes] [seed0] [max_width max_height]
-environment: SWEEP_MAX_NEIGHBOURS (13), SWEEP_LIGHT (1), SWEEP_ONLY=<scene index> (one scene of the sequence, with traces)"""
+environment: SWEEP_MAX_NEIGHBOURS (13), SWEEP_LIGHT (1), SWEEP_FCOLOUR (1: float32 colours off the 1/255 grid), SWEEP_ONLY=<scene index> (one scene of the sequence, with traces)"""
 import os
 import sys
 import time
@@ -128,6 +128,45 @@ def main():
                     dpw = float(np.nan_to_num(np.abs(trl[:, 1:10] - to[:, 1:10])).max())
                     worst['light_water'] = max(worst.get('light_water', 0.0), dpw)
                     assert dpw < (2e-3 if closed else 2e-4), (s, 'light water params', closed, dpw, W, H, nn, kw)
+        # float32 colours (--image-scale inputs are not k/255): the colours ride in extension planes (SUCRE_EXT_COLOUR)
+        if os.environ.get('SWEEP_FCOLOUR', '1') != '0' and sum(len(x[0]) for x in samples) > 0:
+            gen = torch.Generator().manual_seed(seed0 + s)
+            frgb, fviews = [], []
+            for v in sc.views:
+                f = (v.rgb_u8.to(torch.float64) / 255).to(torch.float32)
+                f = (f + (torch.rand(f.shape, generator=gen) - 0.5) * 0.003).clamp(0, 1).contiguous()
+                frgb.append(f)
+                fviews.append(engine.DeviceView(depth=v.depth_f32().cuda().contiguous(), rgb=f.cuda(), K=sc.K, R=v.R, t=v.t, name=v.name))
+            rf = engine.Restoration(H, W, len(fviews), float_colour=True)
+            rf.match(fviews[sc.target], fviews)
+            assert rf.view_counts().cpu().numpy().tolist() == [len(m) for _, _, m in per_view], (s, 'float colour counts')
+            fsamples = []
+            for ((name, kept, m), f), smp in zip([p for p in sorted(zip(per_view, frgb), key=lambda p: p[0][0]) if p[0][1]], samples):
+                fsamples.append((smp[0], smp[1], smp[2], f.numpy()[m.v2.astype(np.int64), m.u2.astype(np.int64)].T.copy()))
+            Tf = int(T)
+            for closed in (False, True):
+                rf.fit_init(fviews[sc.target])
+                trf = rf.fit(Tf, use_closed_form=closed).cpu().numpy()
+                Jf = rf.J().cpu().numpy()
+                J0 = None
+                if not closed:
+                    J0 = frgb[sc.target].numpy().copy()
+                    J0[tgt.depth_f32().numpy() <= 0] = np.nan
+                Jo, po, to = oracle.fit(H, W, fsamples, J0, num_iter=Tf, use_closed_form=closed)
+                assert np.array_equal(np.isnan(Jf), np.isnan(Jo)), (s, 'float colour nan mask', closed)
+                knee = closed and bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))
+                assert abs(trf[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'float colour cost 0', closed, trf[0, 0], to[0, 0])
+                if knee:
+                    continue
+                err = np.nan_to_num(np.abs(Jf - Jo)).reshape(-1, 3)
+                err[np.argsort(err.max(axis=1))[-5:]] = 0.0
+                n_valid = max(1, int((~np.isnan(Jo).any(axis=2)).sum()))
+                scale = max(1.0, float(np.nanmax(np.abs(Jo)))) if closed else 1.0
+                rmsf = float(np.sqrt((err.astype(np.float64) ** 2).sum(axis=0) / n_valid).max()) / scale
+                dpf = float(np.abs(trf[:, 1:] - to[:, 1:]).max())
+                worst['Jf'] = max(worst.get('Jf', 0.0), rmsf)
+                worst['pf'] = max(worst.get('pf', 0.0), dpf)
+                assert rmsf < (1e-4 if closed else 1e-5) and dpf < (1e-3 if closed else 1e-4), (s, 'float colour', closed, rmsf, dpf, W, H, nn, kw, Tf)
         if (s + 1) % 10 == 0:
             print(f'{s + 1} scenes ok, worst so far {worst}, {time.time() - t0:.0f}s', flush=True)
     print('sweep ok', worst)
