@@ -718,6 +718,15 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
                     cs.sBeta[c] += Jc * __builtin_fmaf(-dJ, acc.q[5][c], acc.q[4][c]);
                     cs.sGZ[c] += __builtin_fmaf(-dJ, acc.q[7][c], acc.q[6][c]);
                     cs.cost += __builtin_fmaf(-dJ, N, acc.q[8][c]);
+                } else if (!kJOnly && N != 0.0f) {
+                    // An OBSERVED pixel whose every a^2 underflowed (ranges of hundreds of metres): the reference's J is
+                    // +-inf there (sucre.py:77), its residuals with it, the cost of the iteration is inf and the channel's
+                    // three parameters are NaN from the next step on (seen with the reference itself on a scene of
+                    // tools/parity_sweep.py).  The sums that factor J out would skip the pixel: hand them the infinity.
+                    cs.sB[c] += dJ;
+                    cs.sBeta[c] += dJ;
+                    cs.sGZ[c] += dJ;
+                    cs.cost += __builtin_inff();
                 }
             }
         });

@@ -834,3 +834,36 @@ def test_randomised_group_sweep_small(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, 'argv', ['group_sweep.py', '9', '515', '160', '120'])
     mod.main()
+
+
+def test_closed_form_overflow_follows_the_reference():
+    """A scene of tools/parity_sweep.py (seed 14000, scene 16) with a far view: ranges of hundreds of metres.  After the
+    first step (beta_R = 0.15) every a^2 = exp(-2 beta z) of some observed pixels underflows float32, the reference's
+    closed-form J is +-inf there (sucre.py:77), the cost of iteration 1 is inf and B_R, beta_R, gamma_R are NaN from
+    then on while the other channels go on -- checked with the reference itself, which the oracle follows digit for digit.
+    The engine's one-pass sums factor J out and would silently skip such a pixel (csrc/fit.hip, strip end): they are
+    handed the infinity instead.  Same first death: iteration, channel, infinite cost; identical before it."""
+    from sucre_amd import engine, synth
+    kw = dict(relief=0.15, spacing=0.1, invalid_frac=0.01, rot_sigma=0.15, pos_sigma=0.1, far_views=1)
+    sc = synth.make_scene(37, 330, 8, seed=14016, **kw)
+    _, samples = helpers.oracle_scene_samples(sc)
+    views = engine.device_views_from_scene(sc, 'cuda')
+    T = 4
+    Jo, po, to = oracle.fit(sc.height, sc.width, samples, None, num_iter=T, use_closed_form=True)
+    assert np.isinf(to[1, 0]) and np.isfinite(to[0]).all() and np.isnan(to[1, [1, 4, 7]]).all() and np.isfinite(to[1, [2, 3, 5, 6, 8, 9]]).all()
+    for fmt in ('f32', 'group'):
+        r = engine.Restoration(sc.height, sc.width, len(views))
+        r.match(views[sc.target], views)
+        r.fit_init(views[sc.target])
+        if fmt == 'group':
+            from sucre_amd import dist as sdist
+            trace = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
+            sdist.fit_shared_water(engine.HipWaterGroup([r], use_closed_form=True, trace=trace), T)
+            tr = trace.cpu().numpy()
+        else:
+            tr = r.fit(T, use_closed_form=True).cpu().numpy()
+        assert abs(tr[0, 0] / to[0, 0] - 1) < 1e-6 and np.abs(tr[0, 1:] - to[0, 1:]).max() < 1e-6, fmt
+        assert np.isinf(tr[1, 0]) and np.array_equal(np.isnan(tr[1]), np.isnan(to[1])), (fmt, tr[1], to[1])
+        assert np.isnan(tr[2:, [0, 1, 4, 7]]).all(), fmt
+        J = r.J().cpu().numpy()
+        assert np.isnan(J[..., 0]).all() and np.array_equal(np.isnan(J), np.isnan(Jo)), fmt

@@ -19,6 +19,23 @@ from oracle import oracle  # noqa: E402
 from sucre_amd import engine, synth  # noqa: E402
 
 
+def overflow_run(tr, to, tag, worst):
+    """True when the oracle's trajectory leaves the finite numbers (an observed pixel whose every a^2 underflows: ranges of
+    hundreds of metres).  The first death must then be the same one in the engine: same iteration, same columns, an
+    infinite cost in both.  What follows is not comparable: the channels that survive have pixels whose sum(a^2) is a
+    DENORMAL number (a few bits of precision), so their J, their residuals and the steps they cause are rounding noise in the
+    reference itself (its float32 operation order decides; the engine's one-pass algebra has another)."""
+    if np.isfinite(to).all():
+        return False
+    worst['overflow_runs'] = worst.get('overflow_runs', 0) + 1
+    first = int((~np.isfinite(to)).any(axis=1).argmax())
+    assert int((~np.isfinite(tr)).any(axis=1).argmax()) == first, (tag, 'first non-finite iteration')
+    assert np.array_equal(np.isfinite(tr[first]), np.isfinite(to[first])) and np.array_equal(np.isinf(tr[first]), np.isinf(to[first])), \
+        (tag, 'what died first', tr[first], to[first])
+    assert first == 0 or np.abs(tr[:first, 1:] - to[:first, 1:]).max() < 1e-5, (tag, 'before the overflow')
+    return True
+
+
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -60,6 +77,18 @@ def main():
                 J = r.J().cpu().numpy()
                 J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
                 Jo, po, to = oracle.fit(H, W, smp, J0, num_iter=T, use_closed_form=closed)
+                if overflow_run(tr, to, (s, fmt, closed), worst):
+                    continue
+                if os.environ.get('SWEEP_ONLY'):
+                    d = np.isnan(J) != np.isnan(Jo)
+                    dtr = np.abs(tr[:, 1:] - to[:, 1:]).max(axis=1)
+                    print(fmt, 'closed' if closed else 'J-param', 'NaN masks differ at', int(d.sum()), 'engine there', J[d][:6], 'oracle there', Jo[d][:6],
+                          'params', tr[-1, 1:], to[-1, 1:], 'max |dparam| by iteration', np.array2string(dtr, precision=2), sep='\n')
+                    if d.any():
+                        idx = np.argwhere(d.any(axis=2))[:3]
+                        for (vv, uu) in idx:
+                            zs = [np.linalg.norm(smp_[2][:, (smp_[0] == uu) & (smp_[1] == vv)], axis=0) for smp_ in smp]
+                            print('pixel', uu, vv, 'ranges of its observations', [z.tolist() for z in zs if z.size])
                 assert np.array_equal(np.isnan(J), np.isnan(Jo)), (s, fmt, closed, 'nan mask')
                 rms_all = float(np.nan_to_num(helpers.rms_per_channel(J, Jo)).max())
                 # Adam on J has the same eps knee per pixel (sucre.py:148 steps J by lr m / (sqrt(v) + eps), and a pixel
@@ -73,16 +102,22 @@ def main():
                 rms = float(np.sqrt((trimmed.astype(np.float64) ** 2).sum(axis=0) / n_valid).max())
                 worst['J_untrimmed'] = max(worst.get('J_untrimmed', 0.0), rms_all if not closed else 0.0)
                 assert closed or rms_all < 1e-4, (s, fmt, closed, 'untrimmed', rms_all)
+                # (a channel whose closed-form J overflows -- an observed pixel whose every a^2 underflows, ranges of
+                # hundreds of metres -- has an infinite cost and NaN parameters from the next step on, in the reference, the
+                # oracle and the engine alike: same iterations, same channels; the other channels are compared)
+                if os.environ.get('SWEEP_ONLY') and not np.array_equal(np.isnan(tr[:, 1:]), np.isnan(to[:, 1:])):
+                    print('engine trace (first 4 rows)', tr[:4], 'oracle trace', to[:4], 'first NaN iteration per column: engine',
+                          np.isnan(tr).argmax(axis=0), 'oracle', np.isnan(to).argmax(axis=0), sep='\n')
                 dp = float(np.abs(tr[:, 1:] - to[:, 1:]).max())
                 key = ('Jc' if closed else 'J') if fmt == 'f32' else 'Ju'
                 bar_J, bar_p = (1e-4, 1e-3) if closed else (1e-5, 1e-4)
                 # closed-form J = sum(y a) / sum(a^2) is unbounded where a pixel has one or two far observations
                 # (a = exp(-beta z) small): the bar is relative to the largest |J| then
-                scale = max(1.0, float(np.nanmax(np.abs(Jo)))) if closed else 1.0
+                scale = max(1.0, float(np.nanmax(np.abs(Jo)))) if closed and np.isfinite(Jo).any() else 1.0
                 # Adam's first step is lr g / (|g| + eps): where it comes out visibly shorter than lr, a gradient sits at
                 # the eps knee (|g| ~ 1e-7) and float32 summation noise of 1e-10 in it already moves the parameters by
                 # 1e-5 -- seen on 2-view scenes in closed-form mode, whose re-solved J makes the gradients nearly cancel
-                knee = closed and bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))
+                knee = bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))   # (rare with J as a parameter, but it happens: scene 451 of seed 13000)
                 if knee:   # the trajectory is then not comparable digit for digit (nor is the reference's with itself):
                     worst['knee'] = worst.get('knee', 0) + 1   # held to the first iteration's cost, which has no step behind it
                     # (absolute floor: with one observation per pixel the re-solved J fits exactly and the cost is rounding
@@ -153,8 +188,10 @@ def main():
                     J0 = frgb[sc.target].numpy().copy()
                     J0[tgt.depth_f32().numpy() <= 0] = np.nan
                 Jo, po, to = oracle.fit(H, W, fsamples, J0, num_iter=Tf, use_closed_form=closed)
+                if overflow_run(trf, to, (s, 'float colour', closed), worst):
+                    continue
                 assert np.array_equal(np.isnan(Jf), np.isnan(Jo)), (s, 'float colour nan mask', closed)
-                knee = closed and bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))
+                knee = bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))
                 assert abs(trf[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'float colour cost 0', closed, trf[0, 0], to[0, 0])
                 if knee:
                     continue
