@@ -36,6 +36,42 @@ def overflow_run(tr, to, tag, worst):
     return True
 
 
+def check_light(rl, views, target, H, W, samples, make_J0, tag, worst):
+    """The artificial-light model of one scene (J-parameter and closed-form) against the oracle: the first iteration's cost
+    has no step behind it and is tight; the trajectory is ill-conditioned by construction (the cam2light gradients sit at
+    Adam's eps), so it is held to the bounds of tests/test_gpu_parity.py over a few steps."""
+    rl.match(views[target], views)
+    assert rl.n_obs() == sum(len(x[0]) for x in samples), (tag, 'light n_obs')
+    Tl = 4
+    for closed in (False, True):
+        rl.fit_init(views[target])
+        trl = rl.fit(Tl, use_closed_form=closed).cpu().numpy()
+        Jl = rl.J().cpu().numpy()
+        Jo, po, to = oracle.fit_light(H, W, samples, None if closed else make_J0(), num_iter=Tl, use_closed_form=closed)
+        if os.environ.get('SWEEP_ONLY') and not np.array_equal(np.isnan(Jl), np.isnan(Jo)):
+            d = np.isnan(Jl) != np.isnan(Jo)
+            print('NaN masks differ at', int(d.sum()), 'of', d.size, 'engine NaNs', int(np.isnan(Jl).sum()), 'oracle NaNs', int(np.isnan(Jo).sum()),
+                  'engine there', Jl[d][:6], 'oracle there', Jo[d][:6], 'traces', trl[:, :4], to[:, :4], sep='\n')
+        assert np.array_equal(np.isnan(Jl), np.isnan(Jo)), (tag, 'light nan mask', closed)
+        if not np.isfinite(to[0, 0]):   # the re-solved J of a pixel lit by almost nothing overflows float32: in both
+            assert trl[0, 0] == to[0, 0] or (np.isnan(trl[0, 0]) and np.isnan(to[0, 0])), (tag, 'light cost 0', closed, trl[0, 0], to[0, 0])
+            worst['light_overflow'] = worst.get('light_overflow', 0) + 1
+            continue
+        assert abs(trl[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (tag, 'light cost 0', closed, trl[0, 0], to[0, 0])
+        worst['light_cost0'] = max(worst.get('light_cost0', 0.0), abs(trl[0, 0] - to[0, 0]) / max(to[0, 0], 1e-12))
+        knee = bool(np.any(np.abs(to[0, 1:10] - 0.1) / 0.05 < 0.99))
+        if os.environ.get('SWEEP_ONLY'):
+            print('light closed' if closed else 'light', 'engine trace', trl[:, :10], 'oracle trace', to[:, :10], sep='\n')
+        if not knee:
+            # (a re-solved J that overflows float32 turns the whole trajectory into NaN from the next iteration on -- in
+            # the oracle and in the engine alike: same iterations, and the finite ones are compared)
+            assert np.array_equal(np.isnan(trl[:, 1:10]), np.isnan(to[:, 1:10])), (tag, 'light NaN iterations', closed)
+            worst['light_nan_runs'] = worst.get('light_nan_runs', 0) + int(np.isnan(to[:, 1:10]).any())
+            dpw = float(np.nan_to_num(np.abs(trl[:, 1:10] - to[:, 1:10])).max())
+            worst['light_water'] = max(worst.get('light_water', 0.0), dpw)
+            assert dpw < (2e-3 if closed else 2e-4), (tag, 'light water params', closed, dpw)
+
+
 def main():
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -127,42 +163,11 @@ def main():
                 worst[key] = max(worst[key], rms / scale)
                 worst['pc' if closed else 'p'] = max(worst['pc' if closed else 'p'], dp)
                 assert rms < bar_J * scale and dp < bar_p, (s, fmt, closed, rms, dp, scale, W, H, nn, kw, T)
-        # artificial-light model on the same scene (J-parameter and closed-form): the first iteration's cost has no step
-        # behind it and is tight; the trajectory is ill-conditioned by construction (the cam2light gradients sit at Adam's
-        # eps), so it is held to the bounds of tests/test_gpu_parity.py over a few steps
+        # artificial-light model on the same scene (J-parameter and closed-form)
         if os.environ.get('SWEEP_LIGHT', '1') != '0' and sum(len(x[0]) for x in samples) > 0:
             rl = engine.Restoration(H, W, len(views), light=True)
-            rl.match(views[sc.target], views)
-            assert rl.n_obs() == sum(len(x[0]) for x in samples), (s, 'light n_obs')
-            Tl = 4
-            for closed in (False, True):
-                rl.fit_init(views[sc.target])
-                trl = rl.fit(Tl, use_closed_form=closed).cpu().numpy()
-                Jl = rl.J().cpu().numpy()
-                J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
-                Jo, po, to = oracle.fit_light(H, W, samples, J0, num_iter=Tl, use_closed_form=closed)
-                if os.environ.get('SWEEP_ONLY') and not np.array_equal(np.isnan(Jl), np.isnan(Jo)):
-                    d = np.isnan(Jl) != np.isnan(Jo)
-                    print('NaN masks differ at', int(d.sum()), 'of', d.size, 'engine NaNs', int(np.isnan(Jl).sum()), 'oracle NaNs', int(np.isnan(Jo).sum()),
-                          'engine there', Jl[d][:6], 'oracle there', Jo[d][:6], 'traces', trl[:, :4], to[:, :4], sep='\n')
-                assert np.array_equal(np.isnan(Jl), np.isnan(Jo)), (s, 'light nan mask', closed)
-                if not np.isfinite(to[0, 0]):   # the re-solved J of a pixel lit by almost nothing overflows float32: in both
-                    assert trl[0, 0] == to[0, 0] or (np.isnan(trl[0, 0]) and np.isnan(to[0, 0])), (s, 'light cost 0', closed, trl[0, 0], to[0, 0])
-                    worst['light_overflow'] = worst.get('light_overflow', 0) + 1
-                    continue
-                assert abs(trl[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'light cost 0', closed, trl[0, 0], to[0, 0])
-                worst['light_cost0'] = max(worst.get('light_cost0', 0.0), abs(trl[0, 0] - to[0, 0]) / max(to[0, 0], 1e-12))
-                knee = bool(np.any(np.abs(to[0, 1:10] - 0.1) / 0.05 < 0.99))
-                if os.environ.get('SWEEP_ONLY'):
-                    print('light closed' if closed else 'light', 'engine trace', trl[:, :10], 'oracle trace', to[:, :10], sep='\n')
-                if not knee:
-                    # (a re-solved J that overflows float32 turns the whole trajectory into NaN from the next iteration
-                    # on -- in the oracle and in the engine alike: same iterations, and the finite ones are compared)
-                    assert np.array_equal(np.isnan(trl[:, 1:10]), np.isnan(to[:, 1:10])), (s, 'light NaN iterations', closed)
-                    worst['light_nan_runs'] = worst.get('light_nan_runs', 0) + int(np.isnan(to[:, 1:10]).any())
-                    dpw = float(np.nan_to_num(np.abs(trl[:, 1:10] - to[:, 1:10])).max())
-                    worst['light_water'] = max(worst.get('light_water', 0.0), dpw)
-                    assert dpw < (2e-3 if closed else 2e-4), (s, 'light water params', closed, dpw, W, H, nn, kw)
+            check_light(rl, views, sc.target, H, W, samples, lambda: oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy()),
+                        (s, 'light', W, H, nn, kw), worst)
         # float32 colours (--image-scale inputs are not k/255): the colours ride in extension planes (SUCRE_EXT_COLOUR)
         if os.environ.get('SWEEP_FCOLOUR', '1') != '0' and sum(len(x[0]) for x in samples) > 0:
             gen = torch.Generator().manual_seed(seed0 + s)
@@ -204,6 +209,13 @@ def main():
                 worst['Jf'] = max(worst.get('Jf', 0.0), rmsf)
                 worst['pf'] = max(worst.get('pf', 0.0), dpf)
                 assert rmsf < (1e-4 if closed else 1e-5) and dpf < (1e-3 if closed else 1e-4), (s, 'float colour', closed, rmsf, dpf, W, H, nn, kw, Tf)
+            if os.environ.get('SWEEP_LIGHT', '1') != '0':   # the light model on float32 colours: points AND colours ride along
+                def float_J0():
+                    J0f = frgb[sc.target].numpy().copy()
+                    J0f[tgt.depth_f32().numpy() <= 0] = np.nan
+                    return J0f
+                rlf = engine.Restoration(H, W, len(fviews), light=True, float_colour=True)
+                check_light(rlf, fviews, sc.target, H, W, fsamples, float_J0, (s, 'light + float colour', W, H, nn, kw), worst)
         if (s + 1) % 10 == 0:
             print(f'{s + 1} scenes ok, worst so far {worst}, {time.time() - t0:.0f}s', flush=True)
     print('sweep ok', worst)
