@@ -3,7 +3,7 @@
 noise, many invalid pixels, far views) -- matching must be bit-identical to the CPU oracle and the fit must stay
 within the test tolerances, in every mode.  Not a test (too long for the suite); run by hand:
     python3 tools/parity_sweep.py [n_scenes] [seed0] [max_width max_height]
-environment: SWEEP_MAX_NEIGHBOURS (13), SWEEP_LIGHT (1), SWEEP_FCOLOUR (1: float32 colours off the 1/255 grid), SWEEP_ONLY=<scene index> (one scene of the sequence, with traces)"""
+environment: SWEEP_MAX_NEIGHBOURS (13), SWEEP_LIGHT (1), SWEEP_FCOLOUR (1: float32 colours off the 1/255 grid), SWEEP_IMPORT (1: the kept views' lists through sucre_import_view), SWEEP_ONLY=<scene index> (one scene of the sequence, with traces)"""
 import os
 import sys
 import time
@@ -163,6 +163,39 @@ def main():
                 worst[key] = max(worst[key], rms / scale)
                 worst['pc' if closed else 'p'] = max(worst['pc' if closed else 'p'], dp)
                 assert rms < bar_J * scale and dp < bar_p, (s, fmt, closed, rms, dp, scale, W, H, nn, kw, T)
+        # the import path (a kept matches file / a hand-built MatchesData: sucre_import_view instead of matching): the kept
+        # views' lists go in, the fit must land where the oracle's does
+        if os.environ.get('SWEEP_IMPORT', '1') != '0' and sum(len(x[0]) for x in samples) > 0:
+            lists = []
+            for (u1_, v1_, cP_, I_) in samples:
+                c = torch.from_numpy(np.ascontiguousarray(cP_, np.float32))
+                z_ = torch.sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2])            # sucre.py:53 in the match kernel's order
+                rgb_ = torch.from_numpy(np.rint(np.ascontiguousarray(I_, np.float64).T * 255).astype(np.uint8))
+                lists.append((torch.from_numpy(u1_.astype(np.int16)), torch.from_numpy(v1_.astype(np.int16)), z_, rgb_))
+            ri = engine.Restoration(H, W, len(lists))
+            ri.import_matches(views[sc.target], lists)
+            assert ri.n_obs() == sum(len(x[0]) for x in samples), (s, 'import n_obs')
+            for closed in (False, True):
+                ri.fit_init(views[sc.target])
+                tri = ri.fit(T, use_closed_form=closed).cpu().numpy()
+                Ji = ri.J().cpu().numpy()
+                J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+                Jo, po, to = oracle.fit(H, W, samples, J0, num_iter=T, use_closed_form=closed)
+                if overflow_run(tri, to, (s, 'import', closed), worst):
+                    continue
+                assert np.array_equal(np.isnan(Ji), np.isnan(Jo)), (s, 'import nan mask', closed)
+                assert abs(tri[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'import cost 0', closed, tri[0, 0], to[0, 0])
+                if bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99)):
+                    continue
+                err = np.nan_to_num(np.abs(Ji - Jo)).reshape(-1, 3)
+                err[np.argsort(err.max(axis=1))[-5:]] = 0.0
+                n_valid = max(1, int((~np.isnan(Jo).any(axis=2)).sum()))
+                scale = max(1.0, float(np.nanmax(np.abs(Jo)))) if closed and np.isfinite(Jo).any() else 1.0
+                rmsi = float(np.sqrt((err.astype(np.float64) ** 2).sum(axis=0) / n_valid).max()) / scale
+                dpi = float(np.abs(tri[:, 1:] - to[:, 1:]).max())
+                worst['Ji'] = max(worst.get('Ji', 0.0), rmsi)
+                worst['pi'] = max(worst.get('pi', 0.0), dpi)
+                assert rmsi < (1e-4 if closed else 1e-5) and dpi < (1e-3 if closed else 1e-4), (s, 'import', closed, rmsi, dpi, W, H, nn, kw, T)
         # artificial-light model on the same scene (J-parameter and closed-form)
         if os.environ.get('SWEEP_LIGHT', '1') != '0' and sum(len(x[0]) for x in samples) > 0:
             rl = engine.Restoration(H, W, len(views), light=True)
