@@ -867,3 +867,19 @@ def test_closed_form_overflow_follows_the_reference():
         assert np.isnan(tr[2:, [0, 1, 4, 7]]).all(), fmt
         J = r.J().cpu().numpy()
         assert np.isnan(J[..., 0]).all() and np.array_equal(np.isnan(J), np.isnan(Jo)), fmt
+
+
+@pytest.mark.timeout(600)
+def test_randomised_camera_sweep_small(monkeypatch):
+    """A short run of tools/camera_sweep.py: neighbour views from other cameras (sizes, focal lengths), camera matrices
+    with skew or K[2][2] != 1 (the general FMA chains instead of the pinhole form), cameras twisted away or moved behind
+    the scene -- match maps and counts bit-identical to the oracle's."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    path = Path(__file__).resolve().parent.parent / 'tools' / 'camera_sweep.py'
+    spec = importlib.util.spec_from_file_location('camera_sweep', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, 'argv', ['camera_sweep.py', '25', '77'])
+    mod.main()
