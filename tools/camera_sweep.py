@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 import helpers  # noqa: E402
 from oracle import oracle  # noqa: E402
-from sucre_amd import engine, synth  # noqa: E402
+from sucre_amd import engine, sfm, synth  # noqa: E402
 
 
 def random_rotation(rng, sigma):
@@ -87,6 +87,20 @@ def main():
             assert np.array_equal(got, ref), (case, k, 'match map', int((got != ref).sum()), (W, H), (w, h), K.tolist())
             counts.append(len(m))
         assert r.view_counts().cpu().numpy().tolist() == counts, (case, 'counts')
+        # the host's overlap cull (sfm.Image.overlapping_views sizes the CLI's workspace by it): a view it drops has no match
+        images = [sfm.Image(i + 1, Path(v.name), Path('depth_' + v.name), sfm.Pose(v.R, v.t), sfm.Camera(i + 1, w, h, K))
+                  for i, (v, K, h, w) in enumerate(others)]
+        timg = sfm.Image(10_000, Path(tgt.name), Path('depth_' + tgt.name), sfm.Pose(tgt.R, tgt.t), sfm.Camera(10_000, W, H, tK))
+        d = tgt.depth_f32()
+        if bool((d > 0).any()):
+            timg.__dict__['_depth_range'] = (float(d[d > 0].min()), float(d[d > 0].max()))
+            keep = set(timg.overlapping_views(images, 'cpu'))
+            for k, n in enumerate(counts):
+                if k not in keep:
+                    assert n == 0, (case, k, 'the cull dropped a view with matches', n)
+                    stats['culled'] = stats.get('culled', 0) + 1
+                elif n == 0:
+                    stats['kept_empty'] = stats.get('kept_empty', 0) + 1
         stats['views'] += len(others)
         stats['matches'] += int(sum(counts))
         if (case + 1) % 20 == 0:
