@@ -41,3 +41,10 @@ constexpr bool kExpNoLoad = false;
 #define SUCRE_EXACT_DIV 0
 #endif
 constexpr bool kExactDiv = SUCRE_EXACT_DIV != 0;
+
+// fit.hip / light.hip: Adam's step on a pixel's J with the IEEE divisions and square root of torch's formula (1) instead of
+// the hardware reciprocal / square root (0, the product: fit_math.h adam_update_J; tools/exp/ab_bench.sh exactadam).
+#ifndef SUCRE_EXACT_J_ADAM
+#define SUCRE_EXACT_J_ADAM 0
+#endif
+constexpr bool kExactJAdam = SUCRE_EXACT_J_ADAM != 0;

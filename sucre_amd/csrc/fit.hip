@@ -619,7 +619,7 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
                 float Jc = J[c], m = f[c * kStripPx + lane], v = f[(3 + c) * kStripPx + lane];
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
                 sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
-                adam_update(Jc, m, v, gscale * acc.pa[c], co);
+                adam_update_J(Jc, m, v, gscale * acc.pa[c], co);
                 st[c * kStripPx + lane] = Jc;
                 st[(3 + c) * kStripPx + lane] = m;
                 st[(6 + c) * kStripPx + lane] = v;

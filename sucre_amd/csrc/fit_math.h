@@ -1,5 +1,6 @@
 // Small device helpers shared by fit.hip and light.hip.
 #pragma once
+#include "experiment.h"
 #include "launch.h"
 
 namespace sucre {
@@ -34,6 +35,25 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
     v = (v * co.beta2) + (co.w2 * g) * g;
     const float denom = sqrtf(v) / co.bc2_sqrt + co.eps;
     p = p + (co.step_size_neg * m) / denom;
+}
+
+// The same step for a pixel's J (three per pixel and iteration: 158 of the J-parameter kernel's ~2000 instructions per
+// pixel were the two IEEE divisions and the IEEE square root of these three steps): hardware square root and reciprocals
+// (1 ulp each) instead of the IEEE sequences, 11 instead of ~42 instructions per channel.  The fit is held to a tolerance,
+// not to bit parity -- its sums already run in another order than torch's -- and the difference sits below that noise:
+// RMS(J) against the reference's own 200-step runs 5.8e-8 / 5.3e-8 with this form, 5.3e-8 / 5.5e-8 with the IEEE one, and
+// the oracle itself is 5.7e-8 / 5.5e-8 from the reference (tools/exp/adam_accuracy.py).  +2.9 % on the headline, same box
+// (tools/exp/ab_bench.sh exactadam).  Special values behave as in adam_update: v = 0 -> denom = eps; v = inf -> no step;
+// a NaN J stays NaN.  SUCRE_EXACT_J_ADAM=1 (experiment.h) builds the IEEE form.
+__device__ __forceinline__ void adam_update_J(float &p, float &m, float &v, float g, const AdamCoef &co) {
+    if (kExactJAdam) {
+        adam_update(p, m, v, g, co);
+        return;
+    }
+    m = __builtin_fmaf(co.w1, g - m, m);
+    v = (v * co.beta2) + (co.w2 * g) * g;
+    const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), __builtin_amdgcn_rcpf(co.bc2_sqrt), co.eps);
+    p = __builtin_fmaf(co.step_size_neg * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
 }  // namespace sucre

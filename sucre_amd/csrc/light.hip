@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             } else {
                 float Jc = J[c], m = st[(3 + c) * kStripPx], v = st[(6 + c) * kStripPx];
                 acc.s[6 + c] += (pb[c] == 0.0f) ? 0.0f : Jc * pb[c];
-                adam_update(Jc, m, v, gscale * pa[c], co);
+                adam_update_J(Jc, m, v, gscale * pa[c], co);
                 st[c * kStripPx] = Jc; st[(3 + c) * kStripPx] = m; st[(6 + c) * kStripPx] = v;
             }
         }

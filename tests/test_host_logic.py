@@ -600,6 +600,7 @@ def test_experiment_variants_compile(tmp_path):
         'tneither': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_NOLOAD',
         'tring4w4': '-DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4',
         'texactdiv': '-DSUCRE_EXACT_DIV=1',
+        'texactadam': '-DSUCRE_EXACT_J_ADAM=1',
     }
     objects = {'texactdiv': 'match'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here

@@ -19,20 +19,32 @@ from oracle import oracle  # noqa: E402
 from sucre_amd import engine, synth  # noqa: E402
 
 
-def overflow_run(tr, to, tag, worst):
-    """True when the oracle's trajectory leaves the finite numbers (an observed pixel whose every a^2 underflows: ranges of
-    hundreds of metres).  The first death must then be the same one in the engine: same iteration, same columns, an
-    infinite cost in both.  What follows is not comparable: the channels that survive have pixels whose sum(a^2) is a
-    DENORMAL number (a few bits of precision), so their J, their residuals and the steps they cause are rounding noise in the
-    reference itself (its float32 operation order decides; the engine's one-pass algebra has another)."""
-    if np.isfinite(to).all():
+def overflow_run(tr, to, tag, worst, zmax=0.0, closed=True):
+    """True when the run is outside the domain where float32 trajectories are comparable: ranges so long that
+    a^2 = exp(-2 beta z) leaves the normal float32 numbers (beta z > 40: hundreds of metres).  A pixel whose sum(a^2) is a
+    DENORMAL number has a closed-form J with a few bits of precision -- rounding noise in the reference itself (its
+    float32 operation order decides; the engine's one-pass algebra has another) -- and once every a^2
+    of an observed pixel is zero, J is +-inf, the cost is inf and the channel's parameters are NaN from the next step on.
+    Such a run is held to its first iteration and, if it was still on the oracle's trajectory when the oracle died, to dying
+    in the same iteration and the same columns with an infinite cost."""
+    finite = np.isfinite(to).all()
+    beta_max = float(np.nanmax(np.abs(np.where(np.isfinite(to[:, 4:7]), to[:, 4:7], 0.0)))) if to.size else 0.0
+    if finite and (not closed or zmax * beta_max <= 40.0):   # (with J as a parameter nothing is divided by sum(a^2))
         return False
-    worst['overflow_runs'] = worst.get('overflow_runs', 0) + 1
-    first = int((~np.isfinite(to)).any(axis=1).argmax())
-    assert int((~np.isfinite(tr)).any(axis=1).argmax()) == first, (tag, 'first non-finite iteration')
-    assert np.array_equal(np.isfinite(tr[first]), np.isfinite(to[first])) and np.array_equal(np.isinf(tr[first]), np.isinf(to[first])), \
-        (tag, 'what died first', tr[first], to[first])
-    assert first == 0 or np.abs(tr[:first, 1:] - to[:first, 1:]).max() < 1e-5, (tag, 'before the overflow')
+    first = int((~np.isfinite(to)).any(axis=1).argmax()) if not finite else len(to)
+    if os.environ.get('SWEEP_ONLY'):
+        fe = int((~np.isfinite(tr)).any(axis=1).argmax()) if not np.isfinite(tr).all() else -1
+        print(tag, 'far-range run: zmax', zmax, 'beta max', beta_max, 'oracle first non-finite iteration', first, 'engine', fe,
+              'costs: oracle', np.array2string(to[:first + 1, 0], precision=3), 'engine', np.array2string(tr[:first + 1, 0], precision=3), sep='\n')
+    assert abs(tr[0, 0] - to[0, 0]) < 1e-4 * abs(to[0, 0]) + 1e-9 and np.abs(tr[0, 1:] - to[0, 1:]).max() < 1e-5, (tag, 'first iteration of a far-range run')
+    on_track = first > 0 and np.abs(tr[:first, 1:] - to[:first, 1:]).max() < 1e-5
+    if not finite and on_track:
+        worst['overflow_runs'] = worst.get('overflow_runs', 0) + 1
+        assert int((~np.isfinite(tr)).any(axis=1).argmax()) == first and not np.isfinite(tr).all(), (tag, 'first non-finite iteration')
+        assert np.array_equal(np.isfinite(tr[first]), np.isfinite(to[first])) and np.array_equal(np.isinf(tr[first]), np.isinf(to[first])), \
+            (tag, 'what died first', tr[first], to[first])
+    else:
+        worst['far_runs'] = worst.get('far_runs', 0) + 1
     return True
 
 
@@ -90,6 +102,7 @@ def main():
             continue
         sc = synth.make_scene(W, H, nn, seed=seed0 + s, **kw)
         per_view, samples = helpers.oracle_scene_samples(sc)
+        zmax = max([float(np.linalg.norm(x[2], axis=0).max()) for x in samples if len(x[0])] + [0.0])
         views = engine.device_views_from_scene(sc, 'cuda')
         tgt = sc.views[sc.target]
         T = int(rng.choice([3, 20, 60]))
@@ -113,7 +126,7 @@ def main():
                 J = r.J().cpu().numpy()
                 J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
                 Jo, po, to = oracle.fit(H, W, smp, J0, num_iter=T, use_closed_form=closed)
-                if overflow_run(tr, to, (s, fmt, closed), worst):
+                if overflow_run(tr, to, (s, fmt, closed), worst, zmax, closed):
                     continue
                 if os.environ.get('SWEEP_ONLY'):
                     d = np.isnan(J) != np.isnan(Jo)
@@ -181,7 +194,7 @@ def main():
                 Ji = ri.J().cpu().numpy()
                 J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
                 Jo, po, to = oracle.fit(H, W, samples, J0, num_iter=T, use_closed_form=closed)
-                if overflow_run(tri, to, (s, 'import', closed), worst):
+                if overflow_run(tri, to, (s, 'import', closed), worst, zmax, closed):
                     continue
                 assert np.array_equal(np.isnan(Ji), np.isnan(Jo)), (s, 'import nan mask', closed)
                 assert abs(tri[0, 0] - to[0, 0]) < 1e-5 * to[0, 0] + 1e-9, (s, 'import cost 0', closed, tri[0, 0], to[0, 0])
@@ -226,7 +239,7 @@ def main():
                     J0 = frgb[sc.target].numpy().copy()
                     J0[tgt.depth_f32().numpy() <= 0] = np.nan
                 Jo, po, to = oracle.fit(H, W, fsamples, J0, num_iter=Tf, use_closed_form=closed)
-                if overflow_run(trf, to, (s, 'float colour', closed), worst):
+                if overflow_run(trf, to, (s, 'float colour', closed), worst, zmax, closed):
                     continue
                 assert np.array_equal(np.isnan(Jf), np.isnan(Jo)), (s, 'float colour nan mask', closed)
                 knee = bool(np.any(np.abs(to[0, 1:] - 0.1) / 0.05 < 0.99))
