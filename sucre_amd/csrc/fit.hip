@@ -50,9 +50,10 @@ constexpr float kInv255 = (float)(1.0 / 255.0);
 // ---------------------------------------------------------------------------------------------------------------
 // Arithmetic of one chunk: four levels of this lane's pixel.
 //
-// The loop is VALU-bound next to the stream: 13 plain instructions (2.34 cycles per wave-instruction per SIMD at five
-// waves per SIMD) and 2 v_exp_f32 (4.0 cycles each back to back, not overlapped with anything: tools/probes/exp_probe.hip)
-// per observation-channel.  The 24 exponentials of a chunk are issued back to back, their arguments before them and their
+// The loop's arithmetic is what the launch waits for next to the stream: 13 plain instructions and 2 v_exp_f32 per
+// observation-channel (an exponential issues at 1.7x the cost of a plain instruction and overlaps with nothing:
+// tools/probes/exp_probe.hip; a three-register v_fma_f32 every 2.4-2.6 shader cycles per SIMD at 5-8 waves:
+// tools/probes/fma3_probe.hip -- the loop as it runs reaches about half of that).  The 24 exponentials of a chunk are issued back to back, their arguments before them and their
 // uses after them: interleaved with their dependent arithmetic the loop was 14 % slower (337 -> 296 ns per chunk per SIMD).
 // ---------------------------------------------------------------------------------------------------------------
 struct Acc {
@@ -156,7 +157,7 @@ __device__ __forceinline__ void closed_terms(float z, float a, float g, uint32_t
                                              float &q6, float &q7, float &q8) {
     const float omg = 1.0f - g;
     // I = k/255 folded into y: one rounding instead of two and two VALU operations fewer, like the J-parameter loop (the
-    // kernel is VALU-bound: 94 % busy at 79 instructions per observation, profiles/r03_closed_summary.txt)
+    // kernel is instruction-limited: 79 instructions per observation, profiles/r03_closed_summary.txt)
     const float y = __builtin_fmaf((float)k, kInv255, -(Bc * omg));
     float p = __builtin_fmaf(-Jp, a, y);
     p = valid ? p : 0.0f;  // a padding slot contributes nothing (its Jp a is not zero)

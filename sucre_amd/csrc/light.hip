@@ -13,7 +13,7 @@
 // One iteration = light_grad_kernel (persistent waves on strips like fit_grad_kernel; 26 sums) -> light_tail_kernel (one
 // workgroup: fixed-order float64 reduction, chain rule through Sigma^-1 and through the matrix exponential -- six 8x8
 // block exponentials evaluated in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1, log row).
-// Plain loads instead of the LDS-DMA ring: the kernel is VALU-bound (~150 instructions per observation).
+// Plain loads instead of the LDS-DMA ring: the kernel is instruction-limited (~135 instructions per observation).
 #include <type_traits>
 #include "fit_math.h"
 

@@ -150,9 +150,9 @@ constexpr int kViewsPerGroup = 16;
 // +-0 (kept: it is what the pointers are); (e) per-pixel view masks combined in the kernel -- the four waves' bits
 // through LDS behind a barrier: +6 % (the fast waves wait); one wave per 16 views, no barrier: +11 % (32 K long waves
 // quantise badly over the SIMDs); (f) the dense chunks written with nontemporal stores, so that they do not push the
-// views' records out of L2: -1 % (the run-to-run noise).  The final kernel is 89 % VALU-busy (profiles/r03_jparam_summary.
-// txt), and bit parity with torch fixes its chains -- except the four quotients, which only feed truncations and bound
-// tests (pixel_quotients): -2.3 %, same box.
+// views' records out of L2: -1 % (the run-to-run noise).  Bit parity with torch fixes the kernel's chains -- except the
+// four quotients, which only feed truncations and bound tests (pixel_quotients): 306 M -> 274 M vector instructions per
+// image (profiles/r03_jparam_summary.txt), -2.3 % on the same box.
 //
 // kExt: extension planes are written (`ext`: the camera points, or float32 colours with SUCRE_EXT_COLOUR).
 // kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
