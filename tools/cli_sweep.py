@@ -3,7 +3,8 @@
 reference flags (--use-closed-form, --light-model, --image-scale, --num-iter, --min-cover, --save-interval,
 --keep-matches), each restored twice -- once with the engine's default knobs and once with a random other setting of the
 knobs that must NOT change a single output byte (images in flight, packed views, overlap cull, decode / PNG threads and
-processes, one rank vs two ranks).  Every file of the two output directories must be identical.
+processes, one rank vs two ranks).  Every file of the two output directories must be identical; with --keep-matches a third
+run over the kept matches files (the import path instead of matching) must reproduce the outputs too.
     python3 tools/cli_sweep.py [n_cases] [seed0]"""
 import filecmp
 import os
@@ -85,7 +86,29 @@ def main():
             assert fa == fb and fa, (case, 'file lists differ', fa[:5], fb[:5], flags, knobs, two_ranks)
             diff = [str(f) for f in fa if f.suffix not in ('.h5', '.npz') and not filecmp.cmp(tmp / 'a' / f, tmp / 'b' / f, shallow=False)]
             assert not diff, (case, 'files differ', diff[:6], flags, knobs, two_ranks, (W, H, nx, ny))
-            print(f'case {case}: {W}x{H} grid {nx}x{ny} {" ".join(flags)} | {knobs} two_ranks={two_ranks} -> {len(fa)} files identical, '
+            reused = False
+            if '--keep-matches' in flags:   # a second run over its own kept matches files (the import path) gives the same outputs
+                # (to the tolerance of tests/test_gpu_api.py::test_cli_kept_matches_are_reused_in_every_mode: the second run
+                # rebuilds the camera points on the host and may see the views in another order)
+                import torch
+                shutil.copytree(tmp / 'a', tmp / 'c')
+                run([sys.executable, '-m', 'sucre_amd.sucre', '--output-dir', str(tmp / 'c')] + common, env_b)
+                light = '--light-model' in flags
+                for f in fa:
+                    if f.suffix != '.pt':
+                        continue
+                    a, c = torch.load(tmp / 'a' / f), torch.load(tmp / 'c' / f)
+                    assert set(a) == set(c), (case, f)
+                    Ja, Jc = a['J'].numpy(), c['J'].numpy()
+                    assert np.array_equal(np.isnan(Ja), np.isnan(Jc)), (case, f, 'NaN mask after reuse')
+                    ok = np.isfinite(Ja).all(axis=-1) & np.isfinite(Jc).all(axis=-1)
+                    if ok.any():
+                        d = Ja[ok].astype(np.float64) - Jc[ok].astype(np.float64)
+                        scale = max(1.0, float(np.abs(Ja[ok]).max()))
+                        rms = float(np.sqrt((d * d).mean(axis=0)).max()) / scale
+                        assert rms < (1e-4 if light else 1e-5), (case, f, 'J after reuse', rms, flags, knobs)
+                reused = True
+            print(f'case {case}: reused={reused} {W}x{H} grid {nx}x{ny} {" ".join(flags)} | {knobs} two_ranks={two_ranks} -> {len(fa)} files identical, '
                   f'{time.time() - t0:.0f}s', flush=True)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
