@@ -92,6 +92,19 @@ def test_config2_vs_oracle_10_iterations(closed):
              label=f'config2 closed={closed}')
 
 
+@pytest.mark.timeout(1500)
+def test_config2_the_bench_workload_200_iterations_vs_oracle():
+    """The headline workload itself, start to end: BASELINE config 2 (1920x1080, 64 neighbours + self, seed 0 = the image
+    `bench.py` restores), all 200 Adam iterations with J as a parameter, against the oracle's 200 iterations on the same
+    78 961 990 observations (the oracle needs ~20-40 s of the box's host cores for them)."""
+    from sucre_amd import synth
+    scene = synth.make_scene(1920, 1080, 64, seed=0, device='cuda')
+    eng = _engine_fit(scene, 200, False)
+    orc = _oracle_fit(_host_scene(scene), 200, False)
+    assert eng[3] == 78961990
+    _compare(eng, orc, label='config 2, 200 iterations')
+
+
 @pytest.mark.timeout(900)
 def test_200_iterations_mid_size_vs_oracle():
     """A whole 200-iteration run at 800x600 x 9 views (3 M observations) against the oracle: trajectories must
