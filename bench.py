@@ -56,11 +56,61 @@ def parse():
     p.add_argument('--timeout-s', type=float, default=1500.0,
                    help='a rank (and, without a launcher, the whole N-rank job) that has produced no result after this long '
                         'says where it is stuck and exits non-zero')
+    p.add_argument('--config', type=int, choices=[1, 2, 3, 4, 5], default=None,
+                   help='BASELINE.json configuration by number (presets of the flags above; explicit flags still win): '
+                        '1 = 640x480, 4 neighbours; 2 = 1920x1080, 64 neighbours (the default workload, the one the metric is '
+                        'quoted on); 3 = --batch-images 32; 4 = --shared-water --batch-images 64 (the 512-image scene, 64 images '
+                        'per rank, one all-reduce per iteration); 5 = 3840x2160, 256 neighbours, --obs-format u16mm')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=65, help='views in the CPU-baseline sample (65 = all of config 2)')
     p.add_argument('--cpu-iters', type=int, default=100, help='Adam iterations in the CPU-baseline sample (~15 s of CPU '
                                                              'work on 16 cores together with the matching)')
-    return p.parse_args()
+    args = p.parse_args()
+    preset = CONFIG_PRESETS.get(args.config, {})
+    for key, val in preset.items():
+        if getattr(args, key) == p.get_default(key):   # a flag given explicitly keeps its value
+            setattr(args, key, val)
+    return args
+
+
+# BASELINE.json "configs", by their 1-based position
+CONFIG_PRESETS = {
+    1: dict(width=640, height=480, neighbours=4),
+    2: dict(),
+    3: dict(batch_images=32),
+    4: dict(shared_water=True, batch_images=64),
+    5: dict(width=3840, height=2160, neighbours=256, obs_format='u16mm'),
+}
+
+
+def baseline_config(args):
+    """The BASELINE.json configuration (1-based) the flags amount to, or None for any other workload."""
+    for number, preset in CONFIG_PRESETS.items():
+        want = dict(width=1920, height=1080, neighbours=64, batch_images=1, shared_water=False, obs_format='f32')
+        want.update(preset)
+        if all(getattr(args, k) == v for k, v in want.items()) and not args.light_model:
+            return number
+    return None
+
+
+def survey_jobs(synth, engine, W, H, neighbours, batch_images, seed, device):
+    """BASELINE configs 3 and 4: ``batch_images`` different target images of ONE synthetic survey, each with its
+    ``neighbours`` nearest views + itself (what a user's image_list would hold).  The survey is a lawn-mower grid just large
+    enough that every target (a block of rows x 8 interior cameras) has its neighbours around it.  Returns
+    (survey, device views of the whole survey, jobs = [(target view, its views in name order)], the survey indices of the
+    targets) -- tests/test_gpu_config3.py goes through this same function."""
+    half = (int((neighbours + 1) ** 0.5) + 1) // 2      # cameras needed around a target on each side
+    rows = (batch_images + 7) // 8
+    gx, gy = 2 * half + 8, 2 * half + rows                   # targets: a block of rows x 8 interior cameras
+    survey = synth.make_survey(W, H, gx, gy, seed=seed, device=device)
+    all_views = engine.device_views_from_scene(survey, device)
+    centre = [j * gx + i for j in range(half, half + rows) for i in range(half, half + 8)][:batch_images]
+    jobs = []
+    for idx in centre:
+        sel = survey.neighbours(idx, neighbours)
+        jobs.append((all_views[idx], [all_views[q] for q in sel]))
+    assert len(jobs) == batch_images, (len(jobs), batch_images)
+    return survey, all_views, jobs, centre
 
 
 def cpu_baseline(scene, n_obs_full, n_views_full, num_iter, sample_views, sample_iters):
@@ -204,17 +254,7 @@ def main():
 
     # every rank restores its own image(s) (its own seed of the synthetic survey): per-GPU work is fixed => weak scaling
     if args.batch_images > 1:
-        half = (int((args.neighbours + 1) ** 0.5) + 1) // 2      # cameras needed around a target on each side
-        rows = (args.batch_images + 7) // 8
-        gx, gy = 2 * half + 8, 2 * half + rows                   # targets: a block of rows x 8 interior cameras
-        survey = synth.make_survey(W, H, gx, gy, seed=rank, device=device)
-        all_views = engine.device_views_from_scene(survey, device)
-        centre = [j * gx + i for j in range(half, half + rows) for i in range(half, half + 8)]
-        jobs = []
-        for idx in centre[:args.batch_images]:
-            sel = survey.neighbours(idx, args.neighbours)
-            jobs.append((all_views[idx], [all_views[q] for q in sel]))
-        assert len(jobs) == args.batch_images, (len(jobs), args.batch_images)
+        survey, all_views, jobs, centre = survey_jobs(synth, engine, W, H, args.neighbours, args.batch_images, rank, device)
         scene = survey.scene_for(centre[0], args.neighbours)
     else:
         scene = synth.make_scene(W, H, args.neighbours, seed=rank, device=device)
@@ -320,6 +360,9 @@ def main():
 
     n_obs = resto.n_obs()
     n_fits = len(fit_events)
+    # what this rank holds in HBM for the fit: every workspace (one per in-flight slot, or one per image of a shared-water group)
+    held = group_restos if group_restos is not None else restos
+    workspace_bytes = sum(r.ws.numel() + (r.lws.numel() if r.lws is not None else 0) for r in held)
     timed_region_iter_ms = None
     if S > 1:
         # the fits of different slots overlap: what the timed region sustained is the union of their intervals
@@ -431,13 +474,16 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{len(jobs)} image(s) {W}x{H} x {n_views} views ({n_views - 1} neighbours + self) per step per GPU, '
+            'config': {'workload': (f'{world * len(jobs)}-image scene, {len(jobs)} per rank: ' if group_restos is not None else '')
+                                   + f'{len(jobs)} image(s) {W}x{H} x {n_views} views ({n_views - 1} neighbours + self) per step per GPU, '
                                    f'{T} Adam iterations, '
                                    + ('closed-form J' if args.use_closed_form else 'J as parameter')
                                    + (', artificial-light model' if args.light_model else '')
                                    + (', compact observations (u16 mm ranges, 5 B/obs)' if args.obs_format == 'u16mm' else '')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
+                       'baseline_config': baseline_config(args),
+                       'workspace_bytes_per_rank': workspace_bytes,
                        'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S,
                        'images_per_s_per_gpu': args.steps * len(jobs) / elapsed, 'fit_ms_alone': fit_ms,
                        'ms_per_image': elapsed / args.steps / len(jobs) * 1e3,

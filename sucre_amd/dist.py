@@ -21,7 +21,7 @@ def env_rank_world() -> tuple[int, int, int]:
 def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
     """Reads RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment (torchrun contract)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (backend is not None and COLLECTIVE_AT_WORLD_1)) and not dist.is_initialized():
         if backend is None:
             # RCCL needs one GPU per rank; several ranks sharing a GPU (a 1-GPU test box) talk over gloo instead.
             # device_count() does not initialise the GPU.
@@ -35,10 +35,17 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, int]:
     return rank, local_rank, world
 
 
+# A process group of ONE rank has nothing to sum, so the collective is skipped -- unless this is set: then the call goes
+# through the backend anyway (RCCL reduces the tensor in place on its own stream and hands it back to the launch stream).
+# tests/test_gpu_rccl.py uses it to put the real RCCL path (the float64 view into the engine's buffer, the stream
+# hand-off around every iteration) under test on a one-GPU box.
+COLLECTIVE_AT_WORLD_1 = False
+
+
 def all_reduce_sum(t: torch.Tensor, group=None) -> None:
     """In-place sum over ranks.  RCCL reduces device tensors directly; under gloo (CPU tests, or several ranks
     sharing one GPU) a device tensor is staged through the host."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not COLLECTIVE_AT_WORLD_1):
         return
     if t.is_cuda and dist.get_backend(group) != 'nccl':
         h = t.cpu()

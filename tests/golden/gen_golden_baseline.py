@@ -1,0 +1,129 @@
+"""Reference-made goldens at BASELINE.json's own sizes (task 1).
+
+Run in the dev container only (the reference never travels):  python tests/golden/gen_golden_baseline.py [c1] [c2]
+
+  c1  config 1 IN FULL: 640x480, 4 neighbours + self, ``synth.make_scene(640, 480, 4, seed=0)``; the reference's
+      own ``match_two_way`` over every view and its own ``sucre.adam`` for 200 iterations, J-parameter mode and
+      closed-form mode (sucre.py:124-157, sfm.py:121-138).
+  c2  config 2, SHORT: 1920x1080, 64 neighbours + self, ``synth.make_scene(1920, 1080, 64, seed=0)`` -- bench.py's
+      own rank-0 workload -- all 65 views matched by the reference, then ``sucre.adam`` for a few iterations (a full
+      200-iteration run is ~2.5 h of CPU per mode).
+
+Only OUTPUTS are stored (the inputs regenerate from the seeded generator); SHA-256 digests of the regenerated
+``depth_u16``/``rgb_u8`` planes are stored next to them, so a consumer that regenerates a different scene (a libm
+that rounds one pixel the other way) finds out before it compares anything.  Match sets are pinned by per-view
+counts and by a SHA-256 of the dense int32 match map (q = v2*W + u2 at (v1,u1), -1 elsewhere) -- bit-exact or not.
+Config 1 stores J in full; config 2 stores J[::4, ::4], the NaN-mask popcount and per-channel float64 sums of J
+and J^2 over the finite pixels of the WHOLE image.
+"""
+from __future__ import annotations
+
+import contextlib
+import hashlib
+import io
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+sys.path.insert(0, str(HERE))
+
+import ref_harness as rh  # noqa: E402
+from sucre_amd import synth  # noqa: E402
+
+CONFIGS = {
+    # name: (width, height, n_neighbours, seed, T J-parameter, T closed-form, J stride stored)
+    'baseline_c1_640x480_n4': (640, 480, 4, 0, 200, 200, 1),
+    'baseline_c2_1920x1080_n64': (1920, 1080, 64, 0, 10, 5, 4),
+}
+
+
+def input_digests(scene):
+    """One SHA-256 per view over (uint16 depth plane, uint8 colour plane) + one over all of them and the poses."""
+    per_view, h_all = [], hashlib.sha256()
+    for v in scene.views:
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(v.depth_u16.cpu().numpy().astype(np.uint16)).tobytes())
+        h.update(np.ascontiguousarray(v.rgb_u8.cpu().numpy()).tobytes())
+        per_view.append(h.hexdigest())
+        h_all.update(h.digest())
+        h_all.update(np.ascontiguousarray(v.R.numpy()).tobytes())
+        h_all.update(np.ascontiguousarray(v.t.numpy()).tobytes())
+    h_all.update(np.ascontiguousarray(scene.K.numpy()).tobytes())
+    return per_view, h_all.hexdigest()
+
+
+def match_map_digest(u1, v1, u2, v2, H, W):
+    m = np.full((H, W), -1, np.int32)
+    m[v1.astype(np.int64), u1.astype(np.int64)] = v2.astype(np.int32) * W + u2.astype(np.int32)
+    return hashlib.sha256(m.tobytes()).hexdigest()
+
+
+def j_summary(J):
+    ok = np.isfinite(J).all(axis=-1)
+    Jd = J[ok].astype(np.float64)
+    return dict(nan_count=int((~ok).sum()), sum=Jd.sum(axis=0), sqsum=(Jd * Jd).sum(axis=0))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def generate(name, spec):
+    W, H, nn, seed, T_param, T_closed, stride = spec
+    t0 = time.perf_counter()
+    scene = synth.make_scene(W, H, nn, seed=seed)
+    per_view_digest, scene_digest = input_digests(scene)
+    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names),
+               input_digest_per_view=np.array(per_view_digest), input_digest=np.array(scene_digest),
+               T_param=T_param, T_closed=T_closed, stride=stride,
+               torch_version=np.array(torch.__version__), threads=torch.get_num_threads())
+    timing = {'scene_s': time.perf_counter() - t0}
+    t0 = time.perf_counter()
+    per_view, md, target = rh.reference_matches(scene, min_cover=1e-6)
+    timing['match_s'] = time.perf_counter() - t0
+    out['kept'] = np.array([r['kept'] for r in per_view])
+    out['n_matches'] = np.array([len(r['u1']) for r in per_view], np.int64)
+    out['n_obs'] = np.int64(len(md))
+    out['match_digest'] = np.array([match_map_digest(r['u1'].numpy(), r['v1'].numpy(), r['u2'].numpy(), r['v2'].numpy(), H, W)
+                                    for r in per_view])
+    # sums of the matched coordinates: a mismatch in a digest can be told from a count mismatch and located
+    out['match_sums'] = np.array([[int(r[k].long().sum()) for k in ('u1', 'v1', 'u2', 'v2')] for r in per_view], np.int64)
+    out['d_sum'] = np.array([float(r['d'].double().sum()) for r in per_view])
+    print(name, 'views', len(scene.views), 'n_obs', int(out['n_obs']), f"matching {timing['match_s']:.1f}s", flush=True)
+
+    t0 = time.perf_counter()
+    snaps = (1,) if T_param > 1 else ()
+    fit = quiet(rh.reference_fit, scene, md, target, num_iter=T_param, snapshots=snaps, batch_size=5)
+    timing['fit_param_s'] = time.perf_counter() - t0
+    out['trace_param'] = fit['trace']
+    print(name, f"J-parameter fit {T_param} iterations {timing['fit_param_s']:.1f}s", flush=True)
+    t0 = time.perf_counter()
+    fitc = quiet(rh.reference_fit, scene, md, target, num_iter=T_closed, use_closed_form=True, batch_size=5)
+    timing['fit_closed_s'] = time.perf_counter() - t0
+    out['trace_closed'] = fitc['trace']
+    print(name, f"closed-form fit {T_closed} iterations {timing['fit_closed_s']:.1f}s", flush=True)
+    for key, J in (('param', fit['J']), ('closed', fitc['J'])) + ((('param_1', fit['snaps'][1]),) if snaps else ()):
+        s = j_summary(J)
+        st = max(stride, 4) if key == 'param_1' else stride    # the one-step snapshot is kept subsampled everywhere
+        out[f'J_{key}'] = np.ascontiguousarray(J[::st, ::st])
+        out[f'J_{key}_nan_count'] = np.int64(s['nan_count'])
+        out[f'J_{key}_sum'] = s['sum']
+        out[f'J_{key}_sqsum'] = s['sqsum']
+    out['timing_json'] = np.array(json.dumps(timing))
+    np.savez_compressed(HERE / f'{name}.npz', **out)
+    print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', json.dumps(timing), flush=True)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    want = [a for a in sys.argv[1:]]
+    for name, spec in CONFIGS.items():
+        if not want or any(w in name for w in want):
+            generate(name, spec)

@@ -127,3 +127,123 @@ def check_knee(fx, J, trace, label):
     dJ = min(float(rms_per_channel(J, fx['J_closed_bs5']).max()), float(rms_per_channel(J, fx['J_closed_bs1']).max()))
     assert dJ < 3 * Jsp, (label, 'J', dJ, Jsp)
     return d / par, dJ / Jsp
+
+
+# ---- reference-made goldens at BASELINE.json's own sizes (tests/golden/gen_golden_baseline.py) ---------------------------
+
+BASELINE_C1 = 'baseline_c1_640x480_n4'
+BASELINE_C2 = 'baseline_c2_1920x1080_n64'
+
+
+def scene_digests(scene):
+    """SHA-256 per view over (uint16 depth plane, uint8 colour plane) + one over all views, poses and K -- the
+    restatement of ``input_digests`` of tests/golden/gen_golden_baseline.py (which cannot be imported on the GPU box's
+    side of things without the reference harness)."""
+    import hashlib
+    per_view, h_all = [], hashlib.sha256()
+    for v in scene.views:
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(v.depth_u16.cpu().numpy().astype(np.uint16)).tobytes())
+        h.update(np.ascontiguousarray(v.rgb_u8.cpu().numpy()).tobytes())
+        per_view.append(h.hexdigest())
+        h_all.update(h.digest())
+        h_all.update(np.ascontiguousarray(v.R.numpy()).tobytes())
+        h_all.update(np.ascontiguousarray(v.t.numpy()).tobytes())
+    h_all.update(np.ascontiguousarray(scene.K.numpy()).tobytes())
+    return per_view, h_all.hexdigest()
+
+
+def match_map_digest(match_map: np.ndarray) -> str:
+    """SHA-256 of a dense (H,W) int32 match map (q = v2*W + u2 at (v1,u1), -1 elsewhere)."""
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(match_map, dtype=np.int32).tobytes()).hexdigest()
+
+
+class Baseline:
+    """A reference-made golden at a BASELINE size: OUTPUTS only; the inputs are regenerated here (on the CPU, like the
+    generator did) and checked against the stored digests.  ``inputs_identical`` False means this machine's libm
+    rounded some rendered pixel the other way: the consumer then knows that a difference is the INPUT's, and holds the
+    looser bars it documents instead of the bit-exact ones."""
+
+    def __init__(self, name: str):
+        from sucre_amd import synth
+        self.name = name
+        self.z = np.load(GOLDEN_DIR / f'{name}.npz')
+        z = self.z
+        self.scene = synth.make_scene(int(z['width']), int(z['height']), int(z['n_neighbours']), seed=int(z['seed']))
+        assert self.scene.names == [str(n) for n in z['names']] and self.scene.target == int(z['target'])
+        per_view, total = scene_digests(self.scene)
+        self.views_identical = [a == str(b) for a, b in zip(per_view, z['input_digest_per_view'])]
+        self.inputs_identical = total == str(z['input_digest'])
+        if not self.inputs_identical:
+            print(f'WARNING {name}: the regenerated scene differs from the one the reference ran on '
+                  f'({self.views_identical.count(False)} of {len(per_view)} views) -- libm/torch rounding on this machine')
+
+    def __getitem__(self, key):
+        return self.z[key]
+
+    def j_sums(self, J: np.ndarray):
+        """(nan_count, per-channel float64 sum, sum of squares) of a full (H,W,3) image, as the generator stored them."""
+        ok = np.isfinite(J).all(axis=-1)
+        Jd = J[ok].astype(np.float64)
+        return int((~ok).sum()), Jd.sum(axis=0), (Jd * Jd).sum(axis=0)
+
+
+_BASELINES = {}
+
+
+def load_baseline(name: str) -> Baseline:
+    if name not in _BASELINES:
+        _BASELINES[name] = Baseline(name)
+    return _BASELINES[name]
+
+
+def dense_map(m, H, W):
+    """Dense (H,W) int32 match map of an oracle ViewMatches."""
+    mm = np.full((H, W), -1, np.int32)
+    mm[m.v1.astype(np.int64), m.u1.astype(np.int64)] = m.v2.astype(np.int32) * W + m.u2.astype(np.int32)
+    return mm
+
+
+def check_baseline_matches(b, counts, maps, label):
+    """Per-view match counts and dense match maps against the reference's: bit-exact (SHA-256 of the map) for every
+    view whose regenerated input planes -- and the target's -- are the ones the reference saw."""
+    tgt_same = b.views_identical[b.scene.target]
+    ref_counts = b['n_matches'].tolist()
+    for k, n in enumerate(counts):
+        if b.views_identical[k] and tgt_same:
+            assert n == ref_counts[k], (label, 'count of view', k, n, ref_counts[k])
+            if maps is not None and maps[k] is not None:
+                assert match_map_digest(maps[k]) == str(b['match_digest'][k]), (label, 'match map of view', k)
+        else:
+            assert abs(n - ref_counts[k]) <= 1e-4 * ref_counts[k] + 8, (label, 'count of view', k, n, ref_counts[k])
+
+
+def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label):
+    """A full (H,W,3) J and a (T, >=10) trace against what the REFERENCE stored: J[::stride, ::stride], the NaN count
+    and the per-channel sums of J and J^2 over the whole image, the (T,10) cost / B / beta / gamma trajectory."""
+    st = max(int(b['stride']), 4) if key == 'param_1' else int(b['stride'])
+    ref = b[f'J_{key}']
+    sub = J[::st, ::st]
+    if not b.inputs_identical:   # a libm that renders another scene: the north-star bar instead of the tight ones
+        rms_bar, param_bar, cost_bar = max(rms_bar, 1e-4), max(param_bar, 1e-4), max(cost_bar, 1e-4)
+    nan_count, s, sq = b.j_sums(J)
+    if b.inputs_identical:
+        assert np.array_equal(np.isnan(sub), np.isnan(ref)), (label, 'NaN mask')
+        assert nan_count == int(b[f'J_{key}_nan_count']), (label, 'NaN count of the whole image')
+    rms = rms_per_channel(sub, ref)
+    n_ok = J.shape[0] * J.shape[1] - nan_count
+    dmean = np.abs(s - b[f'J_{key}_sum']) / n_ok         # every pixel of the image enters these two
+    dsq = np.abs(sq - b[f'J_{key}_sqsum']) / n_ok
+    out = dict(rms=rms, dmean=dmean, dsq=dsq)
+    assert rms.max() < rms_bar, (label, key, 'RMS(J) vs the reference', rms)
+    assert dmean.max() < rms_bar and dsq.max() < rms_bar, (label, key, 'whole-image mean / mean square', dmean, dsq)
+    if trace is not None:
+        rt = b['trace_closed' if key == 'closed' else 'trace_param'][:trace.shape[0]]
+        out['dpar'] = float(np.abs(trace[:, 1:10] - rt[:, 1:]).max())
+        out['dcost'] = float(np.abs(trace[:, 0] / rt[:, 0] - 1).max())
+        assert out['dpar'] < param_bar, (label, key, 'B, beta, gamma trajectory', out['dpar'])
+        assert out['dcost'] < cost_bar, (label, key, 'cost trajectory', out['dcost'])
+    print(f'{label} [{key}] vs the REFERENCE: rms(J)={rms} |dmean|={dmean.max():.2e} '
+          f'max|dparams|={out.get("dpar", float("nan")):.2e} max rel dcost={out.get("dcost", float("nan")):.2e}')
+    return out

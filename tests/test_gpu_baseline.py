@@ -1,0 +1,75 @@
+"""The HIP engine against the REFERENCE ITSELF at BASELINE.json's sizes -- directly, not through the oracle.
+
+tests/golden/baseline_c1_640x480_n4.npz and baseline_c2_1920x1080_n64.npz hold what the reference computed
+(tests/golden/gen_golden_baseline.py: its own match_two_way over every view, its own sucre.adam) on scenes the seeded
+generator reproduces; the regenerated inputs are digest-checked before anything is compared (helpers.Baseline).
+
+  config 1 IN FULL: 640x480, 5 views, the reference's 200 iterations, J as a parameter and closed form: full J.
+  config 2, SHORT : 1920x1080 x 65 views (the bench's own image), the reference's matching of all 65 views and its
+                    first 10 (J parameter) / 5 (closed form) iterations at 79 M observations: J[::4, ::4], the NaN count
+                    and the per-channel sums of J and J^2 over the WHOLE image, the cost / B / beta / gamma trajectory.
+
+Bars: match sets bit for bit (per-view counts + SHA-256 of the dense match map); RMS(J) <= 1e-6 in J-parameter mode and
+<= 2e-5 in closed-form mode (north star: 1e-4; the reference's own batch-order noise is 5e-8 resp. 5e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_run(b, T_param, T_closed, with_maps=True):
+    from sucre_amd import engine
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views)
+    counts = r.view_counts().cpu().numpy().tolist()
+    keep = r.view_keep().cpu().numpy().astype(bool).tolist()
+    assert keep == b['kept'].tolist()
+    maps = [r.match_map(k).cpu().numpy() for k in range(len(views))] if with_maps else None
+    helpers.check_baseline_matches(b, counts, maps, b.name + ' engine')
+    if b.inputs_identical:
+        assert r.n_obs() == int(b['n_obs'])
+    out = {}
+    r.fit_init(views[sc.target])
+    t1 = r.fit(1)
+    out['J1'] = r.J().cpu().numpy()
+    t2 = r.fit(T_param - 1)
+    torch.cuda.synchronize()
+    out['J'] = r.J().cpu().numpy()
+    out['trace'] = np.concatenate([t1.cpu().numpy(), t2.cpu().numpy()])
+    r.fit_init(views[sc.target])
+    tc = r.fit(T_closed, use_closed_form=True)
+    torch.cuda.synchronize()
+    out['Jc'] = r.J().cpu().numpy()
+    out['trace_c'] = tc.cpu().numpy()
+    out['n_obs'] = r.n_obs()
+    del r, views
+    torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_config1_in_full_engine_vs_reference():
+    b = helpers.load_baseline(helpers.BASELINE_C1)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    assert (T_param, T_closed) == (200, 200) and int(b['stride']) == 1
+    e = engine_run(b, T_param, T_closed)
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 1, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, 'ENGINE, config 1 in full, 200 iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, 'ENGINE, config 1 in full, 200 iterations')
+
+
+@pytest.mark.timeout(1500)
+def test_config2_short_engine_vs_reference():
+    b = helpers.load_baseline(helpers.BASELINE_C2)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    e = engine_run(b, T_param, T_closed)
+    assert e['n_obs'] > 70_000_000
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, config 2, {T_param} iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} iterations')

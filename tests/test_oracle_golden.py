@@ -231,3 +231,54 @@ def test_shared_water_closed_form_oracle_vs_tied_reference_modules():
     for o, key in zip(imgs, ('J0_bs5', 'J1_bs5')):
         assert np.array_equal(np.isnan(o.J), np.isnan(g[key]))
         assert helpers.rms_per_channel(o.J, g[key]).max() < 1e-4
+
+
+# ---- round 4: the reference ITSELF at BASELINE.json's sizes (tests/golden/gen_golden_baseline.py) ------------------------
+# Config 1 in full (640x480, 4 neighbours + self, the reference's own 200 iterations in both J modes) and config 2
+# short (1920x1080 x 65 views = the bench's rank-0 image, the reference's own matching of all 65 views and its first
+# Adam iterations at 79 M observations, where per-pixel gradients sit at Adam's eps).  Outputs only; the inputs are
+# regenerated and digest-checked (helpers.Baseline).
+
+def oracle_baseline_run(b):
+    sc = b.scene
+    per_view, samples = helpers.oracle_scene_samples(sc)
+    assert sum(len(s[0]) for s in samples) == int(b['n_obs']) or not b.inputs_identical
+    assert [k for _, k, _ in per_view] == b['kept'].tolist()
+    helpers.check_baseline_matches(b, [len(m) for _, _, m in per_view],
+                                   [helpers.dense_map(m, sc.height, sc.width) for _, _, m in per_view], b.name + ' oracle')
+    for k, (_, _, m) in enumerate(per_view):   # the gathered depths (sfm.py:137): their float64 sum; coordinate sums
+        if b.inputs_identical:
+            assert abs(float(m.d.astype(np.float64).sum()) - float(b['d_sum'][k])) <= 1e-9 * float(b['d_sum'][k])
+            assert [int(x.astype(np.int64).sum()) for x in (m.u1, m.v1, m.u2, m.v2)] == b['match_sums'][k].tolist()
+    tgt = sc.views[sc.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    return samples, J0, int(b['T_param']), int(b['T_closed'])
+
+
+def test_baseline_config1_in_full_oracle_vs_reference():
+    """BASELINE config 1 start to end: the oracle's 200 iterations against the reference's own 200 iterations on the
+    640x480, 5-view image (1.34 M observations), J as a parameter and closed form; match sets bit-exact."""
+    b = helpers.load_baseline(helpers.BASELINE_C1)
+    sc = b.scene
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    J1, _, _ = oracle.fit(sc.height, sc.width, samples, J0, num_iter=1)
+    helpers.check_baseline_fit(b, 'param_1', J1, None, 1e-7, 0, 0, 'oracle, config 1, 1 iteration')
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, config 1, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 1, {T_closed} iterations')
+
+
+def test_baseline_config2_short_oracle_vs_reference():
+    """BASELINE config 2, the bench's own image (1920x1080, 64 neighbours + self, seed 0; 79 M observations): the
+    reference's match sets of all 65 views bit for bit, and its first Adam iterations in both J modes -- the regime
+    where the 1/(3 n_obs) scaling puts per-pixel J gradients at the order of Adam's eps."""
+    b = helpers.load_baseline(helpers.BASELINE_C2)
+    sc = b.scene
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    J1, _, _ = oracle.fit(sc.height, sc.width, samples, J0, num_iter=1)
+    helpers.check_baseline_fit(b, 'param_1', J1, None, 1e-7, 0, 0, 'oracle, config 2, 1 iteration')
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, config 2, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 2, {T_closed} iterations')
