@@ -14,7 +14,9 @@
 // being consumed, across strip boundaries: prefetch depth costs LDS, not registers, no latency is exposed between
 // strips, and the only ordinary memory instructions of the loop are the stores of J (and the moments) at a strip's
 // end.  Per-pixel sums live in the lane that owns the pixel: no atomics, no cross-wave reduction, and Adam on J
-// (torch.optim.Adam restated op for op, fit_math.h) runs in the same lane.  The ten global sums go
+// runs in the same lane (fit_math.h adam_update_J: torch.optim.Adam's update with the hardware square root and
+// reciprocals, 1 ulp each, in place of the IEEE sequences -- held to the fit's tolerance, not to bit parity; the nine water
+// parameters take the op-for-op IEEE form, adam_update).  The ten global sums go
 // lane -> wave shuffle -> LDS -> one float32 partial per workgroup -> float64 fixed-order two-level reduction, so
 // results are bitwise reproducible.
 //

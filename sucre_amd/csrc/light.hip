@@ -15,6 +15,7 @@
 // block exponentials evaluated in LDS -- Adam on the 19 parameters, next R, t, Sigma^-1, log row).
 // Plain loads instead of the LDS-DMA ring: the kernel is instruction-limited (~135 instructions per observation).
 #include <type_traits>
+#include <mutex>
 #include "fit_math.h"
 
 namespace sucre {
@@ -121,8 +122,8 @@ __device__ __forceinline__ void light_geometry(const float *params, float *geom,
         if (c < 3) geom[r * 3 + c] = (float)E[0][r * 8 + c];
         else geom[9 + r] = (float)E[0][r * 8 + 3];
     }
-    if (tid >= 64 && tid < 64 + 72) {
-        const int i = (tid - 64) / 12, e = (tid - 64) % 12, r = e / 4, c = e % 4;
+    for (int k = tid; k < 72; k += blockDim.x) {   // any workgroup size writes all 72 derivatives
+        const int i = k / 12, e = k % 12, r = e / 4, c = e % 4;
         dexp[i * 12 + e] = E[i][r * 8 + 4 + c];
     }
     if (tid == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
@@ -575,18 +576,29 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
 // waves, so a workgroup that has to wait for a slot runs its whole share after everybody else; the instantiations differ
 // in registers (4 or 5 waves per SIMD; forcing 5 spills), and a grid of kFitGrid = 5 per CU left a fifth of the
 // J-parameter kernel's work to a second round: 0.413 -> 0.372 ms per iteration.  Asked of the runtime once per instantiation.
+// Cached per (instantiation, device) under a mutex: the command line submits from several threads, and a process may drive
+// GPUs with different CU counts (the grid fixes the summation order, so it must be the CURRENT device's, every time).
 template <class K>
 static int resident_grid(K kernel, const Layout &L) {
-    static int per_device = 0;
-    if (per_device == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
-            per_device = per_cu * cus;
-        else
-            per_device = kFitGrid;
+    constexpr int kMaxDevices = 64;
+    static int per_device[kMaxDevices] = {};
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return L.n_blocks < kFitGrid ? L.n_blocks : kFitGrid;
+    int grid;
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        if (per_device[dev] == 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+                per_device[dev] = per_cu * cus;
+            else
+                per_device[dev] = kFitGrid;
+        }
+        grid = per_device[dev];
     }
-    return L.n_blocks < per_device ? L.n_blocks : per_device;
+    return L.n_blocks < grid ? L.n_blocks : grid;
 }
 
 template <bool kClosed, bool kJOnly, bool kColour, bool kBoth = false>

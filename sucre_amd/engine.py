@@ -29,6 +29,12 @@ class DeviceView:
     R: torch.Tensor       # (3,3) float32, cpu   world-from-camera
     t: torch.Tensor       # (3,1) float32, cpu
     name: str = ''
+    # Optional: the derived float32 matrices K^-1 and -R^T t, given by the caller instead of derived here.  torch derives
+    # them on the HOST (sfm.py:42-47, 92), and MKL's float32 3x3 products differ in the last bit between CPU models, which
+    # moves a handful of boundary pixels per million matches: a caller comparing against results made on another machine
+    # (tests/test_gpu_baseline.py: the reference's own goldens) passes that machine's matrices.
+    Kinv: torch.Tensor | None = None
+    tinv: torch.Tensor | None = None
 
     def to_struct(self, packed: bool = False) -> _lib.SucreView:
         """sucre_view_t of this view (cached: the matrices are derived once per view, not once per target image).
@@ -45,7 +51,7 @@ class DeviceView:
             H, W = self.depth.shape
             records = self.packed_records()
             key = key + (records.data_ptr(),)
-            s = camera_struct(self.K, self.R, self.t, H, W, records.data_ptr(), 0)
+            s = camera_struct(self.K, self.R, self.t, H, W, records.data_ptr(), 0, Kinv=self.Kinv, tinv=self.tinv)
         else:
             s = self._build_struct()
         self.__dict__[slot] = (key, s)
@@ -103,19 +109,19 @@ class DeviceView:
         H, W = self.depth.shape
         assert self.depth.dtype == torch.float32 and self.depth.is_contiguous() and self.depth.is_cuda
         assert self.rgb.dtype in (torch.uint8, torch.float32) and self.rgb.is_contiguous() and self.rgb.shape == (H, W, 3)
-        return camera_struct(self.K, self.R, self.t, H, W, self.depth.data_ptr(), self.rgb.data_ptr())
+        return camera_struct(self.K, self.R, self.t, H, W, self.depth.data_ptr(), self.rgb.data_ptr(), Kinv=self.Kinv, tinv=self.tinv)
 
 
 def camera_struct(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor, H: int, W: int, depth_ptr: int = 0,
-                  rgb_ptr: int = 0) -> _lib.SucreView:
+                  rgb_ptr: int = 0, Kinv: torch.Tensor | None = None, tinv: torch.Tensor | None = None) -> _lib.SucreView:
     """sucre_view_t from a camera matrix and a world-from-camera pose, the derived matrices computed on the host the way
     the reference computes them (K.inverse(): sfm.py:92; Pose.inverse() = (R.T, -R.T @ t): sfm.py:42-47)."""
     K = K.to(torch.float32).cpu()
     R = R.to(torch.float32).cpu()
     t = t.to(torch.float32).cpu().view(3, 1)
-    Kinv = K.inverse()      # sfm.py:92
+    Kinv = K.inverse() if Kinv is None else Kinv.to(torch.float32).cpu().view(3, 3)      # sfm.py:92
     Rinv = R.T              # sfm.py:47
-    tinv = -R.T @ t         # sfm.py:47
+    tinv = -R.T @ t if tinv is None else tinv.to(torch.float32).cpu().view(3, 1)         # sfm.py:47
     s = _lib.SucreView()
     s.depth, s.rgb, s.H, s.W = depth_ptr or None, rgb_ptr or None, int(H), int(W)
     for name, val in (('K', K), ('Kinv', Kinv), ('R', R), ('t', t), ('Rinv', Rinv), ('tinv', tinv)):
@@ -488,7 +494,8 @@ def device_views_from_scene(scene, device='cuda') -> list[DeviceView]:
     out = []
     for v in scene.views:
         out.append(DeviceView(depth=v.depth_f32().to(device).contiguous(), rgb=v.rgb_u8.to(device).contiguous(),
-                              K=scene.K, R=v.R, t=v.t, name=v.name))
+                              K=scene.K, R=v.R, t=v.t, name=v.name,
+                              Kinv=getattr(scene, 'Kinv_given', None), tinv=getattr(v, 'tinv_given', None)))
     return out
 
 
@@ -634,6 +641,55 @@ def acquire_restoration(height: int, width: int, n_views: int, device='cuda', li
     return _POOL[key]
 
 
+_FREE: list = []   # leased workspaces handed back by their owners (lease_restoration / return_restoration)
+_FREE_LOCK = threading.Lock()
+_FREE_KEEP = 4      # at most this many idle workspaces are kept (a 1080p x 65-view one is ~2 GB)
+
+
+def lease_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
+                      obs_format: str | None = None, float_colour: bool = False) -> Restoration:
+    """A workspace for ONE owner (a list-backed ``loader.MatchesData``): taken from the free list when an idle one of the
+    same geometry and kind with enough capacity exists, allocated otherwise; nobody else sees it until the owner hands it
+    back with ``return_restoration``.  ``obs_format`` None: the SUCRE_OBS_FORMAT knob, as in ``acquire_restoration``."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    if obs_format is None:
+        obs_format = 'f32' if (light or float_colour) else os.environ.get('SUCRE_OBS_FORMAT', 'f32')
+    n = int(n_views)
+    want = (int(height), int(width), str(dev), bool(light), obs_format, bool(float_colour))
+    with _FREE_LOCK:
+        for i, r in enumerate(_FREE):
+            if (r.H, r.W, str(r.device), r.light, r.obs_format, r.float_colour) == want and r.capacity >= n:
+                _FREE.pop(i)
+                with torch.cuda.device(dev):   # whatever its last owner had enqueued on it comes first
+                    for ev in r.__dict__.pop('_idle_after', []):
+                        torch.cuda.current_stream(dev).wait_event(ev)
+                return r
+    cap = (n + 7) // 8 * 8 if n <= 256 else (n + 31) // 32 * 32
+    return Restoration(height, width, cap, device=dev, light=light, obs_format=obs_format, float_colour=float_colour)
+
+
+def return_restoration(r: Restoration) -> None:
+    """Hands a leased workspace back.  Its last owner's launches may still be queued (on the caller's stream or on an
+    in-flight slot's): one event per such stream is left on the workspace for the next owner to wait for."""
+    r._keepalive = []
+    try:
+        with torch.cuda.device(r.device):
+            streams = [torch.cuda.current_stream(r.device)] + [s for (d, _), s in _STREAMS.items() if d == str(r.device)]
+            events = []
+            for s in streams:
+                ev = torch.cuda.Event()
+                ev.record(s)
+                events.append(ev)
+            r.__dict__['_idle_after'] = events
+    except Exception:   # interpreter shutdown: the workspace is going away with everything else
+        return
+    with _FREE_LOCK:
+        if len(_FREE) < _FREE_KEEP and all(x is not r for x in _FREE):
+            _FREE.append(r)
+
+
 @contextlib.contextmanager
 def in_flight_slot(index: int, device='cuda', wait_for_caller: bool = True):
     """Several images in flight on one GPU.  Code inside the block enqueues on slot ``index``'s own HIP stream and
@@ -665,5 +721,7 @@ def in_flight_slot(index: int, device='cuda', wait_for_caller: bool = True):
 
 
 def release_pool() -> None:
+    with _FREE_LOCK:
+        _FREE.clear()
     _POOL.clear()
     _STREAMS.clear()

@@ -417,12 +417,13 @@ class MatchesData:
             ext = (torch.cat([cP, I]).contiguous() if (light and not integral)      # both extension sets
                    else cP.contiguous() if light else (None if integral else I.contiguous()))
             lists.append((s.u, s.v, z, rgb) if ext is None else (s.u, s.v, z, rgb, ext))
-        # A private workspace, not a pooled one: the reference's MatchesData objects are independent of each other, and
-        # a pooled workspace (keyed by geometry) would hand md_A the observations md_B imported after it.
-        dev = torch.device(device)
-        if dev.type == 'cuda' and dev.index is None:
-            dev = torch.device('cuda', torch.cuda.current_device())
-        resto = engine.Restoration(height, width, len(lists), device=dev, light=light, float_colour=not integral)
+        # A workspace of its OWN while this container lives (the reference's MatchesData objects are independent of each
+        # other: a workspace shared by geometry would hand md_A the observations md_B imported after it), LEASED from the
+        # engine's free list and handed back when the container is dropped -- image after image of a kept-matches run
+        # reuses one allocation (and its pinned staging buffer) instead of allocating ~2 GB per image.
+        import weakref
+        resto = engine.lease_restoration(height, width, len(lists), device=device, light=light, float_colour=not integral)
+        weakref.finalize(self, engine.return_restoration, resto)
         resto.import_matches(None, lists)
         self.restoration = resto
         return resto

@@ -58,6 +58,25 @@ def input_digests(scene):
     return per_view, h_all.hexdigest()
 
 
+def derived_matrices(scene):
+    """What the reference derives from K, R, t on this host with torch CPU float32 (sfm.py:92 K.inverse(); sfm.py:42-47
+    Pose.inverse() = (R.T, -R.T @ t)): stored because MKL's float32 products differ in the last bit between CPU models."""
+    return dict(Kinv=scene.K.inverse().numpy(), tinv=np.stack([(-v.R.T @ v.t).numpy().ravel() for v in scene.views]))
+
+
+def add_derived(name, spec):
+    """Adds the derived matrices to an existing golden without re-running the reference's fits (same host, same torch:
+    they are pure functions of the seeded poses).  Checks the stored input digest first."""
+    W, H, nn, seed = spec[:4]
+    path = HERE / f'{name}.npz'
+    z = dict(np.load(path))
+    scene = synth.make_scene(W, H, nn, seed=seed)
+    assert input_digests(scene)[1] == str(z['input_digest']), 'this host regenerates another scene'
+    z.update(derived_matrices(scene))
+    np.savez_compressed(path, **z)
+    print(name, 'derived matrices added', path.stat().st_size, 'bytes')
+
+
 def match_map_digest(u1, v1, u2, v2, H, W):
     m = np.full((H, W), -1, np.int32)
     m[v1.astype(np.int64), u1.astype(np.int64)] = v2.astype(np.int32) * W + u2.astype(np.int32)
@@ -84,6 +103,7 @@ def generate(name, spec):
                input_digest_per_view=np.array(per_view_digest), input_digest=np.array(scene_digest),
                T_param=T_param, T_closed=T_closed, stride=stride,
                torch_version=np.array(torch.__version__), threads=torch.get_num_threads())
+    out.update(derived_matrices(scene))
     timing = {'scene_s': time.perf_counter() - t0}
     t0 = time.perf_counter()
     per_view, md, target = rh.reference_matches(scene, min_cover=1e-6)
@@ -123,7 +143,7 @@ def generate(name, spec):
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    want = [a for a in sys.argv[1:]]
+    want = [a for a in sys.argv[1:] if not a.startswith('--')]
     for name, spec in CONFIGS.items():
         if not want or any(w in name for w in want):
-            generate(name, spec)
+            (add_derived if '--add-derived' in sys.argv else generate)(name, spec)

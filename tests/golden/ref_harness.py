@@ -1,7 +1,7 @@
 """Drive the *real* reference (clementinboittiaux/sucre, mounted read-only at /root/reference) on synthetic
 scenes.  Only usable in the dev container: the reference never travels to the GPU box, so this module is
-imported exclusively by ``gen_golden.py`` (fixture generation) and by the optional
-``tests/test_reference_live.py`` cross-checks, which skip when /root/reference is absent.
+imported exclusively by the fixture generators next to it (``gen_golden.py``, ``gen_golden_extras.py``,
+``gen_golden_baseline.py``) and by ``tools/time_reference.py`` (the CPU-baseline calibration); no test imports it.
 
 The reference's hot path imports fine once its three I/O-only dependencies (cv2, h5py, pycolmap — all absent
 here and never called by the functions we exercise) are registered as empty modules.  Synthetic pixels are

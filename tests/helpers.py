@@ -16,18 +16,19 @@ from oracle import oracle  # noqa: E402  (tests are allowed to use the oracle)
 GOLDEN_DIR = Path(__file__).resolve().parent / 'golden'
 
 
-def cam_matrices(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor):
+def cam_matrices(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor, Kinv=None, tinv=None):
     """float32 matrices exactly as the reference derives them: K.inverse() (sfm.py:92), Pose.inverse()
-    = (R.T, -R.T @ t) (sfm.py:42-47)."""
-    Kinv = K.inverse()
+    = (R.T, -R.T @ t) (sfm.py:42-47) -- on THIS host, unless the caller brings the ones another host derived (MKL's
+    float32 products differ in the last bit between CPU models; helpers.Baseline)."""
+    Kinv = K.inverse() if Kinv is None else Kinv
     Rinv = R.T
-    tinv = -R.T @ t
+    tinv = -R.T @ t if tinv is None else tinv
     return dict(K=K.numpy(), Kinv=Kinv.numpy(), R=R.numpy(), t=t.numpy().ravel(),
                 Rinv=Rinv.contiguous().numpy(), tinv=tinv.numpy().ravel())
 
 
 def oracle_cam(scene, view):
-    m = cam_matrices(scene.K, view.R, view.t)
+    m = cam_matrices(scene.K, view.R, view.t, Kinv=getattr(scene, 'Kinv_given', None), tinv=getattr(view, 'tinv_given', None))
     return oracle.make_cam(scene.height, scene.width, **m)
 
 
@@ -172,6 +173,19 @@ class Baseline:
         z = self.z
         self.scene = synth.make_scene(int(z['width']), int(z['height']), int(z['n_neighbours']), seed=int(z['seed']))
         assert self.scene.names == [str(n) for n in z['names']] and self.scene.target == int(z['target'])
+        # The float32 matrices the reference derived from K, R, t on ITS host (torch CPU: K.inverse(), -R.T @ t).  They are
+        # handed to the oracle and to the engine, so the per-pixel arithmetic is compared under the reference's own
+        # matrices on whatever CPU this runs (the build container's and the GPU box's MKL differ in the last bit of
+        # -R.T @ t, which moves ~7 of a million matches of a view).  ``derived_identical``: would this host's have been?
+        own_Kinv = self.scene.K.inverse().numpy()
+        own_tinv = np.stack([(-v.R.T @ v.t).numpy().ravel() for v in self.scene.views])
+        self.derived_identical = bool(np.array_equal(own_Kinv, z['Kinv']) and np.array_equal(own_tinv, z['tinv']))
+        self.scene.Kinv_given = torch.tensor(z['Kinv'])
+        for v, ti in zip(self.scene.views, z['tinv']):
+            v.tinv_given = torch.tensor(ti).view(3, 1)
+        if not self.derived_identical:
+            print(f'NOTE {name}: this host derives other float32 camera matrices than the reference\'s host did '
+                  f'({int((own_tinv != z["tinv"]).any(axis=1).sum())} of {len(own_tinv)} views); the stored ones are used')
         per_view, total = scene_digests(self.scene)
         self.views_identical = [a == str(b) for a, b in zip(per_view, z['input_digest_per_view'])]
         self.inputs_identical = total == str(z['input_digest'])

@@ -591,7 +591,10 @@ def test_experiment_variants_compile(tmp_path):
     """Every build-time knob of csrc/experiment.h (the ablations and tunables behind DESIGN.md section 4.2) still compiles
     for gfx950 -- through the product Makefile's own rule, so the no-scratch check applies to them too.  fit.hip reads
     the knobs (match.hip: SUCRE_EXACT_DIV); objects go to a scratch suffix and are removed."""
+    import shutil
     import subprocess
+    if shutil.which('hipcc') is None and not Path('/opt/rocm/bin/hipcc').exists():
+        pytest.skip('no hipcc on this machine')
     csrc = ROOT / 'sucre_amd' / 'csrc'
     header = (csrc / 'experiment.h').read_text()
     variants = {

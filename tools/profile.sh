@@ -21,6 +21,9 @@ mode_args() {
     *) echo "unknown mode $1" >&2; exit 2 ;;
   esac
 }
+for MODE in $MODES; do   # an unknown mode stops the script before anything is profiled (exit inside $(...) would not)
+  mode_args $MODE > /dev/null || exit 2
+done
 for MODE in $MODES; do
   OUT=gpurun_out/prof_${TAG}/$MODE
   mkdir -p $OUT
