@@ -261,3 +261,17 @@ def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label):
     print(f'{label} [{key}] vs the REFERENCE: rms(J)={rms} |dmean|={dmean.max():.2e} '
           f'max|dparams|={out.get("dpar", float("nan")):.2e} max rel dcost={out.get("dcost", float("nan")):.2e}')
     return out
+
+
+def synth_image(idx, view, K, W, H):
+    """sfm.Image whose pixels come from a synthetic view instead of files (what tests/golden/ref_harness.py does to the
+    reference's class)."""
+    from sucre_amd import sfm
+
+    class _Image(sfm.Image):
+        def get_rgb(self):
+            return view.rgb_f32()
+
+        def get_depth_map(self):
+            return view.depth_f32()
+    return _Image(idx, Path(view.name), Path('depth_' + view.name), sfm.Pose(view.R, view.t), sfm.Camera(1, W, H, K))

@@ -778,3 +778,33 @@ def test_list_backed_matches_data_objects_are_independent(golden):
     assert np.array_equal(a2.J.cpu().numpy(), J_a, equal_nan=True)
     assert helpers.rms_per_channel(J_a, golden['J_closed_init']).max() < 1e-6
     assert not np.array_equal(b.J.cpu().numpy(), J_a, equal_nan=True)
+
+
+def test_matches_file_written_like_the_reference_is_consumed(golden):
+    """(f)1: tests/golden/ref_layout_<fixture>.h5 -- the reference's own matches, written by the h5py calls of
+    loader.py:68-87 in their order -- goes through MatchesFile.on_disk / load_file / check_integrity / load_matches and
+    the fit lands on the reference's own J for that scene (golden J_param_5, J_closed_init)."""
+    from sucre_amd import h5bridge, loader, sucre
+    path = helpers.GOLDEN_DIR / f'ref_layout_{golden.name}.h5'
+    if not path.exists():
+        pytest.skip('fixture made for the plane scene only')
+    if not h5bridge.available():
+        pytest.skip('no h5py interpreter on this machine (SUCRE_H5PY_PYTHON)')
+    sc = golden.scene
+    model = {v.name: helpers.synth_image(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)}
+    target = model[sc.views[sc.target].name]
+    mf = loader.MatchesFile(path, colmap_model=model)
+    assert mf.on_disk()
+    mf.load_file(target, device='cuda')
+    mf.check_integrity()
+    assert len(mf) == int(golden['n_obs'])
+    assert [im.name for im in mf.get_image_list()] == sorted(str(n) for n, k in zip(golden['names'], golden['kept']) if k)
+    md = mf.load_matches()
+    m = sucre.SUCRe(image=target).to('cuda')
+    sucre.adam(sucre=m, matches_data=md, lr=0.05, num_iter=5, batch_size=5, device='cuda')
+    J = m.J.detach().cpu().numpy()
+    assert np.array_equal(np.isnan(J), np.isnan(golden['J_param_5']))
+    assert helpers.rms_per_channel(J, golden['J_param_5']).max() < 1e-6
+    closed = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
+    closed.update_J(md)
+    assert helpers.rms_per_channel(closed.J.cpu().numpy(), golden['J_closed_init']).max() < 1e-6

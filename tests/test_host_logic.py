@@ -653,3 +653,80 @@ def test_persistent_kernels_fit_the_grids_they_are_launched_with():
         seen[name] = occ
         assert occ >= need, (name, occ, need)
     assert sum('fit_grad_kernel' in n for n in seen) >= 4 and sum('group_iter_kernel' in n for n in seen) >= 4
+
+
+# ---- round 4: a matches file in the reference's format, written with the reference's own h5py call sequence ---------------
+
+H5_FIXTURE = helpers.GOLDEN_DIR / 'ref_layout_plane_64x48_n4.h5'
+
+
+def _need_h5py():
+    from sucre_amd import h5bridge
+    if not h5bridge.available():
+        pytest.skip('no h5py interpreter on this machine (SUCRE_H5PY_PYTHON)')
+    return h5bridge
+
+
+def test_reference_written_matches_file_reads_back_as_the_reference_match_lists():
+    """tests/golden/ref_layout_plane_64x48_n4.h5 holds the reference's own matches of the plane fixture, written by the
+    h5py calls of loader.py:68-87 in their order (groups created in REVERSE name order, I NaN-prefilled then overwritten):
+    h5bridge must hand the groups back in name order with the reference's datasets, dtypes and values."""
+    h5bridge = _need_h5py()
+    fx = helpers.load_fixture('plane_64x48_n4')
+    groups = h5bridge.read_groups(H5_FIXTURE)
+    kept = [str(n) for n, k in zip(fx['names'], fx['kept']) if k]
+    assert list(groups) == sorted(kept)
+    for k, name in enumerate(str(n) for n in fx['names']):
+        if not fx['kept'][k]:
+            assert name not in groups
+            continue
+        ds = groups[name]
+        assert sorted(ds) == ['I', 'd', 'u1', 'u2', 'v1', 'v2']
+        u1, v1, u2, v2 = fx.match_lists(k)
+        for key, want in (('u1', u1), ('v1', v1), ('u2', u2), ('v2', v2)):
+            assert ds[key].dtype == np.int16 and np.array_equal(ds[key], want), (name, key)
+        view = fx.scene.views[k]
+        assert ds['d'].dtype == np.float32 and np.array_equal(ds['d'], view.depth_f32().numpy()[v2.astype(np.int64), u2.astype(np.int64)])
+        assert ds['I'].dtype == np.float32 and ds['I'].shape == (3, len(u1))
+        assert np.array_equal(ds['I'], view.rgb_f32().numpy()[v2.astype(np.int64), u2.astype(np.int64)].T)
+
+
+def test_half_written_reference_matches_file_is_refused():
+    """A crash between save_matches and prepare_matches leaves I NaN-prefilled (loader.py:76); the reference's
+    check_integrity trips on it (loader.py:89-101) and so must load_file -- before anything reaches the engine."""
+    _need_h5py()
+    fx = helpers.load_fixture('plane_64x48_n4')
+    sc = fx.scene
+    model = {v.name: helpers.synth_image(i + 1, v, sc.K, sc.width, sc.height) for i, v in enumerate(sc.views)}
+    mf = loader.MatchesFile(helpers.GOLDEN_DIR / 'ref_layout_plane_64x48_n4_unprepared.h5', colmap_model=model)
+    assert mf.on_disk()
+    with pytest.raises(AssertionError, match=r'dataset /img_\d+\.png/I contains NaN'):
+        mf.load_file(model[sc.views[sc.target].name], device='cuda')
+
+
+def test_colmap_binary_model_written_from_the_format_description():
+    """(f)3: tests/golden/colmap_bin_model/*.bin was written field by field from COLMAP's documented binary layout by
+    tests/golden/gen_colmap_bin_fixture.py -- no code shared with sfm.py's reader or its text writer -- with the
+    expected world-from-camera poses computed by scipy from the (qvec, tvec) it wrote.  COLMAPModel must read it the
+    way the reference reads pycolmap's Reconstruction (sfm.py:186-238): PINHOLE K per camera, pose = cam_from_world
+    inverted, name -> image, depth path naming."""
+    root = helpers.GOLDEN_DIR / 'colmap_bin_model'
+    exp = np.load(root / 'expected.npz')
+    model = sfm.COLMAPModel(root, Path('/data/images'), Path('/data/depth'))
+    assert sorted(model.cameras) == sorted(exp['camera_ids'].tolist())
+    for cid, (w, h), (fx, fy, cx, cy) in zip(exp['camera_ids'], exp['camera_wh'], exp['camera_params']):
+        cam = model.cameras[int(cid)]
+        assert (cam.width, cam.height) == (int(w), int(h))
+        assert torch.equal(cam.K, torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32))
+    assert sorted(model.images) == sorted(exp['image_id'].tolist()) and len(model.images) == 6
+    for i, name in enumerate(str(n) for n in exp['names']):
+        im = model[Path(name).name]       # the reference keys its images by the file's base name (sfm.py:84, 224)
+        assert im.id == int(exp['image_id'][i]) and im.camera.id == int(exp['camera_id'][i]) and im.name == Path(name).name
+        assert im.rgb_path == Path('/data/images') / name
+        assert im.depth_map_path == (Path('/data/depth') / name).with_name('depth_' + Path(name).stem + '.png')
+        assert np.abs(im.pose.R.numpy() - exp['R_wfc'][i]).max() < 2e-7      # float32 of a float64 rotation
+        assert np.abs(im.pose.t.numpy().ravel() - exp['t_wfc'][i]).max() < 1e-6
+    # half resolution: the reference's integer size and per-axis intrinsic scale (sfm.py:193-199)
+    half = sfm.COLMAPModel(root, Path('/i'), Path('/d'), image_scale=0.5)
+    cam = half.cameras[7]
+    assert (cam.width, cam.height) == (960, 540) and abs(float(cam.K[0, 0]) - 1497.6 / 2) < 1e-3 and abs(float(cam.K[1, 2]) - 540.5 / 2) < 1e-3
