@@ -178,6 +178,10 @@ __device__ __forceinline__ void closed_terms(float z, float a, float g, uint32_t
 template <bool kMasked>
 __device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], const uint32_t (&cc)[3], const Water &w,
                                                  const float (&Jp)[3], AccOne &acc) {
+    if (kExpNoCompute) {  // ablation build only (experiment.h): touch the data, skip the model
+        acc.q[8][0] += (zz[0] + zz[1]) + (zz[2] + zz[3]) + (float)(cc[0] ^ cc[1] ^ cc[2]);
+        return;
+    }
     Exps e;
     chunk_exps(zz, w, e);
 #pragma unroll
@@ -193,6 +197,10 @@ __device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], co
 
 __device__ __forceinline__ void accumulate_level(float z, const uint32_t (&k)[3], const Water &w, const float (&Jp)[3],
                                                  AccOne &acc) {
+    if (kExpNoCompute) {
+        acc.q[8][0] += z + (float)(k[0] ^ k[1] ^ k[2]);
+        return;
+    }
     const bool valid = z > 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -203,19 +211,26 @@ __device__ __forceinline__ void accumulate_level(float z, const uint32_t (&k)[3]
 // ---------------------------------------------------------------------------------------------------------------
 // Item stream: per-wave LDS-DMA ring.
 //
-// An item is copied by two LDS-DMA instructions (global_load_lds_dwordx4: lane i moves 16 bytes from src + 16 i to
-// slot + 16 i -- a dwordx3 one also strides by 16 and leaves holes, tools/probes/lds_dma_probe.hip) of nA and nB
-// active lanes, the second one continuing where the first ends, so the LDS image is a byte-exact copy of
-// 16 (nA + nB) bytes.  The DMAs have no VGPR destination: hipcc can neither sink them next to their use nor drain
-// them early; they live in inline asm and are waited for by hand-counted s_waitcnt vmcnt (vmcnt retires in issue
-// order; cdna_hip_programming.md 5.7).  What may still be outstanding when item q is needed: the items issued after
-// it (two instructions each) and, if they were issued after it, the stores of the previous strip's end.
+// An item is copied by two LDS-DMA instructions (global_load_lds_dwordx4: lane i moves 16 bytes from src + voff_i to
+// slot + 16 i -- a dwordx3 one also strides by 16 and leaves holes, tools/probes/lds_dma_probe.hip).  ALL 64 lanes are
+// active in both (round 4; until then the lanes beyond the item were masked out of EXEC: two 64-bit masks computed and
+// EXEC written four times per item, ~25 scalar instructions of the ~85 an item cost next to its 180 of arithmetic):
+//   A  lanes 0 .. nA-1 copy the item's first 16 nA bytes (nA = 64 for items of a KiB or more); the lanes beyond them
+//      re-read lane nA-1's 16 bytes into the slot's bytes past 16 nA;
+//   B  lanes 0 .. nB-1 copy the remaining 16 nB bytes to slot + 16 nA; the lanes beyond them re-read lane nB-1's 16 bytes
+//      into what follows.  B is issued after A and A's surplus bytes only exist when nB = 0, so no surplus byte ever
+//      lands on a real one; a slot is 2 KiB (16 nA + 1024 <= 2048), the ring's only cost: 24 KiB of LDS per workgroup.
+// The surplus lanes read bytes some other lane of the same instruction reads: no extra traffic beyond the L1.
+// The DMAs have no VGPR destination: hipcc can neither sink them next to their use nor drain them early; they live in
+// inline asm and are waited for by hand-counted s_waitcnt vmcnt (vmcnt retires in issue order; cdna_hip_programming.md
+// 5.7).  What may still be outstanding when item q is needed: the items issued after it (two instructions each) and, if
+// they were issued after it, the stores of the previous strip's end.
 // ---------------------------------------------------------------------------------------------------------------
 // waves per SIMD the fit kernels are compiled for (register budget 512 / waves) = workgroups per CU of their
 // persistent grids: kFitWaves / kClosedWaves (layout.h)
 constexpr int kRing = SUCRE_RING;
 constexpr int kAhead = kRing - 1;
-constexpr int kSlot = kChunk;  // largest item: a full float32 chunk (1792 B)
+constexpr int kSlot = 2048;  // largest item (a full float32 chunk, 1792 B) + room for the second DMA's surplus lanes
 
 struct __attribute__((aligned(16))) FitLds {
     uint8_t ring[4][kRing][kSlot];  // per-wave item ring
@@ -228,36 +243,41 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p));  // low 32 bits of a flat LDS address = LDS offset
 }
 
+// PlanItem.shape: [6:0] nA - 1, [14:8] max(nB, 1) - 1, [22:16] B's first 16-byte piece (nA, or nA - 1 when nB = 0: B then
+// re-reads the item's last piece), [31] a full chunk (nA = 64 and nB = kFullB: both offsets are per-lane constants).
+constexpr uint32_t kShapeFull = 1u << 31;
+__host__ __device__ constexpr uint32_t full_chunk_b(int fmt) { return (uint32_t)(chunk_bytes(fmt) - 1024) / 16u; }   // 48 / 16 lanes
+__host__ __device__ __forceinline__ uint32_t item_shape(uint32_t bytes, bool full_chunk) {
+    const uint32_t pieces = bytes / 16u;   // every item is a multiple of 16 bytes (static_asserts below)
+    const uint32_t nA = pieces < 64u ? pieces : 64u, nB = pieces - nA;
+    return (nA - 1u) | ((nB ? nB - 1u : 0u) << 8) | ((nB ? nA : nA - 1u) << 16) | (full_chunk ? kShapeFull : 0u);
+}
+static_assert(level_bytes(0) % 16 == 0 && level_bytes(1) % 16 == 0 && kChunk % 16 == 0 && kChunk16 % 16 == 0, "items are copied in 16-byte pieces");
+static_assert(kChunk <= 2048 && kChunk >= 1024 && kChunk16 >= 1024, "a full chunk is one whole DMA + a partial one");
 
-__device__ __forceinline__ uint64_t lane_mask(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
-
-// src (wave-uniform global address) -> LDS slot (wave-uniform LDS byte address).  EXEC is all ones on entry (whole
-// waves run this code) and is restored inside the statement; M0 is written in the statement that reads it.
-__device__ __forceinline__ void dma_item(const uint8_t *src, uint32_t slot, uint32_t lane, uint32_t nA, uint32_t nB) {
+// src (wave-uniform global address) -> LDS bytes [slotA, ...) and [slotB, ...) (wave-uniform LDS byte addresses) through the
+// per-lane byte offsets voffA / voffB.  EXEC is all ones (whole waves run this code) and stays so; M0 is written in the
+// statement that reads it.  s_nop 4: a VMEM instruction must not read an SGPR a VALU instruction (v_readfirstlane) wrote
+// in the five preceding cycles, and the compiler's hazard recogniser does not look inside an asm statement.
+__device__ __forceinline__ void dma_item(const uint8_t *src, uint32_t slotA, uint32_t slotB, uint32_t voffA, uint32_t voffB) {
     if (kExpNoLoad) return;  // ablation build only (experiment.h): the ring keeps whatever LDS holds
     unsigned keep;
-    const uint32_t voffA = lane * 16u, voffB = voffA + nA * 16u;
-    const uint32_t slotB = slot + nA * 16u;
-    const uint64_t mA = lane_mask(nA), mB = lane_mask(nB);
     asm volatile(
         "s_nop 4\n\t"
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
-        "s_mov_b64 exec, %6\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %1, %2" SUCRE_DMA_POLICY "\n\t"
         "s_mov_b32 m0, %4\n\t"
-        "s_mov_b64 exec, %7\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %5, %2" SUCRE_DMA_POLICY "\n\t"
-        "s_mov_b64 exec, -1\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voffA), "s"(src), "s"(slot), "s"(slotB), "v"(voffB), "s"(mA), "s"(mB)
+        : "v"(voffA), "s"(src), "s"(slotA), "s"(slotB), "v"(voffB)
         : "memory");
 }
 
-// Waits until at most n vector-memory instructions of this wave are outstanding (n <= 2 kAhead + 9).
+// Waits until at most n vector-memory instructions of this wave are outstanding.
 __device__ __forceinline__ void wait_vm(uint32_t n) {
 #define SUCRE_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
     switch (n) {
@@ -268,7 +288,7 @@ __device__ __forceinline__ void wait_vm(uint32_t n) {
     }
 #undef SUCRE_W
 }
-static_assert(2 * kAhead + 9 <= 21, "wait_vm covers 2 * {0..kAhead} + {0, 3, 9} outstanding instructions");
+static_assert(2 * kAhead + 9 <= 63, "s_waitcnt vmcnt takes six bits");
 
 // Which strips a wave works on: strip k W + wid on even passes k, k W + (W - 1 - wid) on odd ones (the strips are
 // sorted heaviest first, so this boustrophedon deal balances the waves), W = waves of the launch.
@@ -289,80 +309,69 @@ __host__ __device__ __forceinline__ WaveDeal make_deal(uint32_t wid, uint32_t W,
 // The plan: every wave's item stream, written once per image (launch_plan, called by the compaction) so that the
 // per-iteration kernels do no bookkeeping.  (History: the first strip kernel walked the strips itself with two
 // cursors; 136 scalar instructions per item on the CU's one scalar unit put a 74 us floor under the launch,
-// measured with both the loads and the arithmetic compiled out.)
+// measured with both the loads and the arithmetic compiled out.  Rounds 2-3 listed self-describing items -- kind, wait
+// count, end flag -- that one loop dispatched on: ~85 scalar instructions and 13-26 register copies per item, because
+// every item walked a compare-and-branch chain to its kind and to its s_waitcnt immediate and the accumulators changed
+// registers between the branches.  Round 4: the stream has a fixed grammar per strip, so the consumer is straight-line
+// code per strip with the full chunks in two tight loops, and every wait is an immediate known from the position.)
 //
-// PlanItem.bits: [6:0] nA, [14:8] nB (lanes of the two DMA instructions), [18:16] kind, [22:20] levels of a short
-// chunk, [28:24] how many of this wave's vector-memory instructions may still be outstanding when the item is needed
-// (the items issued after it, two instructions each, plus the stores of the previous strip's end if they were
-// issued after it), [31] the strip ends with this item.
+// A wave's stream, strip after strip (StripEntry says how many): [J plane 768 B][full chunks of four levels, first the
+// ones without an empty slot, then the ones that need the z > 0 test][the short last chunk, r < 4 levels][J-parameter
+// mode: the Adam moments 1536 B].  After the last strip's items come two items that are issued and never consumed (they
+// re-read the wave's first J plane), so that EVERY consumed item has exactly kAhead items issued behind it: the wait
+// of an item is vmcnt(2 kAhead), plus the strip-end stores for the first kAhead items of every strip but the first.
 // ---------------------------------------------------------------------------------------------------------------
-enum ItemKind : uint32_t { kItemJ = 0, kItemChunk = 1, kItemChunkMasked = 2, kItemTail = 3, kItemMoments = 4 };
-
-__host__ __device__ __forceinline__ uint32_t item_bits(uint32_t nA, uint32_t nB, uint32_t kind, uint32_t r, bool end) {
-    return nA | (nB << 8) | (kind << 16) | (r << 20) | (end ? 0x80000000u : 0u);
-}
-
 // kMode 0: J plane, chunks, moments (J-parameter iteration, 9 stores at a strip's end); 1: J plane, chunks
 // (closed-form iteration and update_J, 3 stores).  One thread per (fit wave, strip of that wave): it finds where its
 // strip's items start in the wave's list from the level counts of the wave's earlier strips (at most a handful) and
-// writes them, waits included.  The wait of item i: the items issued after it (item i is consumed after the items up to
-// i + kAhead were issued: two instructions each), plus the previous strip's stores if they were issued after it -- which
-// is the case for the first kAhead items of every strip but the wave's first.  (The first version replayed the issue
-// order serially, one thread per wave over all its strips: 90 + 60 us per image for the two modes.)
+// writes them.  (The first version replayed the issue order serially, one thread per wave over all its strips: 90 + 60 us
+// per image for the two modes.)
 __device__ __forceinline__ uint32_t strip_items(uint32_t levels, int mode) { return 1u + ((levels + 3u) >> 2) + (mode == 0 ? 1u : 0u); }
 
 __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, int fmt, uint32_t W0, uint32_t W1,
-                                                   uint32_t Kmax, uint32_t stride0, uint32_t stride1, PlanItem *__restrict__ plan0,
-                                                   PlanItem *__restrict__ plan1, uint32_t *__restrict__ count0,
-                                                   uint32_t *__restrict__ count1, uint64_t comp_off, uint64_t state_off) {
+                                                   uint32_t Kmax, uint32_t stride0, uint32_t stride1, uint32_t kmax0, uint32_t kmax1,
+                                                   PlanItem *__restrict__ plan0, PlanItem *__restrict__ plan1,
+                                                   StripEntry *__restrict__ strips0, StripEntry *__restrict__ strips1,
+                                                   uint32_t *__restrict__ count0, uint32_t *__restrict__ count1, uint64_t comp_off,
+                                                   uint64_t state_off) {
     const int mode = blockIdx.y;   // both plans in one launch
-    const uint32_t W = mode ? W1 : W0, stride = mode ? stride1 : stride0;
+    const uint32_t W = mode ? W1 : W0, stride = mode ? stride1 : stride0, kmax = mode ? kmax1 : kmax0;
     PlanItem *plan = mode ? plan1 : plan0;
+    StripEntry *strips = mode ? strips1 : strips0;
     uint32_t *count = mode ? count1 : count0;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     const uint32_t wid = idx / Kmax, k = idx - wid * Kmax;
     if (wid >= W) return;
     const WaveDeal d = make_deal(wid, W, (uint32_t)n_strips);
-    if (k == 0u && d.K == 0u) count[wid] = 0u;
+    if (k == 0u) count[wid] = d.K;
     if (k >= d.K) return;
-    uint32_t start = 0u, n = 0u;   // first item of strip k in the wave's list; items of the whole list
-    for (uint32_t kk = 0; kk < d.K; ++kk) {
-        const uint32_t c = strip_items(meta[d.strip(kk)].levels, mode);
-        if (kk < k) start += c;
-        n += c;
-    }
-    if (k == 0u) count[wid] = n;
+    uint32_t start = 0u;   // first item of strip k in the wave's list
+    for (uint32_t kk = 0; kk < k; ++kk) start += strip_items(meta[d.strip(kk)].levels, mode);
     const uint32_t strip = d.strip(k);
     const StripMeta m = meta[strip];
-    const uint32_t nch = (m.levels + 3u) >> 2;
+    const uint32_t nfull = m.levels >> 2, r = m.levels & 3u;   // full chunks, levels of the short last one
+    const uint32_t nu = min(nfull, m.full >> 2);               // chunks wholly below the strip's smallest pixel count
     const uint32_t lb = (uint32_t)level_bytes(fmt);
     const uint64_t st = state_off + (uint64_t)strip * (kStateFloats * 4);
-    const uint32_t kStores = mode == 0 ? 9u : 3u;
-    PlanItem *out = plan + (size_t)wid * stride;
-    auto put = [&](uint32_t pos, uint32_t src64, uint32_t bits) {
-        const uint32_t i = start + pos;
-        const uint32_t issued = min(n, i + 1u + (uint32_t)kAhead);
-        const uint32_t vm = 2u * (issued - 1u - i) + ((k > 0u && pos < (uint32_t)kAhead) ? kStores : 0u);
-        out[i] = PlanItem{src64, bits | (vm << 24), strip, 0u};
-    };
-    put(0u, (uint32_t)(st >> 6), item_bits(32u, 16u, kItemJ, 0u, mode != 0 && nch == 0u));
-    for (uint32_t g = 0; g < nch; ++g) {
-        const uint32_t r = min((uint32_t)kGroupLv, m.levels - g * kGroupLv);
-        const uint64_t src = comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb;
-        const uint32_t kind = r < (uint32_t)kGroupLv ? kItemTail : ((g + 1u) * kGroupLv <= m.full ? kItemChunk : kItemChunkMasked);
-        put(1u + g, (uint32_t)(src >> 6), item_bits((fmt ? 8u : 16u) * r, 12u * r, kind, r, mode != 0 && g + 1u == nch));
+    PlanItem *out = plan + (size_t)wid * stride + start;
+    strips[(size_t)wid * kmax + k] = StripEntry{strip, nu | ((nfull - nu) << 8) | (r << 16)};
+    *out++ = PlanItem{(uint32_t)(st >> 6), item_shape(3u * kStripPx * 4u, false)};
+    for (uint32_t g = 0; g < nfull; ++g)
+        *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb) >> 6), item_shape((uint32_t)chunk_bytes(fmt), true)};
+    if (r) *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)nfull * kGroupLv) * lb) >> 6), item_shape(r * lb, false)};
+    if (mode == 0) *out++ = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_shape(6u * kStripPx * 4u, false)};
+    if (k + 1u == d.K) {   // the trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
+        const uint64_t st0 = state_off + (uint64_t)d.strip(0) * (kStateFloats * 4);
+        for (int j = 0; j < 3; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false)};
     }
-    if (mode == 0) put(1u + nch, (uint32_t)((st + 3 * kStripPx * 4) >> 6), item_bits(64u, 32u, kItemMoments, 0u, true));
 }
-
-__device__ __forceinline__ uint32_t item_kind(uint32_t bits) { return (bits >> 16) & 7u; }
 
 // Plan items are read through the constant address space: for it the compiler emits scalar loads (s_load) whenever the
 // address is wave-uniform and tracks their completion itself.  A vector load here would count in vmcnt and be waited
 // for with vmcnt(0), draining the ring.  (A hand-issued s_load in inline asm with the wait in a second statement is
 // NOT safe: the compiler may copy the destination registers between the two -- e.g. at the unrolled loop's back
 // edge -- before the data has landed; seen as strips ended twice or never once two processes shared the GPU.)
-typedef uint32_t ItemRegs __attribute__((ext_vector_type(4)));   // src64, bits, strip, pad
+typedef uint32_t ItemRegs __attribute__((ext_vector_type(2)));   // PlanItem: src64, shape / StripEntry: strip, counts
 typedef const __attribute__((address_space(4))) ItemRegs *ConstItems;
 
 // A wave-uniform pointer that the compiler may hold in vector registers -> scalar registers.
@@ -373,15 +382,10 @@ __device__ __forceinline__ T *uniform_ptr(T *p) {
     return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
 }
 
-
-__device__ __forceinline__ ConstItems const_items(const PlanItem *p) {
+template <class T>
+__device__ __forceinline__ ConstItems const_items(const T *p) {
+    static_assert(sizeof(T) == 8, "two dwords per entry");
     return (ConstItems)(reinterpret_cast<uintptr_t>(uniform_ptr(p)));
-}
-
-// Issues the item described by `it` into `slot` (LDS byte address).
-__device__ __forceinline__ void issue_item(const ItemRegs &it, const uint8_t *__restrict__ ws, uint32_t slot, uint32_t lane) {
-    const uint8_t *src = ws + ((uint64_t)it.x << 6);
-    dma_item(src, slot, lane, it.y & 127u, (it.y >> 8) & 127u);
 }
 
 // A full chunk in a ring slot -> this lane's four ranges and three colour dwords.
@@ -409,62 +413,80 @@ __device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t
     for (int c = 0; c < 3; ++c) k[c] = cb[c * kStripPx * r + lane * r + j];
 }
 
-// The streaming skeleton shared by the fit kernels: the wave's items in plan order, kAhead of them in flight.
+// The streaming skeleton shared by the fit kernels: the wave's strips in plan order, kAhead items in flight at any time.
 //   on_J(slot pointer)                      a strip begins: its J plane has landed
 //   on_chunk(slot pointer, masked)          a full chunk
 //   on_tail(slot pointer, r)                the strip's short last chunk
-//   on_end(strip, slot pointer or nullptr)  the strip is complete (J-parameter mode: its moments have landed);
-//                                           must issue exactly the mode's number of vector stores per lane
-template <int kFmt, class OnJ, class OnChunk, class OnTail, class OnEnd>
-__device__ __forceinline__ void stream_items(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n,
-                                             const uint8_t *__restrict__ ws, int wave, int lane, OnJ on_J,
-                                             OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
-    if (n == 0) return;
+//   on_end(strip, slot pointer or nullptr)  the strip is complete (kMoments: its moments have landed); must issue exactly
+//                                           kStores vector stores per lane (9 with the moments, 3 without)
+// One STEP per item: wait for the LDS reads of the item whose slot is about to be overwritten, issue item i + kAhead into
+// it, fetch the descriptor of item i + kAhead + 1 (scalar load, used one step later), wait for item i.  The wait is an
+// immediate: vmcnt(2 kAhead), or vmcnt(2 kAhead + kStores) for the first kAhead items behind a strip's stores.
+template <int kFmt, int kStores, bool kMoments, class OnJ, class OnChunk, class OnTail, class OnEnd>
+__device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
+                                              uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, OnJ on_J,
+                                              OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
+    static_assert(kRing == 3, "the slot rotation below is written for a ring of three");
+    if (K == 0) return;
     const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
-    // descriptors of the items in flight: d[S] describes the item that lives in ring slot S
+    const uint8_t *ringp = &lds.ring[wave][0][0];
     const ConstItems items = const_items(plan);
-    ItemRegs d[kRing];
-#pragma unroll
-    for (int S = 0; S < kRing; ++S) d[S] = items[(uint32_t)S < n ? S : 0];
-#pragma unroll
-    for (int S = 0; S < kAhead; ++S)
-        if ((uint32_t)S < n) issue_item(d[S], ws, ring0 + (uint32_t)S * kSlot, lane);
-    uint32_t i = 0;
-    bool more = true;
-    while (more) {
-        // the loop is unrolled over the ring, so slots and descriptor registers are compile-time: one step consumes
-        // item i from slot S, issues item i + kAhead into slot (S + kAhead) % kRing, and refills d[S] with the
-        // descriptor of item i + kRing
-#pragma unroll
-        for (int S = 0; S < kRing; ++S) {
-            if (more) {
-                const int Sin = (S + kAhead) % kRing;
-                // Slot Sin held item i - 1.  Its LDS reads must have RETURNED before the DMA below may overwrite it:
-                // a chunk's reads have (the arithmetic consumed them), but a J plane is read into registers that are
-                // first used one step later -- without this wait the DMA raced those reads (rare, and only under load:
-                // wrong J, first channel first, seen when other work shared the GPU).
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (i + (uint32_t)kAhead < n) issue_item(d[Sin], ws, ring0 + (uint32_t)Sin * kSlot, lane);   // loaded one step ago
-                const uint32_t bits = d[S].y, strip = d[S].z;
-                if (i + (uint32_t)kRing < n) d[S] = items[i + (uint32_t)kRing];
-                const uint32_t vm = (bits >> 24) & 31u;
-                if (vm == 2u * kAhead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead) : "memory");  // the steady state
-                else wait_vm(vm);
-                const uint8_t *sp = &lds.ring[wave][S][0];
-                const uint32_t kind = item_kind(bits);
-                if (kind == kItemChunk) on_chunk(sp, false);
-                else if (kind == kItemChunkMasked) on_chunk(sp, true);
-                else if (kind == kItemJ) on_J(sp);
-                else if (kind == kItemTail) on_tail(sp, (bits >> 20) & 7u);
-                if (bits & 0x80000000u) on_end(strip, kind == kItemMoments ? sp : (const uint8_t *)nullptr);
-                ++i;
-                more = i < n;
-            }
+    const ConstItems strips = const_items(strip_list);
+    // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch)
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t voffB_full = (64u + min((uint32_t)lane, full_chunk_b(kFmt) - 1u)) * 16u;
+    auto issue = [&](const ItemRegs it, uint32_t slot_off) {
+        const uint8_t *src = ws + ((uint64_t)it.x << 6);
+        const uint32_t slot = ring0 + slot_off;
+        if (it.y & kShapeFull) {
+            dma_item(src, slot, slot + 1024u, lane16, voffB_full);
+        } else {
+            const uint32_t a_last = it.y & 127u, b_last = (it.y >> 8) & 127u, b_base = (it.y >> 16) & 127u;
+            dma_item(src, slot, slot + ((a_last + 1u) << 4), min((uint32_t)lane, a_last) << 4, (b_base + min((uint32_t)lane, b_last)) << 4);
         }
+    };
+    // the first kAhead items (a wave with a strip has at least 1 + kAhead + 1 entries: its items, the trailing ones, the spare)
+    issue(items[0], 0u);
+    issue(items[1], (uint32_t)kSlot);
+    ItemRegs nxt = items[2];           // item i + kAhead, issued at the top of step i
+    uint32_t i = 0;                    // the item being consumed
+    uint32_t cs = 0u;                  // byte offset of its slot in the wave's ring; item i + kAhead goes to the slot before it
+    uint32_t behind = 0u;              // how many of the next items were issued before the previous strip's stores
+    auto step = [&]() -> const uint8_t * {
+        // The slot that takes item i + kAhead held item i - 1.  Its LDS reads must have RETURNED before the DMA may overwrite
+        // it: a chunk's reads have (the arithmetic consumed them), but a J plane is read into registers that are first used
+        // one step later -- without this wait the DMA raced those reads (rare, and only under load: wrong J, first channel
+        // first, seen when other work shared the GPU).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t is = cs == 0u ? (uint32_t)(2 * kSlot) : cs - (uint32_t)kSlot;
+        issue(nxt, is);
+        nxt = items[i + (uint32_t)kAhead + 1u];
+        if (behind) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead + kStores) : "memory");
+            --behind;
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead) : "memory");
+        }
+        const uint8_t *sp = ringp + cs;
+        cs = cs == (uint32_t)(2 * kSlot) ? 0u : cs + (uint32_t)kSlot;
+        ++i;
+        return sp;
+    };
+    ItemRegs se = strips[0];
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t strip = se.x, counts = se.y;
+        if (k + 1u < K) se = strips[k + 1u];
+        const uint32_t nu = counts & 255u, nm = (counts >> 8) & 255u, r = (counts >> 16) & 7u;
+        on_J(step());
+        for (uint32_t g = 0; g < nu; ++g) on_chunk(step(), false);
+        for (uint32_t g = 0; g < nm; ++g) on_chunk(step(), true);
+        if (r) on_tail(step(), r);
+        if (kMoments) on_end(strip, step());
+        else on_end(strip, (const uint8_t *)nullptr);
+        behind = (uint32_t)kAhead;
     }
-    wait_vm(0);  // nothing of ours is in flight past this point
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of ours is in flight past this point (the trailing items included)
 }
-
 
 // Two-level, fixed-order float64 reduction of the per-workgroup partials (layout [kNumSums][n_blocks]):
 //   gpart[q][g] = sum of the 32 workgroups of group g  (one load per lane + fixed-shape shuffle tree)
@@ -588,12 +610,12 @@ __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums],
 // One wave's share of a J-parameter iteration on one image (sucre.py:142-148 with J among the parameters): streams
 // the wave's items, steps J of every strip, and keeps adding the lane's shares of the global sums to acc / sBeta.
 template <int kFmt>
-__device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n_items,
+__device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                           const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
                                           const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3]) {
     float J[3] = {0.f, 0.f, 0.f};
-    stream_items<kFmt>(
-        lds, plan, n_items, ws, wave, lane,
+    stream_strips<kFmt, 9, true>(
+        lds, plan, strips, n_strips_wave, ws, wave, lane,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -639,7 +661,8 @@ __device__ __forceinline__ void zero_acc(Acc &acc) {
 // J-parameter iteration of one image: one launch.
 template <bool kFused, int kFmt>
 __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t *__restrict__ ws,
-                                                       const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
+                                                       const PlanItem *__restrict__ plan, const StripEntry *__restrict__ plan_strips, const uint32_t *__restrict__ plan_count,
+                                                       uint32_t plan_stride, uint32_t plan_kmax,
                                                        float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                        float *__restrict__ state, float *partials, const AdamCoef co,
                                                        unsigned *ticket, double *gpart, int n_groups, double *sums,
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     // a store compacted in the other format is not read at all; the logged cost turns NaN instead
     const bool fmt_ok = *obs_format == (uint32_t)kFmt;
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t n_items = fmt_ok ? plan_count[wid] : 0u;
+    const uint32_t n_mine = fmt_ok ? plan_count[wid] : 0u;   // strips of this wave
 
     // The lane's shares of the global sums keep accumulating across its strips; the per-pixel sums restart with
     // every strip.
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     zero_acc(acc);
     if (!fmt_ok) acc.cost = __builtin_nanf("");
     float sBeta[3] = {0.f, 0.f, 0.f};
-    grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, n_items, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+    grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
 
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
                          sBeta[0], sBeta[1], sBeta[2], acc.cost};
@@ -673,13 +696,13 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
 struct ClosedSums { float sB[3], sGZ[3], sBeta[3], cost; };
 
 template <int kFmt, bool kJOnly>
-__device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t n_items,
+__device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                             const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
                                             const Water &w, bool fmt_ok, ClosedSums &cs) {
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
-    stream_items<kFmt>(
-        lds, plan, n_items, ws, wave, lane,
+    stream_strips<kFmt, 3, false>(
+        lds, plan, strips, n_strips_wave, ws, wave, lane,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -737,7 +760,8 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
 
 template <bool kFused, int kFmt, bool kJOnly>
 __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uint8_t *__restrict__ ws,
-                                                         const PlanItem *__restrict__ plan, const uint32_t *__restrict__ plan_count, uint32_t plan_stride,
+                                                         const PlanItem *__restrict__ plan, const StripEntry *__restrict__ plan_strips, const uint32_t *__restrict__ plan_count,
+                                                       uint32_t plan_stride, uint32_t plan_kmax,
                                                          float *pstate, const uint64_t *__restrict__ n_obs_total,
                                                          float *__restrict__ state, float *partials, const AdamCoef co,
                                                          unsigned *ticket, double *gpart, int n_groups, double *sums,
@@ -751,9 +775,9 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
     // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
     // plan was written for the store's format, so the items themselves are sound)
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t n_items = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;
+    const uint32_t n_mine = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;   // strips of this wave
     ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
-    closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, n_items, ws, state, wave, lane, w, fmt_ok, cs);
+    closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, fmt_ok, cs);
     if (kJOnly) return;
     float s[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
@@ -772,8 +796,8 @@ struct Params9 { float v[9]; };
 // ---------------------------------------------------------------------------------------------------------------
 struct GroupImage {
     uint8_t *ws;
-    uint64_t off_plan[2], off_count[2], off_state, off_format, off_params;
-    uint32_t stride[2], n_waves[2];
+    uint64_t off_plan[2], off_strips[2], off_count[2], off_state, off_format, off_params;
+    uint32_t stride[2], kmax[2], n_waves[2];
 };
 
 struct GroupHeader {
@@ -852,11 +876,12 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_i
         const bool fmt_ok = *reinterpret_cast<const uint32_t *>(ws + im.off_format) == (uint32_t)kFmt;
         if (!fmt_ok) { acc.cost = __builtin_nanf(""); cs.cost = __builtin_nanf(""); continue; }
         if (wid >= im.n_waves[kMode]) continue;
-        const uint32_t n_items = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
+        const uint32_t n_mine = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
         const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + im.off_plan[kMode]) + (size_t)wid * im.stride[kMode]);
+        const StripEntry *strips = uniform_ptr(reinterpret_cast<const StripEntry *>(ws + im.off_strips[kMode]) + (size_t)wid * im.kmax[kMode]);
         float *state = reinterpret_cast<float *>(ws + im.off_state);
-        if (kMode == 0) grad_pass<kFmt>(lds, plan, n_items, ws, state, wave, lane, w, gscale, co, acc, sBeta);
-        else closed_pass<kFmt, false>(lds, plan, n_items, ws, state, wave, lane, w, true, cs);
+        if (kMode == 0) grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+        else closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, true, cs);
     }
     float s[kNumSums];
     if (kMode == 0) {
@@ -974,7 +999,8 @@ static void launch_fit_kernel(Kernel kernel, int mode, const Layout &L, uint8_t 
                               hipStream_t s) {
     hipLaunchKernelGGL(kernel, dim3(L.fit_blocks[mode]), dim3(256), 0, s, ws,
                        reinterpret_cast<const PlanItem *>(ws + L.off_plan[mode]),
-                       reinterpret_cast<const uint32_t *>(ws + L.off_plan_count[mode]), (uint32_t)L.plan_stride[mode],
+                       reinterpret_cast<const StripEntry *>(ws + L.off_plan_strips[mode]),
+                       reinterpret_cast<const uint32_t *>(ws + L.off_plan_count[mode]), (uint32_t)L.plan_stride[mode], (uint32_t)L.plan_kmax[mode],
                        reinterpret_cast<float *>(ws + L.off_params),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
                        reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(ws + L.off_partials), co,
@@ -1039,8 +1065,10 @@ hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
     const uint32_t Wmin = W0 < W1 ? W0 : W1, Wmax = W0 < W1 ? W1 : W0;
     const uint32_t Kmax = ((uint32_t)L.n_strips + Wmin - 1u) / Wmin;   // strips of the busiest wave (of either mode)
     hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips, fmt, W0, W1, Kmax,
-                       (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], reinterpret_cast<PlanItem *>(ws + L.off_plan[0]),
-                       reinterpret_cast<PlanItem *>(ws + L.off_plan[1]), reinterpret_cast<uint32_t *>(ws + L.off_plan_count[0]),
+                       (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], (uint32_t)L.plan_kmax[0], (uint32_t)L.plan_kmax[1],
+                       reinterpret_cast<PlanItem *>(ws + L.off_plan[0]), reinterpret_cast<PlanItem *>(ws + L.off_plan[1]),
+                       reinterpret_cast<StripEntry *>(ws + L.off_plan_strips[0]), reinterpret_cast<StripEntry *>(ws + L.off_plan_strips[1]),
+                       reinterpret_cast<uint32_t *>(ws + L.off_plan_count[0]),
                        reinterpret_cast<uint32_t *>(ws + L.off_plan_count[1]), (uint64_t)L.off_comp, (uint64_t)L.off_state);
     return hipGetLastError();
 }
@@ -1067,8 +1095,8 @@ hipError_t launch_group_set_image(void *group, int i, const Layout &L, uint8_t *
     GroupImage im;
     im.ws = ws;
     for (int m = 0; m < 2; ++m) {
-        im.off_plan[m] = L.off_plan[m]; im.off_count[m] = L.off_plan_count[m];
-        im.stride[m] = (uint32_t)L.plan_stride[m]; im.n_waves[m] = (uint32_t)L.fit_blocks[m] * 4u;
+        im.off_plan[m] = L.off_plan[m]; im.off_strips[m] = L.off_plan_strips[m]; im.off_count[m] = L.off_plan_count[m];
+        im.stride[m] = (uint32_t)L.plan_stride[m]; im.kmax[m] = (uint32_t)L.plan_kmax[m]; im.n_waves[m] = (uint32_t)L.fit_blocks[m] * 4u;
     }
     im.off_state = L.off_state;
     im.off_format = L.off_total_chunks + sizeof(uint64_t);

@@ -50,12 +50,16 @@ constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (
 constexpr int kClosedGrid = 256 * kClosedWaves;
 constexpr int kMaxViews = 4096;
 
-// One entry of a wave's item stream (fit.hip, plan_kernel): what to copy into the LDS ring and what it is.
+// One entry of a wave's item stream (fit.hip, plan_kernel): what to copy into the LDS ring.  What the item IS follows
+// from its position: a wave's stream is, strip after strip, [J plane][full chunks, the unmasked ones first][short last
+// chunk][moments (J-parameter mode)], and StripEntry says how many of each the strip has.
 struct PlanItem {
     uint32_t src64;   // source address: workspace base + 64 * src64
-    uint32_t bits;    // lanes of the two DMA instructions, kind, wait count, end-of-strip flag (fit.hip)
-    uint32_t strip;   // the strip the item belongs to
-    uint32_t pad;
+    uint32_t shape;   // lanes of the two DMA instructions (fit.hip, item_shape)
+};
+struct StripEntry {
+    uint32_t strip;   // index of the strip (state block, StripMeta)
+    uint32_t counts;  // [7:0] full chunks without an empty slot, [15:8] full chunks that need the z > 0 test, [18:16] levels of the short last chunk
 };
 
 struct Layout {
@@ -89,8 +93,10 @@ struct Layout {
     size_t off_partials;    // float  [kNumSums][n_blocks]  one partial per fit workgroup
     size_t off_state;       // float [n_strips][9][64]: J, exp_avg, exp_avg_sq (three channel planes each) of every strip
     size_t off_plan[2];     // PlanItem [4 n_blocks][plan_stride]: item streams of the fit waves (J-parameter / closed-form)
-    size_t off_plan_count[2];  // uint32 [4 n_blocks] items of every wave
-    size_t plan_stride[2];  // items reserved per wave
+    size_t off_plan_strips[2]; // StripEntry [4 n_blocks][plan_kmax]: the strips of every wave, in the order it works on them
+    size_t off_plan_count[2];  // uint32 [4 n_blocks] strips of every wave
+    size_t plan_stride[2];  // items reserved per wave (its strips' items + two never-consumed trailing items + one spare)
+    size_t plan_kmax[2];    // strips reserved per wave
     size_t total;
 };
 
@@ -139,8 +145,10 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     {   // a wave gets at most ceil(n_strips / waves) strips of at most ceil(n_views / 4) chunks + J plane + moments
         for (int m = 0; m < 2; ++m) {
             const size_t waves = (size_t)L->fit_blocks[m] * 4;
-            L->plan_stride[m] = (((size_t)L->n_strips + waves - 1) / waves) * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2);
+            L->plan_kmax[m] = ((size_t)L->n_strips + waves - 1) / waves;
+            L->plan_stride[m] = L->plan_kmax[m] * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2) + 3;
             L->off_plan[m] = take(waves * L->plan_stride[m] * sizeof(PlanItem));
+            L->off_plan_strips[m] = take(waves * L->plan_kmax[m] * sizeof(StripEntry));
             L->off_plan_count[m] = take(waves * sizeof(uint32_t));
         }
     }

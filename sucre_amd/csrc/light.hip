@@ -211,6 +211,12 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
     const uint8_t *ch = sobs + (size_t)g * (kGroupLv * level_bytes(0));
     const float *ex = reinterpret_cast<const float *>(sext + (size_t)g * (kGroupLv * kExtLevelBytes));
     LightChunk c;
+    if (kExpNoLoad) {  // ablation build only (experiment.h): no memory instruction, plausible values
+        const float f = 1.0f + 0.001f * (float)lane;
+        c = LightChunk{{3.0f * f, 3.1f * f, 3.2f * f, r == kGroupLv ? 3.3f * f : 0.0f}, {0.1f * f, 0.2f, -0.1f, 0.3f},
+                       {0.2f, -0.1f * f, 0.1f, 0.2f}, {3.0f, 3.1f, 3.2f * f, 3.3f}, {0x40506070u, 0x30405060u + lane, 0x20304050u}};
+        return c;
+    }
     if (r == kGroupLv) {
         const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + 4 * kStripPx * kGroupLv) + 3 * lane;
@@ -235,6 +241,14 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
         }
     }
     return c;
+}
+
+// every loaded word of a chunk enters one float (the arithmetic-free ablation build's only use of the data)
+__device__ __forceinline__ float chunk_checksum(const LightChunk &k) {
+    float s = (float)(k.cc[0] ^ k.cc[1] ^ k.cc[2]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (k.zz[j] + k.xx[j]) + (k.yy[j] + k.ww[j]);
+    return s;
 }
 
 // The 26 sums over the workgroups' partials, float64, fixed order (thread t adds the workgroups t, t + 256, ..., then a
@@ -380,6 +394,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
                     ColourChunk fc;
                     if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
+                    if (kExpNoCompute) {  // ablation build only: touch the data, skip the model
+                        num[0] += chunk_checksum(kk);
+                        den[0] = 1.0f;
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (!(kk.zz[j] > 0.0f)) continue;
@@ -423,6 +442,10 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
             ColourChunk fc;
             if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
+            if (kExpNoCompute) {
+                acc.s[9] += chunk_checksum(kk);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!(kk.zz[j] > 0.0f)) continue;  // padding slot
