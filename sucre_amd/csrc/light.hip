@@ -207,6 +207,11 @@ __device__ __forceinline__ ColourChunk load_colour_chunk(const uint8_t *sext2, u
 
 // Chunk g of a strip (r of its four levels exist, layout.h / compact.hip) -> this lane's pixel: ranges, extension
 // planes (camera point or float colour) and colour bytes of up to four levels; levels that do not exist read z = 0.
+// kLastUse: this is the launch's last read of the chunk -> non-temporal loads, like the default path's DMAs (measured,
+// J as a parameter: 356 -> 341 us per iteration at config 2).  The closed-form kernel reads every chunk twice, a strip
+// apart: its first read stays a plain load (with both reads non-temporal it was 4 % slower: what the caches still hold
+// of the strip serves the second read).
+template <bool kLastUse = true>
 __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, const uint8_t *sext, uint32_t g, uint32_t r, int lane) {
     const uint8_t *ch = sobs + (size_t)g * (kGroupLv * level_bytes(0));
     const float *ex = reinterpret_cast<const float *>(sext + (size_t)g * (kGroupLv * kExtLevelBytes));
@@ -218,13 +223,17 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
         return c;
     }
     if (r == kGroupLv) {
-        const float4 z4 = *reinterpret_cast<const float4 *>(ch + lane * 16);
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(ch + 4 * kStripPx * kGroupLv) + 3 * lane;
-        const float4 x4 = *reinterpret_cast<const float4 *>(ex + lane * 4);
-        const float4 y4 = *reinterpret_cast<const float4 *>(ex + kStripPx * kGroupLv + lane * 4);
-        const float4 w4 = *reinterpret_cast<const float4 *>(ex + 2 * kStripPx * kGroupLv + lane * 4);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+        auto ld4 = [](const void *p) { return kLastUse ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p); };
+        const f4 z4 = ld4(ch + lane * 16);
+        const u3 cw = kLastUse ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(ch + 4 * kStripPx * kGroupLv + 12 * lane))
+                               : *reinterpret_cast<const u3 *>(ch + 4 * kStripPx * kGroupLv + 12 * lane);
+        const f4 x4 = ld4(ex + lane * 4);
+        const f4 y4 = ld4(ex + kStripPx * kGroupLv + lane * 4);
+        const f4 w4 = ld4(ex + 2 * kStripPx * kGroupLv + lane * 4);
         c = LightChunk{{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
-                       {cp[0], cp[1], cp[2]}};
+                       {cw.x, cw.y, cw.z}};
     } else {
         c.cc[0] = c.cc[1] = c.cc[2] = 0u;
         const uint8_t *cb = ch + 4 * kStripPx * r;
@@ -391,12 +400,12 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 for (int c = 0; c < 3; ++c) num[c] = den[c] = 0.f;
                 for (uint32_t g = 0; g < nch; ++g) {
                     const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
-                    const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
+                    const LightChunk kk = load_light_chunk<kJOnly>(sobs, sext, g, rr, lane);
                     ColourChunk fc;
                     if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
                     if (kExpNoCompute) {  // ablation build only: touch the data, skip the model
                         num[0] += chunk_checksum(kk);
-                        den[0] = 1.0f;
+                        den[0] = den[1] = den[2] = 1.0f;
                         continue;
                     }
 #pragma unroll
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             // (fit_math.h) -- the strip is solved again with gradual underflow (same bits for every other pixel)
             const bool zero = den[0] == 0.f || den[1] == 0.f || den[2] == 0.f;
             if (n > 0 && __any(zero)) {   // rare; an unobserved pixel (the strip where the counts reach 0) has no level 0 either
-                const LightChunk k0 = load_light_chunk(sobs, sext, 0, min((uint32_t)kGroupLv, n), lane);
+                const LightChunk k0 = load_light_chunk<false>(sobs, sext, 0, min((uint32_t)kGroupLv, n), lane);
                 if (__any(zero && k0.zz[0] > 0.0f)) solve(std::true_type{});
             }
 #pragma unroll
@@ -437,11 +446,19 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         }
         float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
         const float bJ[3] = {beta[0] * J[0], beta[1] * J[1], beta[2] * J[2]};   // constant over the pixel's observations
+        // The next chunk's loads are issued before this chunk's arithmetic (one chunk = 19 registers ahead): the loop used to
+        // load, wait, compute -- with four waves per SIMD neither the memory system nor the VALU stayed busy (both ablations
+        // near the full kernel's time, profiles/r04_ablation_table.txt).
+        LightChunk kn = nch ? load_light_chunk(sobs, sext, 0, min((uint32_t)kGroupLv, n), lane) : LightChunk{};
         for (uint32_t g = 0; g < nch; ++g) {
             const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
-            const LightChunk kk = load_light_chunk(sobs, sext, g, rr, lane);
+            const LightChunk kk = kn;
+            if (!kBoth && g + 1u < nch) kn = load_light_chunk(sobs, sext, g + 1u, min((uint32_t)kGroupLv, n - (g + 1u) * kGroupLv), lane);
             ColourChunk fc;
-            if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
+            if (kBoth) {
+                fc = load_colour_chunk(sext2, g, rr, lane);
+                if (g + 1u < nch) kn = load_light_chunk(sobs, sext, g + 1u, min((uint32_t)kGroupLv, n - (g + 1u) * kGroupLv), lane);
+            }
             if (kExpNoCompute) {
                 acc.s[9] += chunk_checksum(kk);
                 continue;
