@@ -317,7 +317,7 @@ __host__ __device__ __forceinline__ WaveDeal make_deal(uint32_t wid, uint32_t W,
 //
 // A wave's stream, strip after strip (StripEntry says how many): [J plane 768 B][full chunks of four levels, first the
 // ones without an empty slot, then the ones that need the z > 0 test][the short last chunk, r < 4 levels][J-parameter
-// mode: the Adam moments 1536 B].  After the last strip's items come two items that are issued and never consumed (they
+// mode: the Adam moments 1536 B].  After the last strip's items come kAhead items that are issued and never consumed (they
 // re-read the wave's first J plane), so that EVERY consumed item has exactly kAhead items issued behind it: the wait
 // of an item is vmcnt(2 kAhead), plus the strip-end stores for the first kAhead items of every strip but the first.
 // ---------------------------------------------------------------------------------------------------------------
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
         *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb) >> 6), item_shape((uint32_t)chunk_bytes(fmt), true)};
     if (r) *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)nfull * kGroupLv) * lb) >> 6), item_shape(r * lb, false)};
     if (mode == 0) *out++ = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_shape(6u * kStripPx * 4u, false)};
-    if (k + 1u == d.K) {   // the trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
+    if (k + 1u == d.K) {   // the kAhead trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
         const uint64_t st0 = state_off + (uint64_t)d.strip(0) * (kStateFloats * 4);
-        for (int j = 0; j < 3; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false)};
+        for (int j = 0; j < kAhead + 1; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false)};
     }
 }
 
@@ -426,7 +426,6 @@ template <int kFmt, int kStores, bool kMoments, class OnJ, class OnChunk, class 
 __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
                                               uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, OnJ on_J,
                                               OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
-    static_assert(kRing == 3, "the slot rotation below is written for a ring of three");
     if (K == 0) return;
     const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
     const uint8_t *ringp = &lds.ring[wave][0][0];
@@ -446,9 +445,9 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         }
     };
     // the first kAhead items (a wave with a strip has at least 1 + kAhead + 1 entries: its items, the trailing ones, the spare)
-    issue(items[0], 0u);
-    issue(items[1], (uint32_t)kSlot);
-    ItemRegs nxt = items[2];           // item i + kAhead, issued at the top of step i
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) issue(items[q], (uint32_t)(q * kSlot));
+    ItemRegs nxt = items[kAhead];      // item i + kAhead, issued at the top of step i
     uint32_t i = 0;                    // the item being consumed
     uint32_t cs = 0u;                  // byte offset of its slot in the wave's ring; item i + kAhead goes to the slot before it
     uint32_t behind = 0u;              // how many of the next items were issued before the previous strip's stores
@@ -458,7 +457,7 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         // one step later -- without this wait the DMA raced those reads (rare, and only under load: wrong J, first channel
         // first, seen when other work shared the GPU).
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t is = cs == 0u ? (uint32_t)(2 * kSlot) : cs - (uint32_t)kSlot;
+        const uint32_t is = cs == 0u ? (uint32_t)((kRing - 1) * kSlot) : cs - (uint32_t)kSlot;   // slot of item i - 1 = of item i + kAhead
         issue(nxt, is);
         nxt = items[i + (uint32_t)kAhead + 1u];
         if (behind) {
@@ -468,7 +467,7 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kAhead) : "memory");
         }
         const uint8_t *sp = ringp + cs;
-        cs = cs == (uint32_t)(2 * kSlot) ? 0u : cs + (uint32_t)kSlot;
+        cs = cs == (uint32_t)((kRing - 1) * kSlot) ? 0u : cs + (uint32_t)kSlot;
         ++i;
         return sp;
     };

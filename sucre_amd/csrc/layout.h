@@ -95,7 +95,7 @@ struct Layout {
     size_t off_plan[2];     // PlanItem [4 n_blocks][plan_stride]: item streams of the fit waves (J-parameter / closed-form)
     size_t off_plan_strips[2]; // StripEntry [4 n_blocks][plan_kmax]: the strips of every wave, in the order it works on them
     size_t off_plan_count[2];  // uint32 [4 n_blocks] strips of every wave
-    size_t plan_stride[2];  // items reserved per wave (its strips' items + two never-consumed trailing items + one spare)
+    size_t plan_stride[2];  // items reserved per wave (its strips' items + the never-consumed trailing items + one spare)
     size_t plan_kmax[2];    // strips reserved per wave
     size_t total;
 };
@@ -146,7 +146,7 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
         for (int m = 0; m < 2; ++m) {
             const size_t waves = (size_t)L->fit_blocks[m] * 4;
             L->plan_kmax[m] = ((size_t)L->n_strips + waves - 1) / waves;
-            L->plan_stride[m] = L->plan_kmax[m] * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2) + 3;
+            L->plan_stride[m] = L->plan_kmax[m] * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2) + SUCRE_RING;   // + kAhead trailing items + a spare
             L->off_plan[m] = take(waves * L->plan_stride[m] * sizeof(PlanItem));
             L->off_plan_strips[m] = take(waves * L->plan_kmax[m] * sizeof(StripEntry));
             L->off_plan_count[m] = take(waves * sizeof(uint32_t));
