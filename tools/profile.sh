@@ -6,7 +6,7 @@
 # the SQ counters.  tools/summarize_prof.py condenses them into profiles/<tag>_<mode>_{kernel_stats.csv,traffic.json,
 # summary.txt}; raw per-dispatch dumps stay on the box.
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 MODES=${*:-"jparam jparam_inflight2 closed light light_closed u16mm_4k shared4"}
 export TMPDIR=/tmp
 mode_args() {
@@ -30,6 +30,11 @@ for MODE in $MODES; do
   M=$(mode_args $MODE)
   if [ $MODE = jparam_inflight2 ]; then   # the default command: two images in flight, kernel durations overlap
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+    # bytes per launch in THIS configuration (counter collection serialises the dispatches, so the window is bench.py's own
+    # HIP-event union, not the profiler's: what the counters add is that a launch moves the same bytes with a neighbour in flight)
+    PMC="--steps 2 --warmup 1 --no-cpu-baseline --num-iter 10 --solo-images 1"
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > $OUT/bench_pmc_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
   else
     STEPS="--steps 2 --warmup 1"; [ $MODE = u16mm_4k ] && STEPS="--steps 1 --warmup 1 --solo-images 1"
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $STEPS --no-cpu-baseline --images-in-flight 1 $M > $OUT/bench_trace.log 2>&1
