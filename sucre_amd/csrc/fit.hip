@@ -236,6 +236,7 @@ struct __attribute__((aligned(16))) FitLds {
     uint8_t ring[4][kRing][kSlot];  // per-wave item ring
     double stot[kSumsPad];
     float wsum[4][kNumSums];
+    double wtotal[4][kNumSums];   // group launches: every wave's sums over the images it has walked so far
     int is_last, is_last_total;  // one flag word per arrive_last level: no wave can see the second verdict as the first
 };
 
@@ -558,6 +559,20 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
     }
 }
 
+// The lanes' ten sums -> lane 0 holds the wave's (fixed-shape shuffle tree).
+__device__ __forceinline__ void wave_sums(float (&s)[kNumSums]) {
+#pragma unroll
+    for (int q = 0; q < kNumSums; ++q) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+    }
+}
+
+template <bool kFused, bool kStep>
+__device__ __forceinline__ void finish_from_wave_sums(FitLds &lds, float *partials, const AdamCoef &co, unsigned *ticket,
+                                                      double *gpart, int n_groups, double *sums, float *pstate,
+                                                      const uint64_t *__restrict__ n_obs_total, double *trace_row);
+
 // End of a fit launch: the lanes' ten sums -> one float32 partial per workgroup -> (fused form) two-level
 // last-arriver reduction in float64 and the Adam step on B, beta, gamma by the workgroup that arrives last.
 template <bool kFused, bool kStep = kFused>
@@ -565,20 +580,25 @@ __device__ __forceinline__ void finish_launch(FitLds &lds, float (&s)[kNumSums],
                                               unsigned *ticket, double *gpart, int n_groups, double *sums,
                                               float *pstate, const uint64_t *__restrict__ n_obs_total,
                                               double *trace_row) {
-    const int n_blocks = gridDim.x;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // ten workgroup sums: wave shuffle tree, then the four waves in fixed order
-#pragma unroll
-    for (int q = 0; q < kNumSums; ++q) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
-    }
+    wave_sums(s);
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < kNumSums; ++q) lds.wsum[wave][q] = s[q];
     }
+    finish_from_wave_sums<kFused, kStep>(lds, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
+}
+
+// ... from the four waves' sums in lds.wsum on.
+template <bool kFused, bool kStep>
+__device__ __forceinline__ void finish_from_wave_sums(FitLds &lds, float *partials, const AdamCoef &co, unsigned *ticket,
+                                                      double *gpart, int n_groups, double *sums, float *pstate,
+                                                      const uint64_t *__restrict__ n_obs_total, double *trace_row) {
+    const int n_blocks = gridDim.x;
+    const int t = threadIdx.x;
     __syncthreads();
     // Publish the workgroup's partials with agent-scope write-through (sc1) stores: they need no release fence
     // (a release = L2 write-back in EVERY workgroup measured +260 us per launch; cdna_hip_programming.md section 5,
@@ -869,30 +889,52 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_i
     zero_acc(acc);
     float sBeta[3] = {0.f, 0.f, 0.f};
     ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+    // The lanes' ten float32 sums run over ONE image, as in the per-image kernels: at every image boundary the wave adds
+    // them up (the shuffle tree of the launch's end) and lane 0 carries the wave's total on in float64 (LDS, the wave's own
+    // slots).  Carried in float32 across a rank's 64 images (BASELINE config 4) the cost lost 1.2e-5 of its value to rounding
+    // (tests/test_gpu_config4.py; 5e-7 at four images).  A group of one image keeps its bits: (float)(double)x = x.
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kNumSums; ++q) lds.wtotal[wave][q] = 0.0;
+    }
+    bool poisoned = false;
     for (int i = 0; i < n_images; ++i) {
         const GroupImage im = images[i];
         uint8_t *ws = uniform_ptr(im.ws);   // between images nothing is in flight: ordinary loads are harmless here
         const bool fmt_ok = *reinterpret_cast<const uint32_t *>(ws + im.off_format) == (uint32_t)kFmt;
-        if (!fmt_ok) { acc.cost = __builtin_nanf(""); cs.cost = __builtin_nanf(""); continue; }
+        if (!fmt_ok) { poisoned = true; continue; }
         if (wid >= im.n_waves[kMode]) continue;
         const uint32_t n_mine = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
         const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + im.off_plan[kMode]) + (size_t)wid * im.stride[kMode]);
         const StripEntry *strips = uniform_ptr(reinterpret_cast<const StripEntry *>(ws + im.off_strips[kMode]) + (size_t)wid * im.kmax[kMode]);
         float *state = reinterpret_cast<float *>(ws + im.off_state);
-        if (kMode == 0) grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
-        else closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, true, cs);
-    }
-    float s[kNumSums];
-    if (kMode == 0) {
-        const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
+        float s[kNumSums];
+        if (kMode == 0) {
+            grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+            const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
 #pragma unroll
-        for (int i = 0; i < kNumSums; ++i) s[i] = q[i];
-    } else {
-        const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
+            for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
+            zero_acc(acc);
+            sBeta[0] = sBeta[1] = sBeta[2] = 0.f;
+        } else {
+            closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, true, cs);
+            const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
 #pragma unroll
-        for (int i = 0; i < kNumSums; ++i) s[i] = q[i];
+            for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
+            cs = ClosedSums{{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+        }
+        wave_sums(s);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < kNumSums; ++j) lds.wtotal[wave][j] += (double)s[j];
+        }
     }
-    finish_launch<true, false>(lds, s, g->partials, co, g->ticket, g->gpart, n_groups, g->sums, nullptr, nullptr, nullptr);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < kNumSums; ++j) lds.wsum[wave][j] = (float)lds.wtotal[wave][j];
+        if (poisoned) lds.wsum[wave][kNumSums - 1] = __builtin_nanf("");   // an image compacted in the other format: the logged cost turns NaN
+    }
+    finish_from_wave_sums<true, false>(lds, g->partials, co, g->ticket, g->gpart, n_groups, g->sums, nullptr, nullptr, nullptr);
 }
 
 // The last pending step; the final parameters also go to every image's own workspace (Restoration.params()).

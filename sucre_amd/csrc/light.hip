@@ -449,15 +449,21 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         // The next chunk's loads are issued before this chunk's arithmetic (one chunk = 19 registers ahead): the loop used to
         // load, wait, compute -- with four waves per SIMD neither the memory system nor the VALU stayed busy (both ablations
         // near the full kernel's time, profiles/r04_ablation_table.txt).
-        LightChunk kn = nch ? load_light_chunk(sobs, sext, 0, min((uint32_t)kGroupLv, n), lane) : LightChunk{};
-        for (uint32_t g = 0; g < nch; ++g) {
-            const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
+        // Closed-form mode has just read the strip front to back for J: the gradient pass walks it BACK to front, so that what
+        // it reads first is what the caches saw last (a second front-to-back walk over a strip larger than a wave's share of
+        // the caches would find none of it).
+        auto chunk_at = [&](uint32_t i) { return kClosed ? nch - 1u - i : i; };
+        auto levels_of = [&](uint32_t g) { return min((uint32_t)kGroupLv, n - g * kGroupLv); };
+        LightChunk kn = nch ? load_light_chunk(sobs, sext, chunk_at(0), levels_of(chunk_at(0)), lane) : LightChunk{};
+        for (uint32_t gi = 0; gi < nch; ++gi) {
+            const uint32_t g = chunk_at(gi);
+            const uint32_t rr = levels_of(g);
             const LightChunk kk = kn;
-            if (!kBoth && g + 1u < nch) kn = load_light_chunk(sobs, sext, g + 1u, min((uint32_t)kGroupLv, n - (g + 1u) * kGroupLv), lane);
+            if (!kBoth && gi + 1u < nch) kn = load_light_chunk(sobs, sext, chunk_at(gi + 1u), levels_of(chunk_at(gi + 1u)), lane);
             ColourChunk fc;
             if (kBoth) {
                 fc = load_colour_chunk(sext2, g, rr, lane);
-                if (g + 1u < nch) kn = load_light_chunk(sobs, sext, g + 1u, min((uint32_t)kGroupLv, n - (g + 1u) * kGroupLv), lane);
+                if (gi + 1u < nch) kn = load_light_chunk(sobs, sext, chunk_at(gi + 1u), levels_of(chunk_at(gi + 1u)), lane);
             }
             if (kExpNoCompute) {
                 acc.s[9] += chunk_checksum(kk);

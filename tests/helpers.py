@@ -109,11 +109,17 @@ KNEE_FIXTURES = ['knee_190x51_n1', 'knee_215x74_n1', 'knee_225x87_n1', 'knee_115
 def knee_bars(fx):
     """The reference against ITSELF on a knee scene (batch_size 1 vs 5: only the summation order differs): the spread
     of the water parameters over the trajectory and of the final J.  A restatement is 'as good as the reference' when
-    it lies within a small multiple of that spread; the cost of iteration 0 has no step behind it and stays tight."""
+    it lies within a small multiple of that spread; the cost of iteration 0 has no step behind it and stays tight.
+    The multiple (KNEE_FACTOR) is 1.5 x the spread, measured from the NEARER of the two reference runs: the oracle sits at
+    0.67 .. 1.38 x and the engine at 0.33 .. 1.19 x on the four scenes (3 x until round 4, when the reference-made goldens
+    at BASELINE sizes became the anchor for everything that is not a knee)."""
     t1, t5 = fx['trace_closed_bs1'], fx['trace_closed_bs5']
     par = float(np.abs(t1[:, 1:] - t5[:, 1:]).max())
     Jsp = float(rms_per_channel(fx['J_closed_bs1'], fx['J_closed_bs5']).max())
     return par, Jsp
+
+
+KNEE_FACTOR = 1.5
 
 
 def check_knee(fx, J, trace, label):
@@ -123,10 +129,10 @@ def check_knee(fx, J, trace, label):
     assert np.any(np.abs(t5[0, 1:] - 0.1) / 0.05 < 0.99)
     assert abs(trace[0, 0] / t5[0, 0] - 1) < 1e-6, (label, 'cost of iteration 0')
     d = min(float(np.abs(trace[:, 1:] - t5[:, 1:]).max()), float(np.abs(trace[:, 1:] - t1[:, 1:]).max()))
-    assert d < 3 * par, (label, 'parameters', d, par)
+    assert d < KNEE_FACTOR * par, (label, 'parameters', d, par)
     assert np.array_equal(np.isnan(J), np.isnan(fx['J_closed_bs5'])), label
     dJ = min(float(rms_per_channel(J, fx['J_closed_bs5']).max()), float(rms_per_channel(J, fx['J_closed_bs1']).max()))
-    assert dJ < 3 * Jsp, (label, 'J', dJ, Jsp)
+    assert dJ < KNEE_FACTOR * Jsp, (label, 'J', dJ, Jsp)
     return d / par, dJ / Jsp
 
 
