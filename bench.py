@@ -49,8 +49,10 @@ def parse():
     p.add_argument('--images-in-flight', type=int, default=2,
                    help='consecutive images (steps) kept in flight on their own HIP streams + workspaces '
                         '(engine.in_flight_slot); 1 = strictly one image at a time')
-    p.add_argument('--obs-format', choices=['f32', 'u16mm'], default='f32',
-                   help="observation store: f32 = 7 B/obs, lossless (configs 1-4); u16mm = 5 B/obs (config 5)")
+    p.add_argument('--obs-format', choices=['f32', 'u16mm', 'f32plain'], default='f32',
+                   help="observation store: f32 = float32 ranges, lossless, 7 B/obs by SURVEY 8(d) (configs 1-4; the library keeps "
+                        "them as 24-bit offsets, 6 B/obs, when the image's ranges allow it -- same bits); f32plain = the float32 "
+                        "words themselves (A/B); u16mm = 5 B/obs (config 5)")
     p.add_argument('--solo-images', type=int, default=3,
                    help='images restored one at a time after the timed region for the roofline block')
     p.add_argument('--timeout-s', type=float, default=1500.0,

@@ -84,6 +84,7 @@ int64_t sucre_ws_offset(int H, int W, int n_views, int region) {
         case SUCRE_WS_PARAMS: return (int64_t)L.off_params;
         case SUCRE_WS_SUMS: return (int64_t)L.off_sums;
         case SUCRE_WS_N_OBS_TOTAL: return (int64_t)L.off_n_obs_total;
+        case SUCRE_WS_STORE_FORMAT: return (int64_t)L.off_total_chunks + 8;
         default: return fail(SUCRE_ERR_RANGE, "unknown workspace region %d", region);
     }
 }
@@ -154,7 +155,7 @@ int sucre_finalize_matches_fmt(void *ws, int H, int W, int n_views, double min_c
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
-    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM)
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN)
         return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
     return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream),
                                      nullptr, nullptr, obs_format), "sucre_finalize_matches_fmt");
@@ -234,9 +235,10 @@ int sucre_update_J(void *ws, int H, int W, int n_views, void *stream) {
 int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
-    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM)
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN)
         return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
-    return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), obs_format, static_cast<hipStream_t>(stream)),
+    return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), obs_format == SUCRE_OBS_U16MM ? SUCRE_OBS_U16MM : SUCRE_OBS_F32,
+                                     static_cast<hipStream_t>(stream)),
                      "sucre_update_J");
 }
 

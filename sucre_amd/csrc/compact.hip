@@ -220,12 +220,23 @@ __global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__res
     if (t == 0) tile_levels[blockIdx.x] = lv[0] + lv[1] + lv[2] + lv[3];
 }
 
+// What the store will be: the format the caller asked for, except that float32 ranges become 24-bit codes (kStoreZ24, layout.h)
+// when the caller allows it and every range of the image lies within 2^24 - 2 bit patterns of the smallest one (view_total_kernel
+// left both ends behind the format word).  One thread; the scatter, the plan and the fit kernels read the two words.
+__device__ __forceinline__ void decide_store_format(uint64_t *total_levels, int fmt_req, int allow_z24) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(total_levels + 1);   // [0] format, [1] code offset, [2] smallest, [3] largest range bits
+    const uint32_t lo = w[2], hi = w[3];
+    const bool z24 = fmt_req == kStoreF32 && allow_z24 && hi >= lo && lo >= 2u && hi - lo <= 0xfffffdu;
+    w[0] = z24 ? (uint32_t)kStoreZ24 : (uint32_t)fmt_req;
+    w[1] = z24 ? lo - 1u : 0u;
+}
+
 // 3b. where every strip's chunks start, in levels: exclusive scan of the sorted tiles' totals by one workgroup of 1024
 //     (coalesced reads: thread t takes a run of consecutive tiles), then every tile spreads its offset over its four
 //     strips.  (Scanning the 16-byte StripMeta records themselves in one workgroup took 62 us per image.)
 __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__restrict__ tile_levels, int n_tiles,
                                                            uint64_t *__restrict__ tile_off, uint64_t *__restrict__ total_levels,
-                                                           int fmt) {
+                                                           int fmt, int allow_z24) {
     __shared__ unsigned long long wave_base[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (n_tiles + 1023) / 1024;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__res
     }
     if (t == 0) {
         *total_levels = total;
-        *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
+        decide_store_format(total_levels, fmt, allow_z24);  // what the scatter, the plan and the fit kernels must be told
     }
     for (int i0 = lo; i0 < hi; i0 += 8) {
         uint32_t v[8];
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict
 //     the counts and the three kernels above do the work.
 __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__restrict__ totals, int n_views, int n_strips,
                                                           StripMeta *__restrict__ meta, uint64_t *__restrict__ total_levels,
-                                                          int fmt) {
+                                                          int fmt, int allow_z24) {
     __shared__ uint32_t start[kMaxBins];              // entry i: the bin of count bins-1-i (heaviest first)
     __shared__ uint32_t first[kMaxBins];              // first strip that starts inside the bin
     __shared__ unsigned long long before[kMaxBins];   // levels of all strips starting in heavier bins
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__rest
         before[t] = bf;
         if (blockIdx.x == 0 && t == 0) {
             *total_levels = total;
-            *reinterpret_cast<uint32_t *>(total_levels + 1) = (uint32_t)fmt;  // what the fit kernels must be told
+            decide_store_format(total_levels, fmt, allow_z24);  // what the scatter, the plan and the fit kernels must be told
         }
         __syncthreads();
     }
@@ -375,6 +386,32 @@ __device__ __forceinline__ uint32_t range_mm(float z) {
 }
 
 // Writes chunk g (r of its four levels exist in the strip) of pixel `lane`.
+// 24-bit code of a range (layout.h, kStoreZ24): bits - offset, 0 for an empty slot.
+__device__ __forceinline__ uint32_t range_code(float z, uint32_t zoff) { return z > 0.0f ? __float_as_uint(z) - zoff : 0u; }
+
+// The same for a store of 24-bit codes (the device's choice for a float32 store without extension planes).
+__device__ __forceinline__ void store_group_z24(uint8_t *strip, uint32_t g, uint32_t r, uint32_t lane, const float (&z)[kGroupLv],
+                                                const uint32_t (&c)[3], uint32_t zoff) {
+    uint8_t *ch = strip + (size_t)g * kChunk24;
+    if (r == kGroupLv) {
+        const uint32_t c0 = range_code(z[0], zoff), c1 = range_code(z[1], zoff), c2 = range_code(z[2], zoff), c3 = range_code(z[3], zoff);
+        uint32_t *p = reinterpret_cast<uint32_t *>(ch + lane * 24);   // the lane's 24 bytes: four codes, then the R, G, B words
+        *reinterpret_cast<uint4 *>(p) = make_uint4(c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8), c[0]);
+        *reinterpret_cast<uint2 *>(p + 4) = make_uint2(c[1], c[2]);
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)kGroupLv - 1u; ++j) {
+            if (j >= r) break;
+            const uint32_t code = range_code(z[j], zoff);
+            uint8_t *zp = ch + (lane * r + j) * 3u;
+            zp[0] = (uint8_t)code; zp[1] = (uint8_t)(code >> 8); zp[2] = (uint8_t)(code >> 16);
+            uint8_t *cb = ch + 3u * kStripPx * r;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) cb[pl * kStripPx * r + lane * r + j] = (uint8_t)(c[pl] >> (8 * j));
+        }
+    }
+}
+
 template <int kFmt, int kExt>
 __device__ __forceinline__ void store_group(uint8_t *strip, float *const (&estrip)[2], uint32_t g, uint32_t r, uint32_t lane,
                                             const LevelGroup<kExt> &q) {
@@ -450,7 +487,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                                                       const uint8_t *__restrict__ ext_dense,
                                                       uint8_t *__restrict__ ext_comp,
                                                       const uint8_t *__restrict__ ext2_dense,
-                                                      uint8_t *__restrict__ ext2_comp) {
+                                                      uint8_t *__restrict__ ext2_comp, const uint32_t *__restrict__ store_fmt) {
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
     constexpr uint32_t kStageMask = (1u << kStageViews) - 1u;
     static_assert(kStageViews == 8 || kStageViews == 16, "a stage group is a byte or a half word of the 32-bit presence words");
@@ -463,7 +500,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     const uint32_t dlane = dst % kStripPx;
     const StripMeta sm = meta[dst / kStripPx];
     const uint32_t nl = sm.levels;
-    uint8_t *out = comp + sm.lvoff * (uint64_t)level_bytes(kFmt);
+    // a float32 store without extension planes may have been made a store of 24-bit codes (decide_store_format)
+    const bool z24 = kFmt == 0 && kExt == 0 && store_fmt[0] == (uint32_t)kStoreZ24;   // workgroup-uniform
+    const uint32_t zoff = store_fmt[1];
+    uint8_t *out = comp + sm.lvoff * (uint64_t)(z24 ? level_bytes(kStoreZ24) : level_bytes(kFmt));
     float *const eout[2] = {kExt >= 1 ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr,
                             kExt >= 2 ? reinterpret_cast<float *>(ext2_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr};
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
@@ -553,7 +593,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
             q.c[0] |= cr << (8 * j); q.c[1] |= cg << (8 * j); q.c[2] |= cb << (8 * j);
             ++lv;
             if ((lv & 3u) == 0u) {   // four levels collected: this pixel's share of chunk lv/4 - 1 (a full one)
-                store_group<kFmt, kExt>(out, eout, (lv >> 2) - 1u, kGroupLv, dlane, q);
+                if (z24) store_group_z24(out, (lv >> 2) - 1u, kGroupLv, dlane, q.z, q.c, zoff);
+                else store_group<kFmt, kExt>(out, eout, (lv >> 2) - 1u, kGroupLv, dlane, q);
                 clear_group(q);
             }
         }
@@ -563,7 +604,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     // level count: the strip has as many levels as its richest pixel
     for (uint32_t g = lv >> 2; g * kGroupLv < nl; ++g) {
         const uint32_t r = min((uint32_t)kGroupLv, nl - g * kGroupLv);
-        store_group<kFmt, kExt>(out, eout, g, r, dlane, q);
+        if (z24) store_group_z24(out, g, r, dlane, q.z, q.c, zoff);
+        else store_group<kFmt, kExt>(out, eout, g, r, dlane, q);
         clear_group(q);
     }
 #undef SUCRE_EACH_REG
@@ -580,6 +622,11 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     auto *invperm = reinterpret_cast<uint32_t *>(ws + L.off_invperm);
     auto *meta = reinterpret_cast<StripMeta *>(ws + L.off_strip_meta);
     const int bins = num_bins(L.n_views);
+    // fmt: what the caller asked for (include/sucre_hip.h): SUCRE_OBS_F32 = float32 ranges, kept as 24-bit codes when the image
+    // allows it and nothing rides along in extension planes; SUCRE_OBS_U16MM; SUCRE_OBS_F32_PLAIN = float32 ranges as they are
+    const int store_req = fmt == SUCRE_OBS_U16MM ? kStoreU16 : kStoreF32;
+    const int allow_z24 = (fmt == SUCRE_OBS_F32 && !ext_dense) ? 1 : 0;
+    const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2;
     hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(ws + L.off_vbits),
                        pmask, L.mask_words, keep, L.n_views, L.n_tiles, pcount, blockhist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(bins), dim3(256), 0, s, blockhist, L.n_tiles, totals);
@@ -587,14 +634,14 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
                        L.n_tiles, perm, invperm);
     if (L.n_views < kMaxBins - 1) {
         hipLaunchKernelGGL(strip_table_kernel, dim3((L.n_strips + 255) / 256), dim3(256), 0, s, totals, L.n_views, L.n_strips,
-                           meta, reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+                           meta, reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow_z24);
     } else {
         // the counting sort is done with its histograms: their space holds the sorted tiles' totals and offsets
         auto *tile_levels = blockhist;
         auto *tile_off = reinterpret_cast<uint64_t *>(blockhist + align_up((size_t)L.n_tiles, 2));
         hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels);
         hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(1024), 0, s, tile_levels, L.n_tiles, tile_off,
-                           reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), fmt);
+                           reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow_z24);
         hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles);
     }
     const dim3 grid(L.n_tiles), block(256);
@@ -602,18 +649,18 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     uint8_t *comp = ws + L.off_comp;
     if (ext_dense && ext2_dense)  // light model on float32 colours: camera points and colours ride along
         hipLaunchKernelGGL((scatter_kernel<0, 2>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
     else if (ext_dense)  // light model / float32 colours: float32 store only
         hipLaunchKernelGGL((scatter_kernel<0, 1>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
-    else if (fmt)
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
+    else if (fmt == SUCRE_OBS_U16MM)
         hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
     else
         hipLaunchKernelGGL((scatter_kernel<0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
-                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp);
+                           pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_plan(L, ws, fmt, s);   // the fit waves' item streams over the store just written (fit.hip)
+    return launch_plan(L, ws, s);   // the fit waves' item streams over the store just written (fit.hip); it reads the store's format
 }
 
 }  // namespace sucre

@@ -247,14 +247,14 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // PlanItem.shape: [6:0] nA - 1, [14:8] max(nB, 1) - 1, [22:16] B's first 16-byte piece (nA, or nA - 1 when nB = 0: B then
 // re-reads the item's last piece), [31] a full chunk (nA = 64 and nB = kFullB: both offsets are per-lane constants).
 constexpr uint32_t kShapeFull = 1u << 31;
-__host__ __device__ constexpr uint32_t full_chunk_b(int fmt) { return (uint32_t)(chunk_bytes(fmt) - 1024) / 16u; }   // 48 / 16 lanes
+__host__ __device__ constexpr uint32_t full_chunk_b(int fmt) { return (uint32_t)(chunk_bytes(fmt) - 1024) / 16u; }   // 48 / 16 / 32 lanes
 __host__ __device__ __forceinline__ uint32_t item_shape(uint32_t bytes, bool full_chunk) {
     const uint32_t pieces = bytes / 16u;   // every item is a multiple of 16 bytes (static_asserts below)
     const uint32_t nA = pieces < 64u ? pieces : 64u, nB = pieces - nA;
     return (nA - 1u) | ((nB ? nB - 1u : 0u) << 8) | ((nB ? nA : nA - 1u) << 16) | (full_chunk ? kShapeFull : 0u);
 }
-static_assert(level_bytes(0) % 16 == 0 && level_bytes(1) % 16 == 0 && kChunk % 16 == 0 && kChunk16 % 16 == 0, "items are copied in 16-byte pieces");
-static_assert(kChunk <= 2048 && kChunk >= 1024 && kChunk16 >= 1024, "a full chunk is one whole DMA + a partial one");
+static_assert(level_bytes(0) % 16 == 0 && level_bytes(1) % 16 == 0 && level_bytes(2) % 16 == 0 && kChunk % 16 == 0 && kChunk16 % 16 == 0 && kChunk24 % 16 == 0, "items are copied in 16-byte pieces");
+static_assert(kChunk <= 2048 && kChunk >= 1024 && kChunk16 >= 1024 && kChunk24 >= 1024, "a full chunk is one whole DMA + a partial one");
 
 // src (wave-uniform global address) -> LDS bytes [slotA, ...) and [slotB, ...) (wave-uniform LDS byte addresses) through the
 // per-lane byte offsets voffA / voffB.  EXEC is all ones (whole waves run this code) and stays so; M0 is written in the
@@ -329,13 +329,14 @@ __host__ __device__ __forceinline__ WaveDeal make_deal(uint32_t wid, uint32_t W,
 // per image for the two modes.)
 __device__ __forceinline__ uint32_t strip_items(uint32_t levels, int mode) { return 1u + ((levels + 3u) >> 2) + (mode == 0 ? 1u : 0u); }
 
-__global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, int fmt, uint32_t W0, uint32_t W1,
+__global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__ meta, int n_strips, const uint32_t *__restrict__ store_fmt, uint32_t W0, uint32_t W1,
                                                    uint32_t Kmax, uint32_t stride0, uint32_t stride1, uint32_t kmax0, uint32_t kmax1,
                                                    PlanItem *__restrict__ plan0, PlanItem *__restrict__ plan1,
                                                    StripEntry *__restrict__ strips0, StripEntry *__restrict__ strips1,
                                                    uint32_t *__restrict__ count0, uint32_t *__restrict__ count1, uint64_t comp_off,
                                                    uint64_t state_off) {
     const int mode = blockIdx.y;   // both plans in one launch
+    const int fmt = (int)store_fmt[0];   // kStoreF32 / kStoreU16 / kStoreZ24: what the compaction has just written (decide_store_format)
     const uint32_t W = mode ? W1 : W0, stride = mode ? stride1 : stride0, kmax = mode ? kmax1 : kmax0;
     PlanItem *plan = mode ? plan1 : plan0;
     StripEntry *strips = mode ? strips1 : strips0;
@@ -389,9 +390,40 @@ __device__ __forceinline__ ConstItems const_items(const T *p) {
     return (ConstItems)(reinterpret_cast<uintptr_t>(uniform_ptr(p)));
 }
 
-// A full chunk in a ring slot -> this lane's four ranges and three colour dwords.
+// What a kernel instantiated for float32 ranges finds in the store: the float32 words, or their 24-bit codes
+// (layout.h, kStoreZ24; chosen on the device by the compaction): bits(z) = code + zoff, code 0 = empty slot.
+struct RangeCodes { bool z24; uint32_t zoff; };
+
+__device__ __forceinline__ RangeCodes range_codes(const uint32_t *__restrict__ store_fmt) {
+    RangeCodes rc;
+    rc.z24 = __builtin_amdgcn_readfirstlane(store_fmt[0]) == (uint32_t)kStoreZ24;
+    rc.zoff = __builtin_amdgcn_readfirstlane(store_fmt[1]);
+    return rc;
+}
+
+// Is the store one the instantiation can read?  (kFmt 0: float32 ranges, as words or as 24-bit codes; 1: uint16 millimetres.)
 template <int kFmt>
-__device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&zz)[kGroupLv], uint32_t (&cc)[3]) {
+__device__ __forceinline__ bool store_matches(const uint32_t *__restrict__ store_fmt) {
+    const uint32_t f = __builtin_amdgcn_readfirstlane(store_fmt[0]);
+    return kFmt == kStoreU16 ? f == (uint32_t)kStoreU16 : (f == (uint32_t)kStoreF32 || f == (uint32_t)kStoreZ24);
+}
+
+// A full chunk in a ring slot -> this lane's four ranges and three colour dwords.  masked: the chunk may hold empty slots.
+template <int kFmt>
+__device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&zz)[kGroupLv], uint32_t (&cc)[3], const RangeCodes &rc, bool masked) {
+    if (kFmt == 0 && rc.z24) {   // wave-uniform: the lane's 24 bytes side by side -- four codes in three dwords, then R, G, B
+        const uint2 a = *reinterpret_cast<const uint2 *>(sp + lane * 24), b = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 8),
+                    c = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 16);
+        const uint32_t c0 = a.x & 0xffffffu, c1 = __builtin_amdgcn_alignbit(a.y, a.x, 24) & 0xffffffu,
+                       c2 = __builtin_amdgcn_alignbit(b.x, a.y, 16) & 0xffffffu, c3 = b.x >> 8;
+        zz[0] = __uint_as_float(c0 + rc.zoff); zz[1] = __uint_as_float(c1 + rc.zoff);
+        zz[2] = __uint_as_float(c2 + rc.zoff); zz[3] = __uint_as_float(c3 + rc.zoff);
+        if (masked) {   // an empty slot reads as range 0, like in the float32 store
+            zz[0] = c0 ? zz[0] : 0.0f; zz[1] = c1 ? zz[1] : 0.0f; zz[2] = c2 ? zz[2] : 0.0f; zz[3] = c3 ? zz[3] : 0.0f;
+        }
+        cc[0] = b.y; cc[1] = c.x; cc[2] = c.y;
+        return;
+    }
     if (kFmt == 0) {
         const float4 z4 = *reinterpret_cast<const float4 *>(sp + lane * 16);
         zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
@@ -406,10 +438,15 @@ __device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&
 
 // Level j of a short chunk (r < 4 levels, rows of r) in a ring slot.
 template <int kFmt>
-__device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t r, uint32_t j, float &z, uint32_t (&k)[3]) {
-    if (kFmt == 0) z = reinterpret_cast<const float *>(sp)[lane * r + j];
+__device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t r, uint32_t j, float &z, uint32_t (&k)[3], const RangeCodes &rc) {
+    const bool z24 = kFmt == 0 && rc.z24;
+    if (z24) {
+        const uint8_t *zp = sp + (lane * r + j) * 3u;
+        const uint32_t code = (uint32_t)zp[0] | ((uint32_t)zp[1] << 8) | ((uint32_t)zp[2] << 16);
+        z = code ? __uint_as_float(code + rc.zoff) : 0.0f;
+    } else if (kFmt == 0) z = reinterpret_cast<const float *>(sp)[lane * r + j];
     else z = (float)reinterpret_cast<const uint16_t *>(sp)[lane * r + j] * kMPerMm;
-    const uint8_t *cb = sp + (kFmt ? 2 : 4) * kStripPx * r;
+    const uint8_t *cb = sp + (z24 ? 3 : kFmt ? 2 : 4) * kStripPx * r;
 #pragma unroll
     for (int c = 0; c < 3; ++c) k[c] = cb[c * kStripPx * r + lane * r + j];
 }
@@ -425,7 +462,7 @@ __device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t
 // immediate: vmcnt(2 kAhead), or vmcnt(2 kAhead + kStores) for the first kAhead items behind a strip's stores.
 template <int kFmt, int kStores, bool kMoments, class OnJ, class OnChunk, class OnTail, class OnEnd>
 __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
-                                              uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, OnJ on_J,
+                                              uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, bool z24, OnJ on_J,
                                               OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
     if (K == 0) return;
     const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
@@ -434,7 +471,7 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
     const ConstItems strips = const_items(strip_list);
     // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch)
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    const uint32_t voffB_full = (64u + min((uint32_t)lane, full_chunk_b(kFmt) - 1u)) * 16u;
+    const uint32_t voffB_full = (64u + min((uint32_t)lane, (z24 ? full_chunk_b(kStoreZ24) : full_chunk_b(kFmt)) - 1u)) * 16u;
     auto issue = [&](const ItemRegs it, uint32_t slot_off) {
         const uint8_t *src = ws + ((uint64_t)it.x << 6);
         const uint32_t slot = ring0 + slot_off;
@@ -631,10 +668,10 @@ __device__ __forceinline__ void finish_from_wave_sums(FitLds &lds, float *partia
 template <int kFmt>
 __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                           const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
-                                          const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3]) {
+                                          const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3], const RangeCodes &rc) {
     float J[3] = {0.f, 0.f, 0.f};
     stream_strips<kFmt, 9, true>(
-        lds, plan, strips, n_strips_wave, ws, wave, lane,
+        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -643,7 +680,7 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
         [&](const uint8_t *sp, bool masked) {  // chunk of four levels
             float zz[kGroupLv];
             uint32_t cc[3];
-            read_chunk<kFmt>(sp, lane, zz, cc);
+            read_chunk<kFmt>(sp, lane, zz, cc, rc, masked);
             if (masked) accumulate_chunk<true>(zz, cc, w, J, acc);
             else accumulate_chunk<false>(zz, cc, w, J, acc);
         },
@@ -651,7 +688,7 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
             for (uint32_t j = 0; j < r; ++j) {
                 float z;
                 uint32_t k[3];
-                read_level<kFmt>(sp, lane, r, j, z, k);
+                read_level<kFmt>(sp, lane, r, j, z, k, rc);
                 accumulate_level(z, k, w, J, acc);
             }
         },
@@ -693,7 +730,8 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     const Water w = load_water(pstate);
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
     // a store compacted in the other format is not read at all; the logged cost turns NaN instead
-    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    const RangeCodes rc = range_codes(obs_format);
+    const bool fmt_ok = store_matches<kFmt>(obs_format);
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t n_mine = fmt_ok ? plan_count[wid] : 0u;   // strips of this wave
 
@@ -703,7 +741,7 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     zero_acc(acc);
     if (!fmt_ok) acc.cost = __builtin_nanf("");
     float sBeta[3] = {0.f, 0.f, 0.f};
-    grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+    grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta, rc);
 
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
                          sBeta[0], sBeta[1], sBeta[2], acc.cost};
@@ -717,11 +755,11 @@ struct ClosedSums { float sB[3], sGZ[3], sBeta[3], cost; };
 template <int kFmt, bool kJOnly>
 __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                             const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
-                                            const Water &w, bool fmt_ok, ClosedSums &cs) {
+                                            const Water &w, bool fmt_ok, ClosedSums &cs, const RangeCodes &rc) {
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
     stream_strips<kFmt, 3, false>(
-        lds, plan, strips, n_strips_wave, ws, wave, lane,
+        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -738,7 +776,7 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
         [&](const uint8_t *sp, bool masked) {
             float zz[kGroupLv];
             uint32_t cc[3];
-            read_chunk<kFmt>(sp, lane, zz, cc);
+            read_chunk<kFmt>(sp, lane, zz, cc, rc, masked);
             if (masked) accumulate_chunk<true>(zz, cc, w, Jp, acc);
             else accumulate_chunk<false>(zz, cc, w, Jp, acc);
         },
@@ -746,7 +784,7 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
             for (uint32_t j = 0; j < r; ++j) {
                 float z;
                 uint32_t k[3];
-                read_level<kFmt>(sp, lane, r, j, z, k);
+                read_level<kFmt>(sp, lane, r, j, z, k, rc);
                 accumulate_level(z, k, w, Jp, acc);
             }
         },
@@ -790,13 +828,14 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water(pstate);
-    const bool fmt_ok = *obs_format == (uint32_t)kFmt;
+    const RangeCodes rc = range_codes(obs_format);
+    const bool fmt_ok = store_matches<kFmt>(obs_format);
     // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
     // plan was written for the store's format, so the items themselves are sound)
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t n_mine = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;   // strips of this wave
     ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
-    closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, fmt_ok, cs);
+    closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, fmt_ok, cs, rc);
     if (kJOnly) return;
     float s[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
@@ -901,8 +940,9 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_i
     for (int i = 0; i < n_images; ++i) {
         const GroupImage im = images[i];
         uint8_t *ws = uniform_ptr(im.ws);   // between images nothing is in flight: ordinary loads are harmless here
-        const bool fmt_ok = *reinterpret_cast<const uint32_t *>(ws + im.off_format) == (uint32_t)kFmt;
-        if (!fmt_ok) { poisoned = true; continue; }
+        const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + im.off_format);
+        const RangeCodes rc = range_codes(store_fmt);
+        if (!store_matches<kFmt>(store_fmt)) { poisoned = true; continue; }
         if (wid >= im.n_waves[kMode]) continue;
         const uint32_t n_mine = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
         const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + im.off_plan[kMode]) + (size_t)wid * im.stride[kMode]);
@@ -910,14 +950,14 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_i
         float *state = reinterpret_cast<float *>(ws + im.off_state);
         float s[kNumSums];
         if (kMode == 0) {
-            grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta);
+            grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta, rc);
             const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
             zero_acc(acc);
             sBeta[0] = sBeta[1] = sBeta[2] = 0.f;
         } else {
-            closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, true, cs);
+            closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, true, cs, rc);
             const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
@@ -1100,12 +1140,13 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s)
 }
 
 // Writes both plans (J-parameter and closed-form item streams) for the store the compaction has just built.
-hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s) {
+hipError_t launch_plan(const Layout &L, uint8_t *ws, hipStream_t s) {
     auto *meta = reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta);
     const uint32_t W0 = (uint32_t)L.fit_blocks[0] * 4u, W1 = (uint32_t)L.fit_blocks[1] * 4u;
     const uint32_t Wmin = W0 < W1 ? W0 : W1, Wmax = W0 < W1 ? W1 : W0;
     const uint32_t Kmax = ((uint32_t)L.n_strips + Wmin - 1u) / Wmin;   // strips of the busiest wave (of either mode)
-    hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips, fmt, W0, W1, Kmax,
+    hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips,
+                       reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2, W0, W1, Kmax,
                        (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], (uint32_t)L.plan_kmax[0], (uint32_t)L.plan_kmax[1],
                        reinterpret_cast<PlanItem *>(ws + L.off_plan[0]), reinterpret_cast<PlanItem *>(ws + L.off_plan[1]),
                        reinterpret_cast<StripEntry *>(ws + L.off_plan_strips[0]), reinterpret_cast<StripEntry *>(ws + L.off_plan_strips[1]),

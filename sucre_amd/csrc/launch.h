@@ -53,7 +53,7 @@ hipError_t launch_fit_iter_fused(const Layout &L, uint8_t *ws, const AdamCoef &c
 hipError_t launch_fit_grad(const Layout &L, uint8_t *ws, const AdamCoef &co, unsigned flags, hipStream_t s);
 hipError_t launch_fit_step(const Layout &L, uint8_t *ws, const AdamCoef &co, double *trace_row, hipStream_t s);
 hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s);
-hipError_t launch_plan(const Layout &L, uint8_t *ws, int fmt, hipStream_t s);
+hipError_t launch_plan(const Layout &L, uint8_t *ws, hipStream_t s);
 hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStream_t s);
 hipError_t launch_set_n_obs_total(const Layout &L, uint8_t *ws, uint64_t n, hipStream_t s);
 // shared water parameters over several images: one launch + one collective per iteration (fit.hip)

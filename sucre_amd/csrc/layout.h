@@ -17,7 +17,14 @@ constexpr int kChunk = kChunkZ + kChunkRGB;  // 1792 bytes per (tile, view)
 constexpr int kChunkZ16 = 512;       // bytes: 256 uint16 ranges
 constexpr int kChunk16 = kChunkZ16 + kChunkRGB;  // 1280 bytes per (sorted tile, level)
 constexpr float kMmPerM = 1000.0f, kMPerMm = 0.001f;
-__host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt ? kChunk16 : kChunk; }
+// Store format 2 (kStoreZ24, chosen ON THE DEVICE for a store the caller asked to be SUCRE_OBS_F32): the float32 ranges of an
+// image whose bit patterns all lie within 2^24 - 2 of the smallest one -- any scene whose ranges span less than about a
+// factor of four -- are kept as 24-bit codes, code = bits(z) - bits(z_min) + 1 (0 = empty slot): bits(z) = code + offset
+// gives every range back exactly, 6 instead of 7 bytes per observation.  A full chunk: 64 x {4 codes (12 B), R word, G word,
+// B word} = 1536 B, a lane's 24 bytes side by side; the short last chunk: [code: 64 x r x 3 B][R: 64 x r][G][B].
+constexpr int kStoreF32 = 0, kStoreU16 = 1, kStoreZ24 = 2;
+constexpr int kChunk24 = 6 * 256;    // 1536 bytes
+__host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt == kStoreU16 ? kChunk16 : fmt == kStoreZ24 ? kChunk24 : kChunk; }
 constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
 // Compact store (what the fit streams): the count-sorted pixels are cut into STRIPS of 64 consecutive pixels -- one
 // pixel per lane of the wave that owns the strip.  A strip with n levels is stored as ceil(n/4) chunks of 64 pixels x
@@ -28,7 +35,8 @@ constexpr int kStripPx = 64;
 constexpr int kStripsPerTile = kTilePx / kStripPx;
 constexpr int kGroupLv = 4;                       // levels per full chunk
 constexpr int kStateFloats = 9 * kStripPx;        // J[3], exp_avg[3], exp_avg_sq[3] planes of a strip (2304 B)
-__host__ __device__ constexpr int level_bytes(int fmt) { return (fmt ? 2 : 4) * kStripPx + 3 * kStripPx; }  // 448 / 320
+__host__ __device__ constexpr int range_bytes(int fmt) { return fmt == kStoreU16 ? 2 : fmt == kStoreZ24 ? 3 : 4; }
+__host__ __device__ constexpr int level_bytes(int fmt) { return (range_bytes(fmt) + 3) * kStripPx; }  // 448 / 320 / 384
 constexpr int kExtLevelBytes = 3 * 4 * kStripPx;  // extension planes of one level of a strip: 3 floats x 64 pixels
 
 struct StripMeta {
@@ -78,7 +86,10 @@ struct Layout {
     size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
     int n_strips;           // n_tiles * 4 strips of 64 sorted pixels
     size_t off_strip_meta;  // StripMeta [n_strips]
-    size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [1]: observation format of the compact store (SUCRE_OBS_*)
+    size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [5]: format of the compact store (kStore*), the
+                            // offset of its 24-bit range codes (kStoreZ24), smallest / largest range bits of the dense store
+    size_t off_zrange;      // uint2  [n_tiles][n_views]   smallest / largest float32 bit pattern of the pair's ranges (0xffffffff / 0: none)
+    size_t off_zpart;       // uint2  [ceil(n_tiles / 32)] the same over 32 tiles and all views
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]
     size_t off_view_partial;// uint32 [ceil(n_tiles / 32)][n_views]  match counts of 32 tiles per view (finalize)
@@ -126,6 +137,8 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->n_strips = L->n_tiles * kStripsPerTile;
     L->off_strip_meta = take((size_t)L->n_strips * sizeof(StripMeta));
     L->off_total_chunks = take(sizeof(uint64_t));
+    L->off_zrange = take(nt * nv * 2 * sizeof(uint32_t));
+    L->off_zpart = take((nt + 31) / 32 * 2 * sizeof(uint32_t));
     L->off_view_count = take(nv * sizeof(uint64_t));
     L->off_view_keep = take(nv * sizeof(uint32_t));
     L->off_view_partial = take((nt + 31) / 32 * nv * sizeof(uint32_t));

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                     int k1, int tiles_x, int n_tiles, int tiles_per_xcd,
                                                     size_t tile_stride, size_t view_stride, uint8_t *__restrict__ ext,
                                                     int ext_mode, uint8_t *__restrict__ ext2,
-                                                    uint64_t *__restrict__ vbits) {
+                                                    uint64_t *__restrict__ vbits, uint2 *__restrict__ zrange) {
     // A wave's results of one view pass through LDS on their way out: the lanes COMPUTE on rows of the tile (see below) but
     // the dense chunk is stored four adjacent slots per lane (one 16-byte + three 4-byte stores per lane, as the readers expect)
     __shared__ __attribute__((aligned(16))) float lz[4][kTilePx];
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const bool pin = pin1 && pinhole_form(vw->K) && pinhole_form(vw->Kinv);   // the pair's four matrices: one scalar branch
         int total = 0;
         unsigned long long bal[4];
+        uint32_t zlo = 0xffffffffu, zhi = 0u;   // smallest / largest bit pattern of the pair's ranges (positive floats order like integers)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool m = ok1[j];
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 m = match_pixel(c1, W1f, H1f, vw, packed, W2f, H2f, pin, wP[j], u1, v1b + 4 * j, &q, c2, &rgbw);
                 if (m) {
                     z = sqrtf(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]);
+                    zlo = min(zlo, __float_as_uint(z)); zhi = max(zhi, __float_as_uint(z));
                     if (kBoth) {                          // float32 colour image, camera point kept as well
                         const auto *pf = global_ptr(reinterpret_cast<const float *>(rgb2)) + q * 3;
                         f2[0] = pf[0]; f2[1] = pf[1]; f2[2] = pf[2];
@@ -253,6 +255,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (lane < 4)   // the four ballots in ONE store instruction (lane j holds word j)
             vbits[((size_t)tile * n_views + k) * 4 + lane] = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
         if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
+        // what the compaction needs to know to keep the ranges as 24-bit codes (layout.h, kStoreZ24): twelve shuffles per pair
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
+        if (lane == 0) zrange[(size_t)tile * n_views + k] = make_uint2(zlo, zhi);
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: LDS
             __builtin_amdgcn_wave_barrier();                          // operations of one wave complete in order
@@ -323,11 +329,18 @@ __global__ __launch_bounds__(256) void project_points_kernel(const CamDev cam, c
 // walking the table down a column -- 130-byte strides -- took 18 + 5 us per image.)
 constexpr int kStatTiles = 32;
 
+// Both also fold the pairs' range bits (match_kernel / count_view_kernel leave the smallest and the largest per (tile, view)
+// pair with a match) into the image's: over ALL views -- a view the min_cover rule drops may widen the span, which only ever
+// costs the 24-bit store (layout.h), never correctness.
 __global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__restrict__ cnt, int n_tiles, int n_views,
-                                                           uint32_t *__restrict__ partial) {
+                                                           uint32_t *__restrict__ partial, const uint2 *__restrict__ zrange,
+                                                           uint2 *__restrict__ zpart) {
+    __shared__ uint32_t plo[4], phi[4];
     const int t0 = blockIdx.x * kStatTiles, n = min(kStatTiles, n_tiles - t0);
+    uint32_t zlo = 0xffffffffu, zhi = 0u;
     for (int k = threadIdx.x; k < n_views; k += 256) {
         const uint16_t *p = cnt + (size_t)t0 * n_views + k;
+        const uint2 *zr = zrange + (size_t)t0 * n_views + k;
         uint32_t s = 0;
         if (n == kStatTiles) {
 #pragma unroll
@@ -335,17 +348,41 @@ __global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__res
         } else {
             for (int i = 0; i < n; ++i) s += p[(size_t)i * n_views];
         }
+        for (int i = 0; i < n; ++i) {
+            if (p[(size_t)i * n_views] == 0) continue;   // a pair without a match has never been written
+            const uint2 r = zr[(size_t)i * n_views];
+            zlo = min(zlo, r.x); zhi = max(zhi, r.y);
+        }
         partial[(size_t)blockIdx.x * n_views + k] = s;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
+    if ((threadIdx.x & 63) == 0) { plo[threadIdx.x >> 6] = zlo; phi[threadIdx.x >> 6] = zhi; }
+    __syncthreads();
+    if (threadIdx.x == 0) zpart[blockIdx.x] = make_uint2(min(min(plo[0], plo[1]), min(plo[2], plo[3])), max(max(phi[0], phi[1]), max(phi[2], phi[3])));
 }
 
 __global__ __launch_bounds__(1024) void view_total_kernel(const uint32_t *__restrict__ partial, int n_rows, int n_views,
                                                           double min_cover, double hw, uint64_t *__restrict__ view_count,
                                                           uint32_t *__restrict__ view_keep, uint64_t *__restrict__ n_obs,
-                                                          uint64_t *__restrict__ n_obs_total) {
+                                                          uint64_t *__restrict__ n_obs_total, const uint2 *__restrict__ zpart,
+                                                          uint32_t *__restrict__ zspan) {
     __shared__ unsigned long long part[1024];
     __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t plo[16], phi[16];
     const int t = threadIdx.x;
+    {   // the image's smallest / largest range bits
+        uint32_t zlo = 0xffffffffu, zhi = 0u;
+        for (int i = t; i < n_rows; i += 1024) { const uint2 r = zpart[i]; zlo = min(zlo, r.x); zhi = max(zhi, r.y); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
+        if ((t & 63) == 0) { plo[t >> 6] = zlo; phi[t >> 6] = zhi; }
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < 16; ++w) { zlo = min(zlo, plo[w]); zhi = max(zhi, phi[w]); }
+            zspan[0] = zlo; zspan[1] = zhi;
+        }
+    }
     int kc = 64;   // views side by side (a power of two), 1024 / kc slices of the partial rows
     while (kc < n_views && kc < 1024) kc <<= 1;
     const int slices = 1024 / kc, k0 = t & (kc - 1), r = t / kc;
@@ -517,17 +554,25 @@ __global__ __launch_bounds__(256) void export_view_ext_kernel(const uint8_t *__r
 // views it fills): thread t holds slot t, wave w's ballot is word w.
 __global__ __launch_bounds__(256) void count_view_kernel(const uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                          int n_views, int k, size_t tile_stride, size_t view_stride,
-                                                         uint64_t *__restrict__ vbits) {
+                                                         uint64_t *__restrict__ vbits, uint2 *__restrict__ zrange) {
     __shared__ int part[4];
+    __shared__ uint32_t plo[4], phi[4];
     const int tile = blockIdx.x, t = threadIdx.x;
     const float z = reinterpret_cast<const float *>(obs + (size_t)tile * tile_stride + (size_t)k * view_stride)[t];
     const unsigned long long bal = __ballot(z > 0.0f);
+    uint32_t zlo = z > 0.0f ? __float_as_uint(z) : 0xffffffffu, zhi = z > 0.0f ? __float_as_uint(z) : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
     if ((t & 63) == 0) {
         vbits[((size_t)tile * n_views + k) * 4 + (t >> 6)] = bal;
         part[t >> 6] = __builtin_popcountll(bal);
+        plo[t >> 6] = zlo; phi[t >> 6] = zhi;
     }
     __syncthreads();
-    if (t == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
+    if (t == 0) {
+        cnt[(size_t)tile * n_views + k] = (uint16_t)(part[0] + part[1] + part[2] + part[3]);
+        zrange[(size_t)tile * n_views + k] = make_uint2(min(min(plo[0], plo[1]), min(plo[2], plo[3])), max(max(phi[0], phi[1]), max(phi[2], phi[3])));
+    }
 }
 
 hipError_t launch_export_view_ext(const Layout &L, const uint8_t *ws, const uint8_t *ext_dense, int k, float *out, hipStream_t s) {
@@ -547,7 +592,8 @@ hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t
         hipLaunchKernelGGL(import_view_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws + L.off_obs, k,
                            L.tiles_x, L.H, L.W, L.obs_tile_stride, L.obs_view_stride, u1, v1, z, rgb, n, ext_dense, L.n_views, ext, ext2_dense);
     hipLaunchKernelGGL(count_view_kernel, dim3(L.n_tiles), dim3(256), 0, s, ws + L.off_obs, cnt, L.n_views, k,
-                       L.obs_tile_stride, L.obs_view_stride, reinterpret_cast<uint64_t *>(ws + L.off_vbits));
+                       L.obs_tile_stride, L.obs_view_stride, reinterpret_cast<uint64_t *>(ws + L.off_vbits),
+                       reinterpret_cast<uint2 *>(ws + L.off_zrange));
     return hipGetLastError();
 }
 
@@ -588,7 +634,8 @@ hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target
     auto *vbits = reinterpret_cast<uint64_t *>(ws + L.off_vbits);
     auto launch = [&](auto kernel, int mode) {
         hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, ws + L.off_obs, cnt, target.depth, to_cam(target), views_dev, L.n_views, k0,
-                           k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, mode, ext2, vbits);
+                           k1, L.tiles_x, L.n_tiles, tiles_per_xcd, L.obs_tile_stride, L.obs_view_stride, ext, mode, ext2, vbits,
+                           reinterpret_cast<uint2 *>(ws + L.off_zrange));
     };
     if (ext2) launch(match_kernel<true, true>, SUCRE_EXT_POINTS_COLOUR);
     else if (ext) launch(match_kernel<false, true>, ext_mode);
@@ -610,10 +657,13 @@ hipError_t launch_finalize(const Layout &L, uint8_t *ws, double min_cover, hipSt
     auto *vk = reinterpret_cast<uint32_t *>(ws + L.off_view_keep);
     auto *partial = reinterpret_cast<uint32_t *>(ws + L.off_view_partial);
     const int rows = (L.n_tiles + kStatTiles - 1) / kStatTiles;
-    hipLaunchKernelGGL(view_partial_kernel, dim3(rows), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, partial);
+    auto *zpart = reinterpret_cast<uint2 *>(ws + L.off_zpart);
+    hipLaunchKernelGGL(view_partial_kernel, dim3(rows), dim3(256), 0, s, cnt, L.n_tiles, L.n_views, partial,
+                       reinterpret_cast<const uint2 *>(ws + L.off_zrange), zpart);
     hipLaunchKernelGGL(view_total_kernel, dim3(1), dim3(1024), 0, s, partial, rows, L.n_views, min_cover,
                        (double)L.W * (double)L.H, vc, vk, reinterpret_cast<uint64_t *>(ws + L.off_n_obs),
-                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total));
+                       reinterpret_cast<uint64_t *>(ws + L.off_n_obs_total), zpart,
+                       reinterpret_cast<uint32_t *>(ws + L.off_total_chunks) + 4);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_compact(L, ws, s, ext_dense, ext_comp, fmt, ext2_dense, ext2_comp);
 }

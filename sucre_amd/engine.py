@@ -329,6 +329,13 @@ class Restoration:
     def view_keep(self) -> torch.Tensor:
         return self._region(_lib.WS_VIEW_KEEP, torch.int32, self.n_views)
 
+    def store_format(self) -> torch.Tensor:
+        """uint32[4] on the device: how the last ``match`` / ``import_matches`` laid the observations out -- _lib.STORE_F32,
+        STORE_U16MM or STORE_Z24 (float32 ranges as 24-bit offsets of their bit patterns: the device's choice for an 'f32'
+        store whose ranges span less than 2^24 patterns; same results bit for bit), the offset, the smallest and the largest
+        range bit pattern."""
+        return self._region(_lib.WS_STORE_FORMAT, torch.int32, 4)
+
     def n_obs_device(self) -> torch.Tensor:
         return self._region(_lib.WS_N_OBS, torch.int64, 1)
 

@@ -883,3 +883,74 @@ def test_randomised_camera_sweep_small(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, 'argv', ['camera_sweep.py', '25', '77'])
     mod.main()
+
+
+# ---- round 4: float32 ranges kept as 24-bit offsets of their bit patterns (layout.h kStoreZ24) ---------------------------------
+
+def _fit_digest(r, tgt, T=12):
+    import hashlib
+    out = []
+    for closed in (False, True):
+        r.fit_init(tgt)
+        t = r.fit(T, use_closed_form=closed)
+        torch.cuda.synchronize()
+        out.append(hashlib.md5(t.cpu().numpy().tobytes() + r.J().cpu().numpy().tobytes() + r.params().cpu().numpy().tobytes()).hexdigest())
+    return out
+
+
+def test_float32_store_as_24_bit_offsets_changes_no_bit():
+    """An 'f32' store is the caller's word for "float32 ranges, lossless": the compaction keeps them as 24-bit offsets from
+    the image's smallest range bit pattern when they all fit (decided on the device, 6 instead of 7 bytes per observation)
+    and as the float32 words otherwise.  Same trace, J and parameters bit for bit as 'f32plain' (the words themselves), in
+    both J modes, on a scene with relief and far views; and the device really chose the compact form."""
+    from sucre_amd import _lib, engine, synth
+    for (W, H, nn, seed, far) in ((333, 207, 13, 7, 0), (160, 120, 6, 3, 1), (96, 64, 2, 11, 0)):
+        scene = synth.make_scene(W, H, nn, seed=seed, device='cuda', far_views=far, relief=0.4)
+        views = engine.device_views_from_scene(scene, 'cuda')
+        got = {}
+        for fmt in ('f32', 'f32plain'):
+            r = engine.Restoration(H, W, len(views), obs_format=fmt)
+            r.match(views[scene.target], views)
+            word = r.store_format().cpu().numpy().astype(np.uint32)
+            lo, hi = int(word[2]), int(word[3])
+            assert lo <= hi and hi - lo <= 0xfffffd, 'the synthetic scenes span less than 2^24 range bit patterns'
+            assert int(word[0]) == (_lib.STORE_Z24 if fmt == 'f32' else _lib.STORE_F32) and (int(word[1]) == lo - 1 if fmt == 'f32' else int(word[1]) == 0)
+            got[fmt] = _fit_digest(r, views[scene.target])
+            del r
+        assert got['f32'] == got['f32plain'], (W, H, nn)
+
+
+def test_24_bit_offsets_exactly_when_the_ranges_fit():
+    """The decision at its boundary, through the import path (explicit ranges): views whose ranges are the bit patterns
+    lo .. lo + span.  span = 2^24 - 3: the largest that fits (code 0 is the empty slot); one more: the float32 words are
+    kept.  Either way the fit equals the one on the float32 words bit for bit."""
+    from sucre_amd import _lib, engine
+    H, W = 32, 48
+    g = torch.Generator().manual_seed(5)
+    n = H * W
+    v1, u1 = torch.meshgrid(torch.arange(H, dtype=torch.int16), torch.arange(W, dtype=torch.int16), indexing='ij')
+    u1, v1 = u1.reshape(-1), v1.reshape(-1)
+    lo = int(np.float32(1.7).view(np.uint32))
+    rgb_t = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g)
+    depth_t = torch.full((H, W), 2.0)
+    target = engine.DeviceView(depth=depth_t.cuda(), rgb=rgb_t.cuda(), K=torch.eye(3), R=torch.eye(3), t=torch.zeros(3, 1))
+    for span, want in ((0xfffffd, _lib.STORE_Z24), (0xfffffe, _lib.STORE_F32), (5, _lib.STORE_Z24)):
+        lists = []
+        for k in range(3):
+            bits = lo + torch.randint(0, span + 1, (n,), generator=g, dtype=torch.int64)
+            if k == 0:
+                bits[0], bits[1] = lo, lo + span          # both ends are present
+            keep = torch.rand(n, generator=g) < (0.9 if k < 2 else 0.3)   # ragged pixel counts: masked chunks and short last chunks
+            keep[:2] = True
+            z = torch.from_numpy(bits.numpy().astype(np.uint32).view(np.float32))
+            rgb = torch.randint(0, 256, (n, 3), dtype=torch.uint8, generator=g)
+            lists.append((u1[keep], v1[keep], z[keep], rgb[keep]))
+        got = {}
+        for fmt in ('f32', 'f32plain'):
+            r = engine.Restoration(H, W, len(lists), obs_format=fmt)
+            r.import_matches(target, lists)
+            word = r.store_format().cpu().numpy().astype(np.uint32)
+            assert int(word[2]) == lo and int(word[3]) == lo + span
+            assert int(word[0]) == (want if fmt == 'f32' else _lib.STORE_F32), (span, fmt, word)
+            got[fmt] = _fit_digest(r, target, T=6)
+        assert got['f32'] == got['f32plain'], hex(span)
