@@ -478,7 +478,10 @@ __device__ __forceinline__ int nth_set_bit(uint32_t p, int n) {
     return pos + ((n >= (int)(p & 1u)) ? 1 : 0);
 }
 
-template <int kFmt, int kExt>
+// kZ24: the instantiation that writes 24-bit range codes.  Which of the two forms a float32 store takes is decided on the
+// device (decide_store_format), so both instantiations are launched and the one whose form it is not returns at once (a few
+// microseconds per image; one kernel with both store paths in it held 100 registers instead of 92 and lost a wave per SIMD).
+template <int kFmt, int kExt, bool kZ24 = false>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                                                       uint8_t *__restrict__ ext_comp,
                                                       const uint8_t *__restrict__ ext2_dense,
                                                       uint8_t *__restrict__ ext2_comp, const uint32_t *__restrict__ store_fmt) {
+    static_assert(!kZ24 || (kFmt == 0 && kExt == 0), "24-bit range codes: float32 store without extension planes");
+    if ((store_fmt[0] == (uint32_t)kStoreZ24) != kZ24) return;   // the other instantiation's store (kernel-uniform)
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
     constexpr uint32_t kStageMask = (1u << kStageViews) - 1u;
     static_assert(kStageViews == 8 || kStageViews == 16, "a stage group is a byte or a half word of the 32-bit presence words");
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     const StripMeta sm = meta[dst / kStripPx];
     const uint32_t nl = sm.levels;
     // a float32 store without extension planes may have been made a store of 24-bit codes (decide_store_format)
-    const bool z24 = kFmt == 0 && kExt == 0 && store_fmt[0] == (uint32_t)kStoreZ24;   // workgroup-uniform
+    constexpr bool z24 = kZ24;
     const uint32_t zoff = store_fmt[1];
     uint8_t *out = comp + sm.lvoff * (uint64_t)(z24 ? level_bytes(kStoreZ24) : level_bytes(kFmt));
     float *const eout[2] = {kExt >= 1 ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr,
@@ -656,9 +661,13 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     else if (fmt == SUCRE_OBS_U16MM)
         hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
                            pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
-    else
-        hipLaunchKernelGGL((scatter_kernel<0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+    else {
+        hipLaunchKernelGGL((scatter_kernel<0, 0, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
                            pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
+        if (allow_z24)
+            hipLaunchKernelGGL((scatter_kernel<0, 0, true>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                               pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
+    }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_plan(L, ws, s);   // the fit waves' item streams over the store just written (fit.hip); it reads the store's format
 }

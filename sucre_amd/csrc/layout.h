@@ -88,7 +88,8 @@ struct Layout {
     size_t off_strip_meta;  // StripMeta [n_strips]
     size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [5]: format of the compact store (kStore*), the
                             // offset of its 24-bit range codes (kStoreZ24), smallest / largest range bits of the dense store
-    size_t off_zrange;      // uint2  [n_tiles][n_views]   smallest / largest float32 bit pattern of the pair's ranges (0xffffffff / 0: none)
+    size_t off_zrange;      // uint2  [n_tiles][n_views]   smallest / largest float32 bit pattern of ranges of the tile (0xffffffff / 0: none); an imported
+                            // view's entry holds its own, a matched view's the ranges of ALL the views its wave walked (or none)
     size_t off_zpart;       // uint2  [ceil(n_tiles / 32)] the same over 32 tiles and all views
     size_t off_view_count;  // uint64 [n_views]
     size_t off_view_keep;   // uint32 [n_views]

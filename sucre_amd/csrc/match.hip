@@ -157,6 +157,23 @@ constexpr int kViewsPerGroup = 16;
 // kExt: extension planes are written (`ext`: the camera points, or float32 colours with SUCRE_EXT_COLOUR).
 // kBoth (SUCRE_EXT_POINTS_COLOUR): the views' colour images are float32 AND the camera points are kept -- cP goes to
 // `ext`, the float32 colour to `ext2` (light model on resized images).
+// Minimum / maximum over the wave by data-parallel-primitive moves (no LDS traffic; a shuffle tree is six ds_bpermute per
+// value): row_shr 1, 2, 4, 8 inside the rows of 16, then the row broadcasts 15 and 31 -- lane 63 ends up with the result.
+#define SUCRE_DPP_STEP(OP, X, CTRL, ROWS, FILL) X = OP(X, (uint32_t)__builtin_amdgcn_update_dpp((int)(FILL), (int)X, CTRL, ROWS, 0xf, false))
+__device__ __forceinline__ uint32_t wave_umin_to_last(uint32_t x) {
+    SUCRE_DPP_STEP(min, x, 0x111, 0xf, 0xffffffffu); SUCRE_DPP_STEP(min, x, 0x112, 0xf, 0xffffffffu);
+    SUCRE_DPP_STEP(min, x, 0x114, 0xf, 0xffffffffu); SUCRE_DPP_STEP(min, x, 0x118, 0xf, 0xffffffffu);
+    SUCRE_DPP_STEP(min, x, 0x142, 0xa, 0xffffffffu); SUCRE_DPP_STEP(min, x, 0x143, 0xc, 0xffffffffu);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_umax_to_last(uint32_t x) {
+    SUCRE_DPP_STEP(max, x, 0x111, 0xf, 0u); SUCRE_DPP_STEP(max, x, 0x112, 0xf, 0u);
+    SUCRE_DPP_STEP(max, x, 0x114, 0xf, 0u); SUCRE_DPP_STEP(max, x, 0x118, 0xf, 0u);
+    SUCRE_DPP_STEP(max, x, 0x142, 0xa, 0u); SUCRE_DPP_STEP(max, x, 0x143, 0xc, 0u);
+    return x;
+}
+#undef SUCRE_DPP_STEP
+
 template <bool kBoth, bool kExt>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void match_kernel(uint8_t *__restrict__ obs, uint16_t *__restrict__ cnt,
                                                     const float *__restrict__ depth1, const CamDev c1,
@@ -202,6 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
     const int kb = k0 + blockIdx.y * kViewsPerGroup;
     const int ke = min(kb + kViewsPerGroup, k1);
+    // smallest / largest bit pattern of the wave's ranges (positive floats order like integers), over ALL the views the wave
+    // walks: what the compaction needs to know to keep the ranges as 24-bit codes (layout.h, kStoreZ24) is the image's span,
+    // so the wave reduces once, after its last view, and leaves the result in that view's entry (neutral pairs in the others)
+    uint32_t zlo = 0xffffffffu, zhi = 0u;
     for (int k = kb + wave; k < ke; k += 4) {
         const sucre_view_t *vw = views + k;  // wave-uniform: scalar loads
         const uint8_t *__restrict__ rgb2 = vw->rgb;
@@ -210,7 +231,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const bool pin = pin1 && pinhole_form(vw->K) && pinhole_form(vw->Kinv);   // the pair's four matrices: one scalar branch
         int total = 0;
         unsigned long long bal[4];
-        uint32_t zlo = 0xffffffffu, zhi = 0u;   // smallest / largest bit pattern of the pair's ranges (positive floats order like integers)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool m = ok1[j];
@@ -255,10 +275,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (lane < 4)   // the four ballots in ONE store instruction (lane j holds word j)
             vbits[((size_t)tile * n_views + k) * 4 + lane] = lane == 0 ? bal[0] : lane == 1 ? bal[1] : lane == 2 ? bal[2] : bal[3];
         if (lane == 0) cnt[(size_t)tile * n_views + k] = (uint16_t)total;
-        // what the compaction needs to know to keep the ranges as 24-bit codes (layout.h, kStoreZ24): twelve shuffles per pair
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
-        if (lane == 0) zrange[(size_t)tile * n_views + k] = make_uint2(zlo, zhi);
+        if (k + 4 >= ke) {   // the wave's last view (wave-uniform)
+            const uint32_t lo = wave_umin_to_last(zlo), hi = wave_umax_to_last(zhi);
+            if (lane == 63) zrange[(size_t)tile * n_views + k] = make_uint2(lo, hi);
+        } else if (lane == 63) {
+            zrange[(size_t)tile * n_views + k] = make_uint2(0xffffffffu, 0u);
+        }
         if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: LDS
             __builtin_amdgcn_wave_barrier();                          // operations of one wave complete in order
@@ -348,10 +370,13 @@ __global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__res
         } else {
             for (int i = 0; i < n; ++i) s += p[(size_t)i * n_views];
         }
-        for (int i = 0; i < n; ++i) {
-            if (p[(size_t)i * n_views] == 0) continue;   // a pair without a match has never been written
-            const uint2 r = zr[(size_t)i * n_views];
-            zlo = min(zlo, r.x); zhi = max(zhi, r.y);
+        // (every pair is written by whoever filled the view, with or without a match: the neutral pair then)
+        for (int i0 = 0; i0 < n; i0 += 8) {   // eight loads in flight
+            uint2 r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = i0 + j < n ? zr[(size_t)(i0 + j) * n_views] : make_uint2(0xffffffffu, 0u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { zlo = min(zlo, r[j].x); zhi = max(zhi, r[j].y); }
         }
         partial[(size_t)blockIdx.x * n_views + k] = s;
     }
