@@ -141,9 +141,49 @@ def generate(name, spec):
     print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', json.dumps(timing), flush=True)
 
 
+def generate_extensions(name='baseline_c1_extensions'):
+    """The two extensions of the path at config-1 size (640x480, 4 neighbours + self, seed 0): the reference's own
+    --light-model run (sucre.py:54-61, 100 iterations, autograd) and the shared-water composition of TWO reference modules
+    with tied B, beta, gamma (ref_harness.reference_shared_water: this image and its left neighbour, 40 iterations)."""
+    import copy
+    W, H, nn, seed = CONFIGS['baseline_c1_640x480_n4'][:4]
+    scene = synth.make_scene(W, H, nn, seed=seed)
+    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names), stride=4)
+    out['input_digest_per_view'], out['input_digest'] = (np.array(x) for x in input_digests(scene))
+    out.update(derived_matrices(scene))
+    per_view, md, target = rh.reference_matches(scene, min_cover=1e-6)
+    out['n_matches'] = np.array([len(r['u1']) for r in per_view], np.int64)
+    out['kept'] = np.array([r['kept'] for r in per_view])
+    out['n_obs'] = np.int64(len(md))
+    out['match_digest'] = np.array([match_map_digest(r['u1'].numpy(), r['v1'].numpy(), r['u2'].numpy(), r['v2'].numpy(), H, W) for r in per_view])
+    t0 = time.perf_counter()
+    fitl = quiet(rh.reference_fit, scene, md, target, num_iter=100, light_model=True, batch_size=5)
+    print(name, f'light model, 100 iterations {time.perf_counter() - t0:.1f}s', flush=True)
+    out['trace_light'] = fitl['trace']
+    s = j_summary(fitl['J'])
+    out['J_light'] = np.ascontiguousarray(fitl['J'][::4, ::4]); out['J_light_nan_count'] = np.int64(s['nan_count'])
+    out['J_light_sum'], out['J_light_sqsum'] = s['sum'], s['sqsum']
+    other = copy.copy(scene)
+    other.target = scene.target - 1
+    t0 = time.perf_counter()
+    shared = quiet(rh.reference_shared_water, [scene, other], num_iter=40)
+    print(name, f'shared water, two images, 40 iterations {time.perf_counter() - t0:.1f}s', flush=True)
+    out['shared_targets'] = np.array([scene.target, other.target])
+    out['shared_trace'] = shared['trace']
+    out['shared_n_total'] = np.int64(shared['n_total'])
+    for i, J in enumerate(shared['J']):
+        s = j_summary(J)
+        out[f'J_shared{i}'] = np.ascontiguousarray(J[::4, ::4]); out[f'J_shared{i}_nan_count'] = np.int64(s['nan_count'])
+        out[f'J_shared{i}_sum'], out[f'J_shared{i}_sqsum'] = s['sum'], s['sqsum']
+    np.savez_compressed(HERE / f'{name}.npz', **out)
+    print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', flush=True)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     want = [a for a in sys.argv[1:] if not a.startswith('--')]
     for name, spec in CONFIGS.items():
         if not want or any(w in name for w in want):
             (add_derived if '--add-derived' in sys.argv else generate)(name, spec)
+    if 'ext' in want:
+        generate_extensions()

@@ -239,10 +239,12 @@ def check_baseline_matches(b, counts, maps, label):
             assert abs(n - ref_counts[k]) <= 1e-4 * ref_counts[k] + 8, (label, 'count of view', k, n, ref_counts[k])
 
 
-def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label):
+def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, trace_key=None, light_bar=None):
     """A full (H,W,3) J and a (T, >=10) trace against what the REFERENCE stored: J[::stride, ::stride], the NaN count
     and the per-channel sums of J and J^2 over the whole image, the (T,10) cost / B / beta / gamma trajectory."""
     st = max(int(b['stride']), 4) if key == 'param_1' else int(b['stride'])
+    if not b.inputs_identical and light_bar is not None:
+        light_bar = max(light_bar, 1e-2)
     ref = b[f'J_{key}']
     sub = J[::st, ::st]
     if not b.inputs_identical:   # a libm that renders another scene: the north-star bar instead of the tight ones
@@ -259,9 +261,12 @@ def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label):
     assert rms.max() < rms_bar, (label, key, 'RMS(J) vs the reference', rms)
     assert dmean.max() < rms_bar and dsq.max() < rms_bar, (label, key, 'whole-image mean / mean square', dmean, dsq)
     if trace is not None:
-        rt = b['trace_closed' if key == 'closed' else 'trace_param'][:trace.shape[0]]
-        out['dpar'] = float(np.abs(trace[:, 1:10] - rt[:, 1:]).max())
+        rt = b[trace_key or ('trace_closed' if key == 'closed' else 'trace_param')][:trace.shape[0]]
+        out['dpar'] = float(np.abs(trace[:, 1:10] - rt[:, 1:10]).max())
         out['dcost'] = float(np.abs(trace[:, 0] / rt[:, 0] - 1).max())
+        if light_bar is not None:   # cam2light, sigma: their gradients sit at Adam's eps (the reference's own batch-order noise: 1e-3)
+            out['dlight'] = float(np.abs(trace[:, 10:] - rt[:, 10:]).max())
+            assert out['dlight'] < light_bar, (label, key, 'light parameters', out['dlight'])
         assert out['dpar'] < param_bar, (label, key, 'B, beta, gamma trajectory', out['dpar'])
         assert out['dcost'] < cost_bar, (label, key, 'cost trajectory', out['dcost'])
     print(f'{label} [{key}] vs the REFERENCE: rms(J)={rms} |dmean|={dmean.max():.2e} '

@@ -73,3 +73,60 @@ def test_config2_short_engine_vs_reference():
     helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2, 1 iteration')
     helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, config 2, {T_param} iterations')
     helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} iterations')
+
+
+@pytest.mark.timeout(900)
+def test_config1_extensions_engine_vs_reference():
+    """The extensions at config-1 size against the reference itself (tests/golden/baseline_c1_extensions.npz): its own
+    --light-model run of 100 iterations (19 parameters, autograd) and its two-module shared-water composition (40
+    iterations, tied B, beta, gamma) -- the latter through the single-launch group kernel AND through the split
+    grad / all-reduce / step path that N ranks run."""
+    from sucre_amd import dist as sdist
+    from sucre_amd import engine
+    b = helpers.load_baseline('baseline_c1_extensions')
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    # light model
+    r = engine.Restoration(sc.height, sc.width, len(views), light=True)
+    r.match(views[sc.target], views)
+    helpers.check_baseline_matches(b, r.view_counts().cpu().numpy().tolist(), [r.match_map(k).cpu().numpy() for k in range(len(views))], 'extensions engine')
+    r.fit_init(views[sc.target])
+    T = b['trace_light'].shape[0]
+    trace = r.fit(T).cpu().numpy()
+    assert abs(trace[0, 0] / b['trace_light'][0, 0] - 1) < 1e-6
+    helpers.check_baseline_fit(b, 'light', r.J().cpu().numpy(), trace, 1e-4, 2e-4, 5e-3, f'ENGINE, config 1 light model, {T} iterations',
+                               trace_key='trace_light', light_bar=3e-3)
+    del r
+    # shared water: two images of the scene, tied parameters
+    targets = [int(t) for t in b['shared_targets']]
+    rt = b['shared_trace']
+    for path in ('group', 'split'):
+        rs = []
+        for t in targets:
+            x = engine.Restoration(sc.height, sc.width, len(views))
+            x.match(views[t], views)
+            x.fit_init(views[t])
+            rs.append(x)
+        assert sum(x.n_obs() for x in rs) == int(b['shared_n_total'])
+        trace = torch.zeros((rt.shape[0], 10), dtype=torch.float64, device='cuda')
+        if path == 'group':
+            sdist.fit_shared_water(engine.HipWaterGroup(rs, trace=trace), rt.shape[0])
+        else:   # what two ranks do, in one process: every image its own backend, the sums added by hand
+            bes = [engine.HipWaterBackend(x, trace=trace if i == 0 else None) for i, x in enumerate(rs)]
+            total = sum(be.n_obs() for be in bes)
+            for be in bes:
+                be.set_n_obs_total(total)
+            for it in range(1, rt.shape[0] + 1):
+                sums = [be.grad(it).clone() for be in bes]
+                tot = sums[0] + sums[1]
+                for be in bes:
+                    be._sums.copy_(tot)
+                    be.step(it)
+        torch.cuda.synchronize()
+        tr = trace.cpu().numpy()
+        dpar, dcost = np.abs(tr[:, 1:] - rt[:, 1:]).max(), np.abs(tr[:, 0] / rt[:, 0] - 1).max()
+        print(f'ENGINE, config 1 shared water ({path}): max|dparams|={dpar:.2e} max rel dcost={dcost:.2e}')
+        assert dpar < 2e-6 and dcost < 2e-5
+        for i, x in enumerate(rs):
+            helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 1 shared water ({path}), image {i}')
+        del rs

@@ -282,3 +282,24 @@ def test_baseline_config2_short_oracle_vs_reference():
     helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, config 2, {T_param} iterations')
     Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
     helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 2, {T_closed} iterations')
+
+
+def test_baseline_config1_extensions_oracle_vs_reference():
+    """The two extensions of the path at config-1 size (tests/golden/baseline_c1_extensions.npz): the reference's own
+    --light-model run (100 iterations, autograd) and two reference modules with tied water parameters (40 iterations)."""
+    b = helpers.load_baseline('baseline_c1_extensions')
+    sc = b.scene
+    per_view, samples = helpers.oracle_scene_samples(sc)
+    helpers.check_baseline_matches(b, [len(m) for _, _, m in per_view], [helpers.dense_map(m, sc.height, sc.width) for _, _, m in per_view], 'extensions oracle')
+    tgt = sc.views[sc.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    T = b['trace_light'].shape[0]
+    J, params, trace = oracle.fit_light(sc.height, sc.width, samples, J0, num_iter=T)
+    assert abs(trace[0, 0] / b['trace_light'][0, 0] - 1) < 1e-6
+    helpers.check_baseline_fit(b, 'light', J, trace, 1e-4, 2e-4, 5e-3, f'oracle, config 1 light model, {T} iterations', trace_key='trace_light', light_bar=3e-3)
+    g = {k: b[k] for k in ('shared_targets', 'shared_trace', 'shared_n_total')}
+    imgs, pstate, tr, total = shared_oracle_run(sc, g['shared_targets'], g['shared_trace'].shape[0], closed=False)
+    assert total == int(g['shared_n_total'])
+    assert np.abs(tr[:, 1:] - g['shared_trace'][:, 1:]).max() < 2e-6 and np.abs(tr[:, 0] / g['shared_trace'][:, 0] - 1).max() < 2e-5
+    for i, o in enumerate(imgs):
+        helpers.check_baseline_fit(b, f'shared{i}', o.J, None, 1e-6, 0, 0, f'oracle, config 1 shared water, image {i}')
