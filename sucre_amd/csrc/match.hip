@@ -362,7 +362,6 @@ __global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__res
     uint32_t zlo = 0xffffffffu, zhi = 0u;
     for (int k = threadIdx.x; k < n_views; k += 256) {
         const uint16_t *p = cnt + (size_t)t0 * n_views + k;
-        const uint2 *zr = zrange + (size_t)t0 * n_views + k;
         uint32_t s = 0;
         if (n == kStatTiles) {
 #pragma unroll
@@ -370,15 +369,16 @@ __global__ __launch_bounds__(256) void view_partial_kernel(const uint16_t *__res
         } else {
             for (int i = 0; i < n; ++i) s += p[(size_t)i * n_views];
         }
-        // (every pair is written by whoever filled the view, with or without a match: the neutral pair then)
-        for (int i0 = 0; i0 < n; i0 += 8) {   // eight loads in flight
-            uint2 r[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = i0 + j < n ? zr[(size_t)(i0 + j) * n_views] : make_uint2(0xffffffffu, 0u);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { zlo = min(zlo, r[j].x); zhi = max(zhi, r[j].y); }
-        }
         partial[(size_t)blockIdx.x * n_views + k] = s;
+    }
+    {   // the rows of the workgroup's tiles are one contiguous run of pairs (every pair is written by whoever filled the view,
+        // with or without a match: the neutral pair then): all 256 threads, coalesced
+        const uint2 *base = zrange + (size_t)t0 * n_views;
+        const int total = n * n_views;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const uint2 r = base[i];
+            zlo = min(zlo, r.x); zhi = max(zhi, r.y);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, off, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, off, 64)); }
