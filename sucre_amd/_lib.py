@@ -103,6 +103,11 @@ def load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise SucreError(f'{LIB_PATH} is missing: build the gfx950 HIP library first '
                          f'(make -C {LIB_PATH.parent / "csrc"}); there is no fallback path')
+    # PyTorch-ROCm ships its own HIP runtime; it must be the process's one BEFORE this library is loaded (the library then
+    # binds to the copy already mapped).  Loaded first, the library pulls in /opt/rocm's copy and torch its own afterwards:
+    # two runtimes in one process, and every launch on a torch stream fails with "no ROCm-capable device is detected"
+    # (seen with build() and smoke() in one interpreter).
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
