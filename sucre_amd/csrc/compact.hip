@@ -394,9 +394,11 @@ __device__ __forceinline__ void store_group_z24(uint8_t *strip, uint32_t g, uint
                                                 const uint32_t (&c)[3], uint32_t zoff) {
     uint8_t *ch = strip + (size_t)g * kChunk24;
     if (r == kGroupLv) {
-        const uint32_t c0 = range_code(z[0], zoff), c1 = range_code(z[1], zoff), c2 = range_code(z[2], zoff), c3 = range_code(z[3], zoff);
-        uint32_t *p = reinterpret_cast<uint32_t *>(ch + lane * 24);   // the lane's 24 bytes: four codes, then the R, G, B words
-        *reinterpret_cast<uint4 *>(p) = make_uint4(c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8), c[0]);
+        // the lane's 24 bytes: four dwords {code of level j | red of level j << 24} (the reader takes the code with one
+        // v_mad_u32_u24 and the red byte with v_cvt_f32_ubyte3), then the G and B words
+        uint32_t *p = reinterpret_cast<uint32_t *>(ch + lane * 24);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(range_code(z[0], zoff) | (c[0] << 24), range_code(z[1], zoff) | ((c[0] >> 8) << 24),
+                                                   range_code(z[2], zoff) | ((c[0] >> 16) << 24), range_code(z[3], zoff) | ((c[0] >> 24) << 24));
         *reinterpret_cast<uint2 *>(p + 4) = make_uint2(c[1], c[2]);
     } else {
 #pragma unroll

@@ -411,17 +411,21 @@ __device__ __forceinline__ bool store_matches(const uint32_t *__restrict__ store
 // A full chunk in a ring slot -> this lane's four ranges and three colour dwords.  masked: the chunk may hold empty slots.
 template <int kFmt>
 __device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&zz)[kGroupLv], uint32_t (&cc)[3], const RangeCodes &rc, bool masked) {
-    if (kFmt == 0 && rc.z24) {   // wave-uniform: the lane's 24 bytes side by side -- four codes in three dwords, then R, G, B
+    if (kFmt == 0 && rc.z24) {   // wave-uniform: the lane's 24 bytes side by side -- {code | red << 24} x 4, G word, B word
         const uint2 a = *reinterpret_cast<const uint2 *>(sp + lane * 24), b = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 8),
                     c = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 16);
-        const uint32_t c0 = a.x & 0xffffffu, c1 = __builtin_amdgcn_alignbit(a.y, a.x, 24) & 0xffffffu,
-                       c2 = __builtin_amdgcn_alignbit(b.x, a.y, 16) & 0xffffffu, c3 = b.x >> 8;
-        zz[0] = __uint_as_float(c0 + rc.zoff); zz[1] = __uint_as_float(c1 + rc.zoff);
-        zz[2] = __uint_as_float(c2 + rc.zoff); zz[3] = __uint_as_float(c3 + rc.zoff);
-        if (masked) {   // an empty slot reads as range 0, like in the float32 store
-            zz[0] = c0 ? zz[0] : 0.0f; zz[1] = c1 ? zz[1] : 0.0f; zz[2] = c2 ? zz[2] : 0.0f; zz[3] = c3 ? zz[3] : 0.0f;
+        const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+        for (int j = 0; j < kGroupLv; ++j) {
+            // bits(z) = code + offset in one instruction: v_mad_u32_u24 multiplies the LOW 24 BITS of its operands
+            uint32_t bits;
+            asm("v_mad_u32_u24 %0, %1, 1, %2" : "=v"(bits) : "v"(w[j]), "s"(rc.zoff));
+            zz[j] = __uint_as_float(bits);
+            if (masked) zz[j] = (w[j] & 0xffffffu) ? zz[j] : 0.0f;   // an empty slot reads as range 0, like in the float32 store
         }
-        cc[0] = b.y; cc[1] = c.x; cc[2] = c.y;
+        // the red bytes sit in byte 3 of the four dwords: gathered into one word so that the arithmetic below is format-blind
+        cc[0] = __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0703u) | __builtin_amdgcn_perm(b.y, b.x, 0x07030c0cu);
+        cc[1] = c.x; cc[2] = c.y;
         return;
     }
     if (kFmt == 0) {

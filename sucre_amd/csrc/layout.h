@@ -21,7 +21,7 @@ constexpr float kMmPerM = 1000.0f, kMPerMm = 0.001f;
 // image whose bit patterns all lie within 2^24 - 2 of the smallest one -- any scene whose ranges span less than about a
 // factor of four -- are kept as 24-bit codes, code = bits(z) - bits(z_min) + 1 (0 = empty slot): bits(z) = code + offset
 // gives every range back exactly, 6 instead of 7 bytes per observation.  A full chunk: 64 x {4 codes (12 B), R word, G word,
-// B word} = 1536 B, a lane's 24 bytes side by side; the short last chunk: [code: 64 x r x 3 B][R: 64 x r][G][B].
+// B word} = 1536 B, a lane's 24 bytes side by side (four dwords code | red << 24, then the G and B words); the short last chunk: [code: 64 x r x 3 B][R: 64 x r][G][B].
 constexpr int kStoreF32 = 0, kStoreU16 = 1, kStoreZ24 = 2;
 constexpr int kChunk24 = 6 * 256;    // 1536 bytes
 __host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt == kStoreU16 ? kChunk16 : fmt == kStoreZ24 ? kChunk24 : kChunk; }
