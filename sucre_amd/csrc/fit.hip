@@ -8,7 +8,8 @@
 // Work decomposition: 256 x kFitWaves (1280) persistent 256-thread workgroups; every WAVE works alone on strips of 64 count-sorted
 // pixels (csrc/compact.hip, layout.h), one pixel per lane, and never synchronises with the other waves until the
 // launch's final reduction.  A strip is a sequence of ITEMS -- its J plane (768 B), its observation chunks (64 pixels
-// x 4 levels, 1792 B; the last one may hold fewer levels) and, in J-parameter mode, its Adam moments (1536 B) --
+// x 4 levels: 1792 B of float32 ranges + colours, 1536 B when the ranges are kept as 24-bit codes, 1280 B as uint16
+// millimetres; the last one may hold fewer levels) and, in J-parameter mode, its Adam moments (1536 B) --
 // and the strips of a wave follow each other without a gap, so a wave sees ONE stream of items.  Every item is
 // copied HBM -> LDS by two LDS-DMA instructions into a private ring of kRing slots, kAhead items ahead of the one
 // being consumed, across strip boundaries: prefetch depth costs LDS, not registers, no latency is exposed between
