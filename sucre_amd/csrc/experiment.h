@@ -48,3 +48,13 @@ constexpr bool kExactDiv = SUCRE_EXACT_DIV != 0;
 #define SUCRE_EXACT_J_ADAM 0
 #endif
 constexpr bool kExactJAdam = SUCRE_EXACT_J_ADAM != 0;
+
+// light.hip, timing only (results meaningless): light + closed form with the water sums formed in the FIRST observation pass the
+// way fit.hip's one-pass closed form forms them (seven more sums per channel there, the four water accumulations gone from the
+// second pass) -- the variant VERDICT r03 task 6(ii) asked to be timed instead of argued about.  Same box, one image at a time:
+// 570.2 vs 570.5 us per launch (tools/exp/ab_solo.sh product wp1): both passes wait for memory.
+#ifdef SUCRE_EXP_LIGHT_WATER_PASS1
+constexpr bool kExpWaterPass1 = true;
+#else
+constexpr bool kExpWaterPass1 = false;
+#endif

@@ -394,6 +394,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         if (kClosed) {
             // closed-form J of this pixel: numerator / denominator per channel over all levels
             float num[3], den[3];
+            float wq[7][3];   // (kExpWaterPass1 only)
+            if (kExpWaterPass1) {
+#pragma unroll
+                for (int q = 0; q < 7; ++q) wq[q][0] = wq[q][1] = wq[q][2] = 0.f;
+            }
             auto solve = [&](auto gradual) {
                 constexpr bool kGradual = decltype(gradual)::value;
 #pragma unroll
@@ -422,6 +427,14 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                             const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
                             num[c] = __builtin_fmaf(I - b, a, num[c]);
                             den[c] = __builtin_fmaf(a, a, den[c]);
+                            if (kExpWaterPass1) {   // timing experiment only (experiment.h): what the one-pass water sums of
+                                // fit.hip's closed_terms would add to this pass -- omg, z a, z g and seven more sums per channel
+                                const float g2 = 1.0f - b, za = o.z * a, zg = o.z * g2, p = I - b;
+                                wq[0][c] = __builtin_fmaf(p, g2, wq[0][c]); wq[1][c] = __builtin_fmaf(a, g2, wq[1][c]);
+                                wq[2][c] = __builtin_fmaf(p, za, wq[2][c]); wq[3][c] = __builtin_fmaf(a, za, wq[3][c]);
+                                wq[4][c] = __builtin_fmaf(p, zg, wq[4][c]); wq[5][c] = __builtin_fmaf(a, zg, wq[5][c]);
+                                wq[6][c] = __builtin_fmaf(p, p, wq[6][c]);
+                            }
                         }
                     }
                 }
@@ -438,6 +451,13 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             for (int c = 0; c < 3; ++c) {
                 J[c] = num[c] / den[c];  // 0/0 = NaN where nothing was observed
                 st[c * kStripPx] = J[c];
+                if (kExpWaterPass1) {   // the pixel's share of the water sums, formed from the pass-one sums (values meaningless here)
+                    const float dJ = J[c];
+                    acc.s[c] += __builtin_fmaf(-dJ, wq[1][c], wq[0][c]);
+                    acc.s[6 + c] += __builtin_fmaf(-dJ, wq[3][c], wq[2][c]);
+                    acc.s[3 + c] += __builtin_fmaf(-dJ, wq[5][c], wq[4][c]);
+                    acc.s[9] += __builtin_fmaf(-dJ, num[c], wq[6][c]);
+                }
             }
             if (kJOnly) continue;
         } else {
@@ -491,11 +511,13 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                                   : kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
                     const float rl = r * l;
                     const float rlz = rl * z;
-                    acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
-                    pa[c] = __builtin_fmaf(rl, a, pa[c]);
-                    pb[c] = __builtin_fmaf(rlz, a, pb[c]);
-                    acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
-                    acc.s[3 + c] = __builtin_fmaf(rlz, g2, acc.s[3 + c]);
+                    if (!(kExpWaterPass1 && kClosed)) {   // (the experiment has formed these in pass one)
+                        acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
+                        pa[c] = __builtin_fmaf(rl, a, pa[c]);
+                        pb[c] = __builtin_fmaf(rlz, a, pb[c]);
+                        acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
+                        acc.s[3 + c] = __builtin_fmaf(rlz, g2, acc.s[3 + c]);
+                    }
                     dl = __builtin_fmaf(r, E, dl);
                     dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g2, -(bJ[c] * a)), dz);
                 }

@@ -604,8 +604,9 @@ def test_experiment_variants_compile(tmp_path):
         'tring4w4': '-DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4',
         'texactdiv': '-DSUCRE_EXACT_DIV=1',
         'texactadam': '-DSUCRE_EXACT_J_ADAM=1',
+        'twp1': '-DSUCRE_EXP_LIGHT_WATER_PASS1',
     }
-    objects = {'texactdiv': 'match'}   # the source a knob lives in (default: fit)
+    objects = {'texactdiv': 'match', 'twp1': 'light'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here
         assert any(macro in flags for flags in variants.values()) or macro in ('SUCRE_CLOSED_WAVES', 'SUCRE_DMA_POLICY'), macro
     # no other build-time switch hides in the kernel sources
