@@ -5,6 +5,8 @@ Run in the dev container only (the reference never travels):  python tests/golde
   c1  config 1 IN FULL: 640x480, 4 neighbours + self, ``synth.make_scene(640, 480, 4, seed=0)``; the reference's
       own ``match_two_way`` over every view and its own ``sucre.adam`` for 200 iterations, J-parameter mode and
       closed-form mode (sucre.py:124-157, sfm.py:121-138).
+  c2full  config 2 IN FULL for the J-parameter mode: the same image, the reference's own 200 iterations (~1 h of CPU) and 60
+      closed-form iterations (~30 min).
   c2  config 2, SHORT: 1920x1080, 64 neighbours + self, ``synth.make_scene(1920, 1080, 64, seed=0)`` -- bench.py's
       own rank-0 workload -- all 65 views matched by the reference, then ``sucre.adam`` for a few iterations (a full
       200-iteration run is ~2.5 h of CPU per mode).
@@ -40,6 +42,8 @@ CONFIGS = {
     # name: (width, height, n_neighbours, seed, T J-parameter, T closed-form, J stride stored)
     'baseline_c1_640x480_n4': (640, 480, 4, 0, 200, 200, 1),
     'baseline_c2_1920x1080_n64': (1920, 1080, 64, 0, 10, 5, 4),
+    # the same image, the reference's WHOLE J-parameter run (200 iterations: an hour of CPU) and 60 closed-form iterations
+    'baseline_c2full_1920x1080_n64': (1920, 1080, 64, 0, 200, 60, 4),
 }
 
 

@@ -130,3 +130,18 @@ def test_config1_extensions_engine_vs_reference():
         for i, x in enumerate(rs):
             helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 1 shared water ({path}), image {i}')
         del rs
+
+
+@pytest.mark.timeout(1500)
+def test_config2_in_full_engine_vs_reference():
+    """BASELINE config 2 start to end against the reference itself: the bench's own image (1920x1080, 64 neighbours + self,
+    79 M observations), the reference's WHOLE J-parameter run -- all 200 Adam iterations, an hour of its CPU path -- and 60
+    closed-form iterations (tests/golden/baseline_c2full_1920x1080_n64.npz): J[::4, ::4], the NaN count and the sums of J and
+    J^2 over the whole image, and every row of the cost / B / beta / gamma trajectory."""
+    b = helpers.load_baseline(helpers.BASELINE_C2FULL)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    assert T_param == 200 and T_closed >= 50
+    e = engine_run(b, T_param, T_closed, with_maps=False)   # (the match maps are pinned by the short fixture of the same scene)
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2 in full, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, 'ENGINE, config 2 IN FULL, 200 iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} closed-form iterations')
