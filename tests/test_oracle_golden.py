@@ -149,19 +149,29 @@ def test_se3_exp_matches_reference_values():
 
 def test_light_model_with_closed_form_J(golden):
     """--light-model --use-closed-form (sucre.py:66-77 with l != 1).  On the relief fixture this trajectory is chaotic
-    in the reference itself after ~70 iterations (red backscatter goes negative; its own batch-1 vs batch-5 runs
-    differ by 2.8e-3 in the water parameters and 1.8e-2 RMS in J's red channel), so: tight over the first 50
-    iterations, bounded by that self-noise afterwards."""
+    in the reference itself after ~70 iterations (red backscatter goes negative; its own batch-1 vs batch-5 runs --
+    tests/golden/light_closed_spread.npz, gen_golden_extras.py -- differ by 2.8e-3 in the water parameters and 1.8e-2 RMS
+    in J's red channel), so the bars are the reference's OWN spread: tight over the first 50 iterations; at every
+    iteration within helpers.KNEE_FACTOR x the spread its two runs have reached by then (+ 1e-4: analytic against autograd
+    gradients on parameters at Adam's eps) of the nearer run; J within that factor of their RMS distance (+ 2e-5).
+    Measured: 0.6 of the spread on the parameters, 0.25 on J."""
     sc = golden.scene
     _, samples = helpers.oracle_scene_samples(sc)
     J, params, trace = oracle.fit_light(sc.height, sc.width, samples, None, num_iter=100, use_closed_form=True)
-    rt = golden['trace_light_closed']
-    assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-5
-    assert np.abs(trace[:50, 1:] - rt[:50, 1:]).max() < 2e-4 and np.abs(trace[:50, 0] / rt[:50, 0] - 1).max() < 1e-4
-    assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 1e-2
-    assert np.array_equal(np.isnan(J), np.isnan(golden['J_light_closed_100']))
-    rms = helpers.rms_per_channel(J, golden['J_light_closed_100'])
-    assert rms[1:].max() < 1e-4 and rms[0] < 5e-2
+    sp = np.load(helpers.GOLDEN_DIR / 'light_closed_spread.npz')
+    t5, t1 = golden['trace_light_closed'], sp[f'{golden.name}_trace_bs1']
+    J5, J1 = golden['J_light_closed_100'], sp[f'{golden.name}_J_bs1']
+    assert abs(trace[0, 0] / t5[0, 0] - 1) < 1e-5
+    assert np.abs(trace[:50, 1:] - t5[:50, 1:]).max() < 2e-4 and np.abs(trace[:50, 0] / t5[:50, 0] - 1).max() < 1e-4
+    f = helpers.KNEE_FACTOR
+    spread = np.maximum.accumulate(np.abs(t1[:, 1:] - t5[:, 1:]).max(axis=1))
+    d = np.minimum(np.abs(trace[:, 1:] - t5[:, 1:]).max(axis=1), np.abs(trace[:, 1:] - t1[:, 1:]).max(axis=1))
+    assert np.all(d <= f * spread + 1e-4), (d / (f * spread + 1e-4)).max()
+    assert np.array_equal(np.isnan(J), np.isnan(J5))
+    Jspread = helpers.rms_per_channel(J1, J5)
+    rms = np.minimum(helpers.rms_per_channel(J, J5), helpers.rms_per_channel(J, J1))
+    print(f'{golden.name}: oracle, light + closed form: parameters {d.max():.2e} (reference spread {spread[-1]:.2e}); J {rms} (spread {Jspread})')
+    assert np.all(rms <= f * Jspread + 2e-5), (rms, Jspread)
 
 
 def test_u16mm_ranges_stay_inside_the_parity_bar(golden):
