@@ -58,3 +58,33 @@ constexpr bool kExpWaterPass1 = true;
 #else
 constexpr bool kExpWaterPass1 = false;
 #endif
+
+// fit.hip, timing only: every wave of a J-parameter launch records when it entered and left its strips (100 MHz wall clock) --
+// how much of a launch is its ragged end (tools/exp/wave_times.py).
+#ifdef SUCRE_EXP_WAVE_TIMES
+constexpr bool kExpWaveTimes = true;
+#define SUCRE_EXP_EXPORT extern "C" __attribute__((visibility("default")))
+#else
+constexpr bool kExpWaveTimes = false;
+#define SUCRE_EXP_EXPORT [[maybe_unused]] static
+#endif
+
+// fit.hip: s_setprio experiments against the hardware's oldest-wave-first issue order (tools/exp/wave_times.py shows a launch's
+// five resident workgroups per CU finishing one after the other).  0: none; 1: a wave's priority rotates with every strip,
+// offset by the workgroup's generation; 2: static, younger workgroups higher; 3: rotates with every item.
+#ifndef SUCRE_EXP_PRIO
+#define SUCRE_EXP_PRIO 0
+#endif
+constexpr int kExpPrio = SUCRE_EXP_PRIO;
+
+// layout.h: the work a wave of each workgroup generation is dealt, in 64ths of what a wave of generation 0 (the oldest) gets;
+// the first must be 64.  64 everywhere = equal shares (the product).  Measured (tools/exp/wave_times.py, ab_solo.sh): with
+// 64,44,24,14,5 a J-parameter launch ALONE on the GPU takes 126 instead of 134 us (its waves then end within 20 us of each
+// other instead of 75), but with two images in flight -- the default -- the second launch's workgroups arrive as the first one's
+// leave, no longer one generation per CU, and an image takes 25.1 instead of 24.4 ms.
+#ifndef SUCRE_DEAL_FIT
+#define SUCRE_DEAL_FIT 64, 64, 64, 64, 64
+#endif
+#ifndef SUCRE_DEAL_CLOSED
+#define SUCRE_DEAL_CLOSED 64, 64, 64, 64
+#endif

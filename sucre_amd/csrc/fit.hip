@@ -292,21 +292,6 @@ __device__ __forceinline__ void wait_vm(uint32_t n) {
 }
 static_assert(2 * kAhead + 9 <= 63, "s_waitcnt vmcnt takes six bits");
 
-// Which strips a wave works on: strip k W + wid on even passes k, k W + (W - 1 - wid) on odd ones (the strips are
-// sorted heaviest first, so this boustrophedon deal balances the waves), W = waves of the launch.
-struct WaveDeal {
-    uint32_t wid, W, n_strips, K;
-    __host__ __device__ __forceinline__ uint32_t strip(uint32_t k) const { return k * W + ((k & 1u) ? W - 1u - wid : wid); }
-};
-
-__host__ __device__ __forceinline__ WaveDeal make_deal(uint32_t wid, uint32_t W, uint32_t n_strips) {
-    WaveDeal d;
-    d.wid = wid; d.W = W; d.n_strips = n_strips;
-    const uint32_t full = n_strips / W, rem = n_strips % W;
-    d.K = full + ((((full & 1u) ? W - 1u - wid : wid) < rem) ? 1u : 0u);
-    return d;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The plan: every wave's item stream, written once per image (launch_plan, called by the compaction) so that the
 // per-iteration kernels do no bookkeeping.  (History: the first strip kernel walked the strips itself with two
@@ -345,12 +330,17 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     const uint32_t wid = idx / Kmax, k = idx - wid * Kmax;
     if (wid >= W) return;
-    const WaveDeal d = make_deal(wid, W, (uint32_t)n_strips);
-    if (k == 0u) count[wid] = d.K;
-    if (k >= d.K) return;
-    uint32_t start = 0u;   // first item of strip k in the wave's list
-    for (uint32_t kk = 0; kk < k; ++kk) start += strip_items(meta[d.strip(kk)].levels, mode);
-    const uint32_t strip = d.strip(k);
+    // the wave's strips up to its k-th (layout.h, deal_walk): where that one's items start in the wave's list, and how many strips
+    // the wave has in all
+    const DealShares sh = deal_shares(mode, W / 4u);
+    uint32_t start = 0u, strip = 0u, strip0 = 0u;
+    const uint32_t K = deal_walk(wid, W, (uint32_t)n_strips, sh, [&](uint32_t s) { return meta[s].levels; }, [&](uint32_t kk, uint32_t s) {
+        if (kk == 0u) strip0 = s;
+        if (kk < k) start += strip_items(meta[s].levels, mode);
+        if (kk == k) strip = s;
+    });
+    if (k == 0u) count[wid] = K;
+    if (k >= K) return;
     const StripMeta m = meta[strip];
     const uint32_t nfull = m.levels >> 2, r = m.levels & 3u;   // full chunks, levels of the short last one
     const uint32_t nu = min(nfull, m.full >> 2);               // chunks wholly below the strip's smallest pixel count
@@ -363,8 +353,8 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
         *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb) >> 6), item_shape((uint32_t)chunk_bytes(fmt), true)};
     if (r) *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)nfull * kGroupLv) * lb) >> 6), item_shape(r * lb, false)};
     if (mode == 0) *out++ = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_shape(6u * kStripPx * 4u, false)};
-    if (k + 1u == d.K) {   // the kAhead trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
-        const uint64_t st0 = state_off + (uint64_t)d.strip(0) * (kStateFloats * 4);
+    if (k + 1u == K) {   // the kAhead trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
+        const uint64_t st0 = state_off + (uint64_t)strip0 * (kStateFloats * 4);
         for (int j = 0; j < kAhead + 1; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false)};
     }
 }
@@ -494,6 +484,15 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
     uint32_t i = 0;                    // the item being consumed
     uint32_t cs = 0u;                  // byte offset of its slot in the wave's ring; item i + kAhead goes to the slot before it
     uint32_t behind = 0u;              // how many of the next items were issued before the previous strip's stores
+    const uint32_t gen = blockIdx.x >> 8;   // (experiment) which of a CU's resident workgroups this one is, oldest first
+    auto set_prio = [&](uint32_t p) {
+        switch (p & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    };
     auto step = [&]() -> const uint8_t * {
         // The slot that takes item i + kAhead held item i - 1.  Its LDS reads must have RETURNED before the DMA may overwrite
         // it: a chunk's reads have (the arithmetic consumed them), but a J plane is read into registers that are first used
@@ -512,10 +511,13 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         const uint8_t *sp = ringp + cs;
         cs = cs == (uint32_t)((kRing - 1) * kSlot) ? 0u : cs + (uint32_t)kSlot;
         ++i;
+        if (kExpPrio == 3) set_prio(gen + i);
         return sp;
     };
     ItemRegs se = strips[0];
+    if (kExpPrio == 2) set_prio(gen >= 3u ? 3u : gen);
     for (uint32_t k = 0; k < K; ++k) {
+        if (kExpPrio == 1) set_prio(gen + k);
         const uint32_t strip = se.x, counts = se.y;
         if (k + 1u < K) se = strips[k + 1u];
         const uint32_t nu = counts & 255u, nm = (counts >> 8) & 255u, r = (counts >> 16) & 7u;
@@ -719,6 +721,16 @@ __device__ __forceinline__ void zero_acc(Acc &acc) {
     acc.cost = 0.f;
 }
 
+// experiment.h SUCRE_EXP_WAVE_TIMES (tools/exp/wave_times.py): when every wave of the last fit launch entered and left its
+// strips, in ticks of the 100 MHz wall clock.
+constexpr uint32_t kExpWaveSlots = 8192;
+__device__ unsigned long long g_exp_wave_times[5][kExpWaveTimes ? kExpWaveSlots : 1];   // strips begun, strips done, kernel entered, kernel left (100 MHz ticks); shader cycles in the kernel
+}  // namespace sucre
+SUCRE_EXP_EXPORT int sucre_exp_wave_times(unsigned long long *out) {   // exported by the experiment build only
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sucre::g_exp_wave_times), sizeof(sucre::g_exp_wave_times));
+}
+namespace sucre {
+
 // J-parameter iteration of one image: one launch.
 template <bool kFused, int kFmt>
 __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t *__restrict__ ws,
@@ -729,6 +741,7 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
                                                        unsigned *ticket, double *gpart, int n_groups, double *sums,
                                                        double *trace_row, const uint32_t *__restrict__ obs_format) {
     __shared__ FitLds lds;  // 21.9 KB
+    const unsigned long long exp_t_in = kExpWaveTimes ? wall_clock64() : 0ull, exp_c_in = kExpWaveTimes ? clock64() : 0ull;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -746,11 +759,14 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     zero_acc(acc);
     if (!fmt_ok) acc.cost = __builtin_nanf("");
     float sBeta[3] = {0.f, 0.f, 0.f};
+    if (kExpWaveTimes && lane == 0 && wid < kExpWaveSlots) g_exp_wave_times[0][wid] = wall_clock64();
     grad_pass<kFmt>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta, rc);
+    if (kExpWaveTimes && lane == 0 && wid < kExpWaveSlots) g_exp_wave_times[1][wid] = wall_clock64();
 
     float s[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2],
                          sBeta[0], sBeta[1], sBeta[2], acc.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
+    if (kExpWaveTimes && lane == 0 && wid < kExpWaveSlots) { g_exp_wave_times[2][wid] = exp_t_in; g_exp_wave_times[3][wid] = wall_clock64(); g_exp_wave_times[4][wid] = clock64() - exp_c_in; }
 }
 
 // One wave's share of a closed-form iteration on one image, one observation pass (see AccOne); kJOnly:
@@ -840,7 +856,9 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t n_mine = (fmt_ok || kJOnly) ? plan_count[wid] : 0u;   // strips of this wave
     ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
+    if (kExpWaveTimes && !kJOnly && lane == 0 && wid < kExpWaveSlots) g_exp_wave_times[0][wid] = wall_clock64();
     closed_pass<kFmt, kJOnly>(lds, plan + (size_t)wid * plan_stride, plan_strips + (size_t)wid * plan_kmax, n_mine, ws, state, wave, lane, w, fmt_ok, cs, rc);
+    if (kExpWaveTimes && !kJOnly && lane == 0 && wid < kExpWaveSlots) g_exp_wave_times[1][wid] = wall_clock64();
     if (kJOnly) return;
     float s[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
     finish_launch<kFused>(lds, s, partials, co, ticket, gpart, n_groups, sums, pstate, n_obs_total, trace_row);
@@ -1148,8 +1166,8 @@ hipError_t launch_update_J(const Layout &L, uint8_t *ws, int fmt, hipStream_t s)
 hipError_t launch_plan(const Layout &L, uint8_t *ws, hipStream_t s) {
     auto *meta = reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta);
     const uint32_t W0 = (uint32_t)L.fit_blocks[0] * 4u, W1 = (uint32_t)L.fit_blocks[1] * 4u;
-    const uint32_t Wmin = W0 < W1 ? W0 : W1, Wmax = W0 < W1 ? W1 : W0;
-    const uint32_t Kmax = ((uint32_t)L.n_strips + Wmin - 1u) / Wmin;   // strips of the busiest wave (of either mode)
+    const uint32_t Wmax = W0 < W1 ? W1 : W0;
+    const uint32_t Kmax = (uint32_t)(L.plan_kmax[0] > L.plan_kmax[1] ? L.plan_kmax[0] : L.plan_kmax[1]);   // strips of the busiest wave (of either mode)
     hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips,
                        reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2, W0, W1, Kmax,
                        (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], (uint32_t)L.plan_kmax[0], (uint32_t)L.plan_kmax[1],

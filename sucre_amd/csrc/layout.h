@@ -58,6 +58,71 @@ constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (
 constexpr int kClosedGrid = 256 * kClosedWaves;
 constexpr int kMaxViews = 4096;
 
+// ---------------------------------------------------------------------------------------------------------------
+// The deal: which strips a fit wave works on (static, so that every sum is formed in the same order on every run).
+//
+// A full fit grid keeps G = kFitWaves (kClosedWaves) workgroups resident on every CU, i.e. G waves on every SIMD, dispatched
+// in workgroup order: workgroup b is the (b / 256)-th arrival on its CU -- its GENERATION.  The SIMD issues the OLDEST ready wave
+// first, so the generations do not run at one speed: with equal shares generation 0 was done after 54 us of a 126 us launch,
+// generation 4 after 123 us, and for the last 40 us one or two waves per SIMD could not keep the memory system busy
+// (tools/exp/wave_times.py).  The shares are therefore unequal.  The strips (sorted heaviest first) are
+// dealt in ROUNDS: the waves of the generations taking part in round r get consecutive strips, in wave order on even rounds and
+// in reverse on odd ones.  Generation 0 takes part in every round; generation g takes part whenever that keeps its work (in
+// items: a strip's chunks + 2, judged by the round's first strip) nearest to p[g] / kDealDen of generation 0's.  The late rounds
+// hold the light strips, so the shares are met to within a few items.  p = kDealDen for every generation is the plain
+// boustrophedon deal (strip r W + wid / r W + W - 1 - wid), used whenever the grid is not the full one.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kDealDen = 64;
+constexpr int kMaxGen = 8;
+struct DealShares { uint32_t G; uint32_t p[kMaxGen]; };
+
+__host__ __device__ inline DealShares deal_shares(int mode, uint32_t blocks) {
+    const uint32_t fit[kMaxGen] = {SUCRE_DEAL_FIT}, closed[kMaxGen] = {SUCRE_DEAL_CLOSED};
+    DealShares sh;
+    const uint32_t G = (uint32_t)(mode ? kClosedWaves : kFitWaves);
+    bool weighted = blocks == 256u * G && G <= (uint32_t)kMaxGen;
+    for (uint32_t g = 0; weighted && g < G; ++g) weighted = (mode ? closed[g] : fit[g]) >= 1u && (mode ? closed[g] : fit[g]) <= kDealDen;
+    weighted = weighted && (mode ? closed[0] : fit[0]) == kDealDen;   // somebody takes part in every round
+    sh.G = weighted ? G : 1u;
+    for (int g = 0; g < kMaxGen; ++g) sh.p[g] = weighted && (uint32_t)g < G ? (mode ? closed[g] : fit[g]) : kDealDen;
+    return sh;
+}
+
+// Calls f(k, strip) for the wave's strips in its working order; returns how many there are.  levels(strip) = the strip's level
+// count (StripMeta.levels; device data: the deal is made where the plan is written).  W % G == 0 (deal_shares).
+template <class L, class F>
+__host__ __device__ inline uint32_t deal_walk(uint32_t wid, uint32_t W, uint32_t n_strips, const DealShares &sh, L &&levels, F &&f) {
+    const uint32_t Wg = W / sh.G, g = wid / Wg, j = wid - g * Wg;
+    uint32_t base = 0u, k = 0u;
+    uint32_t work[kMaxGen] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // per wave of the generation, in items
+    for (uint32_t r = 0u; base < n_strips; ++r) {
+        const uint32_t items = sh.G > 1u ? ((levels(base) + 3u) >> 2) + 2u : 0u;
+        uint32_t below = 0u, total = 0u;
+        bool mine = false;
+        for (uint32_t q = 0u; q < sh.G; ++q) {
+            // generation q > 0 sits the round out if taking part would put it further above its share than it is below now
+            if (q > 0u && (uint64_t)(2u * work[q] + items) * kDealDen > (uint64_t)2u * sh.p[q] * work[0]) continue;
+            work[q] += items;
+            ++total;
+            below += q < g ? 1u : 0u;
+            mine = mine || q == g;
+        }
+        const uint32_t n_r = total * Wg;
+        if (mine) {
+            const uint32_t rank = below * Wg + j, strip = base + ((r & 1u) ? n_r - 1u - rank : rank);
+            if (strip < n_strips) { f(k, strip); ++k; }
+        }
+        base += n_r;
+    }
+    return k;
+}
+
+// Rounds of a deal = strips of its busiest wave, at most (generation 0 takes part in every round).
+__host__ __device__ inline uint32_t deal_rounds(uint32_t W, uint32_t n_strips, const DealShares &sh) {
+    const uint32_t per_round = sh.G > 1u ? W / sh.G : W;
+    return (n_strips + per_round - 1u) / per_round;
+}
+
 // One entry of a wave's item stream (fit.hip, plan_kernel): what to copy into the LDS ring.  What the item IS follows
 // from its position: a wave's stream is, strip after strip, [J plane][full chunks, the unmasked ones first][short last
 // chunk][moments (J-parameter mode)], and StripEntry says how many of each the strip has.
@@ -156,10 +221,10 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_gpartials = take((size_t)kNumSums * L->n_groups * sizeof(double));
     L->off_partials = take(nt * kNumSums * sizeof(float));
     L->off_state = take((size_t)L->n_strips * kStateFloats * sizeof(float));
-    {   // a wave gets at most ceil(n_strips / waves) strips of at most ceil(n_views / 4) chunks + J plane + moments
+    {   // a wave gets at most one strip per round of the deal, each of at most ceil(n_views / 4) chunks + J plane + moments
         for (int m = 0; m < 2; ++m) {
             const size_t waves = (size_t)L->fit_blocks[m] * 4;
-            L->plan_kmax[m] = ((size_t)L->n_strips + waves - 1) / waves;
+            L->plan_kmax[m] = deal_rounds((uint32_t)waves, (uint32_t)L->n_strips, deal_shares(m, (uint32_t)L->fit_blocks[m]));
             L->plan_stride[m] = L->plan_kmax[m] * (((size_t)n_views + kGroupLv - 1) / kGroupLv + 2) + SUCRE_RING;   // + kAhead trailing items + a spare
             L->off_plan[m] = take(waves * L->plan_stride[m] * sizeof(PlanItem));
             L->off_plan_strips[m] = take(waves * L->plan_kmax[m] * sizeof(StripEntry));

@@ -605,6 +605,8 @@ def test_experiment_variants_compile(tmp_path):
         'texactdiv': '-DSUCRE_EXACT_DIV=1',
         'texactadam': '-DSUCRE_EXACT_J_ADAM=1',
         'twp1': '-DSUCRE_EXP_LIGHT_WATER_PASS1',
+        'twavetimes': '-DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_PRIO=3',
+        'tdeal': '-DSUCRE_DEAL_FIT=64,44,24,14,5 -DSUCRE_DEAL_CLOSED=64,48,32,20',
     }
     objects = {'texactdiv': 'match', 'twp1': 'light'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here
