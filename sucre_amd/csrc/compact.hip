@@ -480,6 +480,8 @@ __device__ __forceinline__ int nth_set_bit(uint32_t p, int n) {
     return pos + ((n >= (int)(p & 1u)) ? 1 : 0);
 }
 
+__device__ unsigned long long g_exp_scatter_clock[2];   // (experiment build) shader cycles / 100 MHz ticks, summed over the workgroups
+
 // kZ24: the instantiation that writes 24-bit range codes.  Which of the two forms a float32 store takes is decided on the
 // device (decide_store_format), so both instantiations are launched and the one whose form it is not returns at once (a few
 // microseconds per image; one kernel with both store paths in it held 100 registers instead of 92 and lost a wave per SIMD).
@@ -495,6 +497,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                                                       uint8_t *__restrict__ ext2_comp, const uint32_t *__restrict__ store_fmt) {
     static_assert(!kZ24 || (kFmt == 0 && kExt == 0), "24-bit range codes: float32 store without extension planes");
     if ((store_fmt[0] == (uint32_t)kStoreZ24) != kZ24) return;   // the other instantiation's store (kernel-uniform)
+    const unsigned long long exp_c0 = kExpWaveTimes ? clock64() : 0ull, exp_t0 = kExpWaveTimes ? wall_clock64() : 0ull;
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
     constexpr uint32_t kStageMask = (1u << kStageViews) - 1u;
     static_assert(kStageViews == 8 || kStageViews == 16, "a stage group is a byte or a half word of the 32-bit presence words");
@@ -616,7 +619,19 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
         clear_group(q);
     }
 #undef SUCRE_EACH_REG
+    if (kExpWaveTimes && t == 0) {   // experiment.h SUCRE_EXP_WAVE_TIMES: the shader clock the kernel ran at (tools/exp/scatter_clock.py)
+        atomicAdd(&g_exp_scatter_clock[0], clock64() - exp_c0);
+        atomicAdd(&g_exp_scatter_clock[1], wall_clock64() - exp_t0);
+    }
 }
+
+}  // namespace sucre
+SUCRE_EXP_EXPORT int sucre_exp_scatter_clock(unsigned long long *out) {   // exported by the experiment build only; reads and clears
+    const int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sucre::g_exp_scatter_clock), sizeof(sucre::g_exp_scatter_clock));
+    const unsigned long long zero[2] = {0ull, 0ull};
+    return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(sucre::g_exp_scatter_clock), zero, sizeof(zero));
+}
+namespace sucre {
 
 hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uint8_t *ext_dense, uint8_t *ext_comp,
                           int fmt, const uint8_t *ext2_dense, uint8_t *ext2_comp) {
