@@ -1,0 +1,41 @@
+// Host check of csrc/layout.h's deal (tests/test_host_logic.py compiles and runs it with g++): for equal and unequal shares,
+// full and partial grids, every strip goes to exactly one wave, a wave's strips come in increasing order, no wave gets more
+// strips than deal_rounds reserves, and equal shares are the plain boustrophedon deal.
+#define __host__
+#define __device__
+#include "layout.h"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+using namespace sucre;
+
+int main() {
+    int bad = 0, cases = 0;
+    for (int mode = 0; mode < 2; ++mode)
+        for (uint32_t blocks : {1u, 7u, 300u, 256u * (uint32_t)(mode ? kClosedWaves : kFitWaves)})
+            for (uint32_t n_strips : {1u, 4u, 5119u, 5120u, 32400u, 131072u}) {
+                const DealShares sh = deal_shares(mode, blocks);
+                const uint32_t W = blocks * 4;
+                std::vector<uint32_t> lev(n_strips);
+                for (uint32_t s = 0; s < n_strips; ++s) lev[s] = (uint32_t)(65.0 * std::pow(1.0 - (double)s / n_strips, 0.7));
+                std::vector<int> seen(n_strips, 0);
+                const uint32_t R = deal_rounds(W, n_strips, sh);
+                bool equal = true;
+                for (uint32_t g = 0; g < sh.G; ++g) equal = equal && sh.p[g] == kDealDen;
+                for (uint32_t wid = 0; wid < W; ++wid) {
+                    uint32_t last = 0, cnt = 0;
+                    const uint32_t K = deal_walk(wid, W, n_strips, sh, [&](uint32_t s) { if (s >= n_strips) ++bad; return s < n_strips ? lev[s] : 0u; },
+                                                 [&](uint32_t k, uint32_t s) {
+                                                     if (k != cnt || (cnt && s <= last) || s >= n_strips) ++bad;
+                                                     else ++seen[s];
+                                                     if (equal && s != k * W + ((k & 1u) ? W - 1u - wid : wid)) ++bad;
+                                                     last = s; ++cnt;
+                                                 });
+                    if (K != cnt || K > R) ++bad;
+                }
+                for (int v : seen) if (v != 1) ++bad;
+                ++cases;
+            }
+    std::printf("%d cases, %d violations\n", cases, bad);
+    return bad != 0;
+}

@@ -627,6 +627,23 @@ def test_experiment_variants_compile(tmp_path):
                 f.unlink()
 
 
+def test_the_deal_gives_every_strip_to_exactly_one_wave(tmp_path):
+    """csrc/layout.h deal_walk / deal_rounds on the host (tests/native/deal_check.cpp, g++): equal shares (the product) and the
+    unequal ones of the SUCRE_DEAL_FIT knob, full and partial grids, 1 .. 131072 strips."""
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('no g++ on this machine')
+    csrc = ROOT / 'sucre_amd' / 'csrc'
+    for name, flags in (('equal', []), ('unequal', ['-DSUCRE_DEAL_FIT=64,44,24,14,5', '-DSUCRE_DEAL_CLOSED=64,48,32,20'])):
+        exe = tmp_path / f'deal_{name}'
+        out = subprocess.run(['g++', '-std=c++17', '-O1', f'-I{csrc}', f'-I{ROOT / "include"}', *flags, str(ROOT / 'tests' / 'native' / 'deal_check.cpp'), '-o', str(exe)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        run = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert run.returncode == 0 and '0 violations' in run.stdout, (name, run.stdout, run.stderr)
+
+
 def test_persistent_kernels_fit_the_grids_they_are_launched_with():
     """The fit kernels deal their strips statically over a launch's waves and are launched with compile-time grids
     (csrc/layout.h: kFitGrid = 5, kClosedGrid = 4 workgroups per CU): a workgroup that is not resident from the start
