@@ -183,6 +183,33 @@ def generate_extensions(name='baseline_c1_extensions'):
     print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', flush=True)
 
 
+def generate_light_c2(name='baseline_c2_light', T=6, T_closed=3):
+    """The light model at BASELINE config-2 size (the bench's own image: 1920x1080, 64 neighbours + self, seed 0, 79 M observations):
+    the reference's own --light-model run (autograd through se3.exp and the Gaussian light cone, sucre.py:54-61) for its first T
+    iterations with J as a parameter and T_closed with --use-closed-form: traces, J[::4, ::4], NaN count, whole-image sums."""
+    W, H, nn, seed = CONFIGS['baseline_c2_1920x1080_n64'][:4]
+    scene = synth.make_scene(W, H, nn, seed=seed)
+    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names), stride=4)
+    out['input_digest_per_view'], out['input_digest'] = (np.array(x) for x in input_digests(scene))
+    out.update(derived_matrices(scene))
+    t0 = time.perf_counter()
+    per_view, md, target = rh.reference_matches(scene, min_cover=1e-6)
+    print(name, f'matching {time.perf_counter() - t0:.1f}s', flush=True)
+    out['n_matches'] = np.array([len(r['u1']) for r in per_view], np.int64)
+    out['kept'] = np.array([r['kept'] for r in per_view])
+    out['n_obs'] = np.int64(len(md))
+    for key, iters, closed in (('light', T, False), ('light_closed', T_closed, True)):
+        t0 = time.perf_counter()
+        fit = quiet(rh.reference_fit, scene, md, target, num_iter=iters, light_model=True, use_closed_form=closed, batch_size=5)
+        print(name, f'{key}, {iters} iterations {time.perf_counter() - t0:.1f}s', flush=True)
+        out[f'trace_{key}'] = fit['trace']
+        sm = j_summary(fit['J'])
+        out[f'J_{key}'] = np.ascontiguousarray(fit['J'][::4, ::4]); out[f'J_{key}_nan_count'] = np.int64(sm['nan_count'])
+        out[f'J_{key}_sum'], out[f'J_{key}_sqsum'] = sm['sum'], sm['sqsum']
+    np.savez_compressed(HERE / f'{name}.npz', **out)
+    print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', flush=True)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     want = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -191,3 +218,5 @@ if __name__ == '__main__':
             (add_derived if '--add-derived' in sys.argv else generate)(name, spec)
     if 'ext' in want:
         generate_extensions()
+    if 'lightc2' in want:
+        generate_light_c2()

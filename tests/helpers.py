@@ -167,6 +167,9 @@ def match_map_digest(match_map: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(match_map, dtype=np.int32).tobytes()).hexdigest()
 
 
+_SCENES = {}
+
+
 class Baseline:
     """A reference-made golden at a BASELINE size: OUTPUTS only; the inputs are regenerated here (on the CPU, like the
     generator did) and checked against the stored digests.  ``inputs_identical`` False means this machine's libm
@@ -178,7 +181,11 @@ class Baseline:
         self.name = name
         self.z = np.load(GOLDEN_DIR / f'{name}.npz')
         z = self.z
-        self.scene = synth.make_scene(int(z['width']), int(z['height']), int(z['n_neighbours']), seed=int(z['seed']))
+        skey = (int(z['width']), int(z['height']), int(z['n_neighbours']), int(z['seed']))
+        if skey not in _SCENES:   # several fixtures hold results on the same scene (config 2: short, in full, light model)
+            _SCENES.clear()       # ... one at a time: a config-2 scene is 0.7 GB
+            _SCENES[skey] = synth.make_scene(*skey[:3], seed=skey[3])
+        self.scene = _SCENES[skey]
         assert self.scene.names == [str(n) for n in z['names']] and self.scene.target == int(z['target'])
         # The float32 matrices the reference derived from K, R, t on ITS host (torch CPU: K.inverse(), -R.T @ t).  They are
         # handed to the oracle and to the engine, so the per-pixel arithmetic is compared under the reference's own

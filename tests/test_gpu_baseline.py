@@ -145,3 +145,28 @@ def test_config2_in_full_engine_vs_reference():
     helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2 in full, 1 iteration')
     helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, 'ENGINE, config 2 IN FULL, 200 iterations')
     helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} closed-form iterations')
+
+
+@pytest.mark.timeout(1500)
+def test_config2_light_model_engine_vs_reference():
+    """--light-model at BASELINE config-2 size against the reference itself (tests/golden/baseline_c2_light.npz: the bench's own
+    image, 79 M observations; the reference's autograd through se3.exp and the light cone for its first iterations, J as a
+    parameter and --use-closed-form): cost of iteration 0, the water trajectory, cam2light / sigma, J[::4, ::4] and the
+    whole-image sums.  The light parameters' gradients are sums of 79 M terms of both signs that the reference forms in
+    float32 batch by batch: its own batch-order noise on them is 1e-3, hence light_bar."""
+    from sucre_amd import engine
+    b = helpers.load_baseline('baseline_c2_light')
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views), light=True)
+    r.match(views[sc.target], views)
+    assert r.view_counts().cpu().numpy().tolist() == b['n_matches'].tolist() or not b.inputs_identical
+    for key, closed in (('light', False), ('light_closed', True)):
+        rt = b[f'trace_{key}']
+        r.fit_init(views[sc.target])
+        trace = r.fit(rt.shape[0], use_closed_form=closed).cpu().numpy()
+        torch.cuda.synchronize()
+        assert abs(trace[0, 0] / rt[0, 0] - 1) < 2e-6, (key, trace[0, 0], rt[0, 0])
+        # (the cost follows the light parameters: the ORACLE's is 7.4e-5 from the reference's after six iterations, 4.2e-6 in closed form)
+        helpers.check_baseline_fit(b, key, r.J().cpu().numpy(), trace, 1e-5 if closed else 2e-6, 2e-5, 2e-5 if closed else 2e-4,
+                                   f'ENGINE, config 2 light model, {rt.shape[0]} iterations', trace_key=f'trace_{key}', light_bar=3e-3)

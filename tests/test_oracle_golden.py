@@ -279,21 +279,6 @@ def test_baseline_config1_in_full_oracle_vs_reference():
     helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 1, {T_closed} iterations')
 
 
-def test_baseline_config2_short_oracle_vs_reference():
-    """BASELINE config 2, the bench's own image (1920x1080, 64 neighbours + self, seed 0; 79 M observations): the
-    reference's match sets of all 65 views bit for bit, and its first Adam iterations in both J modes -- the regime
-    where the 1/(3 n_obs) scaling puts per-pixel J gradients at the order of Adam's eps (SURVEY.md section 7)."""
-    b = helpers.load_baseline(helpers.BASELINE_C2)
-    sc = b.scene
-    samples, J0, T_param, T_closed = oracle_baseline_run(b)
-    J1, _, _ = oracle.fit(sc.height, sc.width, samples, J0, num_iter=1)
-    helpers.check_baseline_fit(b, 'param_1', J1, None, 1e-7, 0, 0, 'oracle, config 2, 1 iteration')
-    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
-    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, config 2, {T_param} iterations')
-    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
-    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 2, {T_closed} iterations')
-
-
 def test_baseline_config1_extensions_oracle_vs_reference():
     """The two extensions of the path at config-1 size (tests/golden/baseline_c1_extensions.npz): the reference's own
     --light-model run (100 iterations, autograd) and two reference modules with tied water parameters (40 iterations)."""
@@ -315,6 +300,21 @@ def test_baseline_config1_extensions_oracle_vs_reference():
         helpers.check_baseline_fit(b, f'shared{i}', o.J, None, 1e-6, 0, 0, f'oracle, config 1 shared water, image {i}')
 
 
+def test_baseline_config2_short_oracle_vs_reference():
+    """BASELINE config 2, the bench's own image (1920x1080, 64 neighbours + self, seed 0; 79 M observations): the
+    reference's match sets of all 65 views bit for bit, and its first Adam iterations in both J modes -- the regime
+    where the 1/(3 n_obs) scaling puts per-pixel J gradients at the order of Adam's eps (SURVEY.md section 7)."""
+    b = helpers.load_baseline(helpers.BASELINE_C2)
+    sc = b.scene
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    J1, _, _ = oracle.fit(sc.height, sc.width, samples, J0, num_iter=1)
+    helpers.check_baseline_fit(b, 'param_1', J1, None, 1e-7, 0, 0, 'oracle, config 2, 1 iteration')
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, config 2, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 2, {T_closed} iterations')
+
+
 def test_baseline_config2_in_full_oracle_trajectory_prefix_vs_reference():
     """The reference's whole 200-iteration run at config 2 (tests/golden/baseline_c2full_1920x1080_n64.npz) is compared with
     the ENGINE in full on the GPU tier (tests/test_gpu_baseline.py); here, in the time the CPU tier has, the oracle follows
@@ -330,3 +330,25 @@ def test_baseline_config2_in_full_oracle_trajectory_prefix_vs_reference():
     rtc = b['trace_closed'][:15]
     # (J after 15 closed-form iterations is the final update_J of those parameters: not what the fixture stores; the trajectory is)
     assert np.abs(trc[:, 1:] - rtc[:, 1:]).max() < 2e-5 and np.abs(trc[:, 0] / rtc[:, 0] - 1).max() < 1e-5
+
+
+def test_baseline_config2_light_model_oracle_trajectory_prefix_vs_reference():
+    """--light-model at BASELINE config-2 size (tests/golden/baseline_c2_light.npz: 79 M observations, the reference's autograd
+    run): the oracle's analytic gradient over the first two iterations with J as a parameter and the first closed-form one --
+    cost of iteration 0 to 1e-6, water parameters to 2e-6, cam2light / sigma to 1e-3 (their gradients: sums of 79 M terms of both
+    signs, float32 batch by batch in the reference).  The whole runs (6 + 3 iterations: water 3.4e-7, light parameters 1.1e-4,
+    RMS(J) 1.4-4.7e-7) take 90 s of CPU and are compared in the GPU tier, engine against reference
+    (tests/test_gpu_baseline.py)."""
+    b = helpers.load_baseline('baseline_c2_light')
+    sc = b.scene
+    per_view, samples = helpers.oracle_scene_samples(sc)
+    assert [len(m) for _, _, m in per_view] == b['n_matches'].tolist() or not b.inputs_identical
+    tgt = sc.views[sc.target]
+    J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+    loose = 1.0 if b.inputs_identical else 100.0
+    for key, closed, T in (('light', False, 2), ('light_closed', True, 1)):
+        rt = b[f'trace_{key}'][:T]
+        _, _, trace = oracle.fit_light(sc.height, sc.width, samples, None if closed else J0, num_iter=T, use_closed_form=closed)
+        dwater, dlight, dcost = np.abs(trace[:, 1:10] - rt[:, 1:10]).max(), np.abs(trace[:, 10:] - rt[:, 10:]).max(), np.abs(trace[:, 0] / rt[:, 0] - 1).max()
+        print(f'oracle, config 2 {key}, {T} iteration(s): cost0 {abs(trace[0, 0] / rt[0, 0] - 1):.1e} water {dwater:.1e} light {dlight:.1e} cost {dcost:.1e}')
+        assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-6 * loose and dwater < 2e-6 * loose and dlight < 1e-3 * loose and dcost < 1e-4 * loose
