@@ -210,6 +210,32 @@ def generate_light_c2(name='baseline_c2_light', T=6, T_closed=3):
     print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', flush=True)
 
 
+def generate_shared_c2(name='baseline_c2_shared', T=5):
+    """Shared water parameters at BASELINE config-2 size (what a rank of config 4 does with its images): TWO reference modules --
+    the bench's own image and its left neighbour in the same 65-view scene, 158 M observations together -- with tied B, beta, gamma
+    (ref_harness.reference_shared_water) for T iterations: the trace, and per image J[::4, ::4], NaN count, whole-image sums."""
+    import copy
+    W, H, nn, seed = CONFIGS['baseline_c2_1920x1080_n64'][:4]
+    scene = synth.make_scene(W, H, nn, seed=seed)
+    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names), stride=4)
+    out['input_digest_per_view'], out['input_digest'] = (np.array(x) for x in input_digests(scene))
+    out.update(derived_matrices(scene))
+    other = copy.copy(scene)
+    other.target = scene.target - 1
+    t0 = time.perf_counter()
+    shared = quiet(rh.reference_shared_water, [scene, other], num_iter=T)
+    print(name, f'shared water, two images, {T} iterations {time.perf_counter() - t0:.1f}s', flush=True)
+    out['shared_targets'] = np.array([scene.target, other.target])
+    out['shared_trace'] = shared['trace']
+    out['shared_n_total'] = np.int64(shared['n_total'])
+    for i, J in enumerate(shared['J']):
+        sm = j_summary(J)
+        out[f'J_shared{i}'] = np.ascontiguousarray(J[::4, ::4]); out[f'J_shared{i}_nan_count'] = np.int64(sm['nan_count'])
+        out[f'J_shared{i}_sum'], out[f'J_shared{i}_sqsum'] = sm['sum'], sm['sqsum']
+    np.savez_compressed(HERE / f'{name}.npz', **out)
+    print(name, 'written', (HERE / f'{name}.npz').stat().st_size, 'bytes', flush=True)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     want = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -220,3 +246,5 @@ if __name__ == '__main__':
         generate_extensions()
     if 'lightc2' in want:
         generate_light_c2()
+    if 'sharedc2' in want:
+        generate_shared_c2()

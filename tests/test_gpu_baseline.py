@@ -170,3 +170,49 @@ def test_config2_light_model_engine_vs_reference():
         # (the cost follows the light parameters: the ORACLE's is 7.4e-5 from the reference's after six iterations, 4.2e-6 in closed form)
         helpers.check_baseline_fit(b, key, r.J().cpu().numpy(), trace, 1e-5 if closed else 2e-6, 2e-5, 2e-5 if closed else 2e-4,
                                    f'ENGINE, config 2 light model, {rt.shape[0]} iterations', trace_key=f'trace_{key}', light_bar=3e-3)
+
+
+@pytest.mark.timeout(1500)
+def test_config2_shared_water_engine_vs_reference():
+    """Shared water parameters at BASELINE config-2 size -- a rank's share of config 4 in small: two 1080p images of the 65-view
+    scene (158 M observations) stepping B, beta, gamma together -- against two reference modules with tied parameters
+    (tests/golden/baseline_c2_shared.npz), through the single-launch group kernel and through the split grad / sum / step path
+    that N ranks run."""
+    from sucre_amd import dist as sdist
+    from sucre_amd import engine
+    b = helpers.load_baseline('baseline_c2_shared')
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    targets = [int(t) for t in b['shared_targets']]
+    rt = b['shared_trace']
+    for path in ('group', 'split'):
+        rs = []
+        for t in targets:
+            x = engine.Restoration(sc.height, sc.width, len(views))
+            x.match(views[t], views)
+            x.fit_init(views[t])
+            rs.append(x)
+        assert sum(x.n_obs() for x in rs) == int(b['shared_n_total']) or not b.inputs_identical
+        trace = torch.zeros((rt.shape[0], 10), dtype=torch.float64, device='cuda')
+        if path == 'group':
+            sdist.fit_shared_water(engine.HipWaterGroup(rs, trace=trace), rt.shape[0])
+        else:   # what two ranks do, in one process: every image its own backend, the sums added by hand
+            bes = [engine.HipWaterBackend(x, trace=trace if i == 0 else None) for i, x in enumerate(rs)]
+            total = sum(be.n_obs() for be in bes)
+            for be in bes:
+                be.set_n_obs_total(total)
+            for it in range(1, rt.shape[0] + 1):
+                sums = [be.grad(it).clone() for be in bes]
+                tot = sums[0] + sums[1]
+                for be in bes:
+                    be._sums.copy_(tot)
+                    be.step(it)
+        torch.cuda.synchronize()
+        tr = trace.cpu().numpy()
+        dpar, dcost = np.abs(tr[:, 1:] - rt[:, 1:]).max(), np.abs(tr[:, 0] / rt[:, 0] - 1).max()
+        print(f'ENGINE, config 2 shared water ({path}), {rt.shape[0]} iterations: max|dparams|={dpar:.2e} max rel dcost={dcost:.2e}')
+        assert dpar < 2e-6 and dcost < 2e-5
+        for i, x in enumerate(rs):
+            helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 2 shared water ({path}), image {i}')
+        del rs
+        torch.cuda.empty_cache()
