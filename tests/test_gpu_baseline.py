@@ -64,17 +64,6 @@ def test_config1_in_full_engine_vs_reference():
     helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, 'ENGINE, config 1 in full, 200 iterations')
 
 
-@pytest.mark.timeout(1500)
-def test_config2_short_engine_vs_reference():
-    b = helpers.load_baseline(helpers.BASELINE_C2)
-    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
-    e = engine_run(b, T_param, T_closed)
-    assert e['n_obs'] > 70_000_000
-    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2, 1 iteration')
-    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, config 2, {T_param} iterations')
-    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} iterations')
-
-
 @pytest.mark.timeout(900)
 def test_config1_extensions_engine_vs_reference():
     """The extensions at config-1 size against the reference itself (tests/golden/baseline_c1_extensions.npz): its own
@@ -130,6 +119,17 @@ def test_config1_extensions_engine_vs_reference():
         for i, x in enumerate(rs):
             helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 1 shared water ({path}), image {i}')
         del rs
+
+
+@pytest.mark.timeout(1500)
+def test_config2_short_engine_vs_reference():
+    b = helpers.load_baseline(helpers.BASELINE_C2)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    e = engine_run(b, T_param, T_closed)
+    assert e['n_obs'] > 70_000_000
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, config 2, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, config 2, {T_param} iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, config 2, {T_closed} iterations')
 
 
 @pytest.mark.timeout(1500)
