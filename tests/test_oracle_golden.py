@@ -318,17 +318,17 @@ def test_baseline_config2_short_oracle_vs_reference():
 def test_baseline_config2_in_full_oracle_trajectory_prefix_vs_reference():
     """The reference's whole 200-iteration run at config 2 (tests/golden/baseline_c2full_1920x1080_n64.npz) is compared with
     the ENGINE in full on the GPU tier (tests/test_gpu_baseline.py); here, in the time the CPU tier has, the oracle follows
-    the first 40 rows of its cost / B / beta / gamma trajectory and the first 15 of the closed-form one."""
+    the first 25 rows of its cost / B / beta / gamma trajectory and the first 8 of the closed-form one."""
     b = helpers.load_baseline(helpers.BASELINE_C2FULL)
     sc = b.scene
     samples, J0, T_param, T_closed = oracle_baseline_run(b)
     assert T_param == 200
-    _, _, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=40)
-    rt = b['trace_param'][:40]
+    _, _, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=25)
+    rt = b['trace_param'][:25]
     assert np.abs(trace[:, 1:] - rt[:, 1:]).max() < 2e-6 and np.abs(trace[:, 0] / rt[:, 0] - 1).max() < 2e-5
-    _, _, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=15, use_closed_form=True)
-    rtc = b['trace_closed'][:15]
-    # (J after 15 closed-form iterations is the final update_J of those parameters: not what the fixture stores; the trajectory is)
+    _, _, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=8, use_closed_form=True)
+    rtc = b['trace_closed'][:8]
+    # (J after 8 closed-form iterations is the final update_J of those parameters: not what the fixture stores; the trajectory is)
     assert np.abs(trc[:, 1:] - rtc[:, 1:]).max() < 2e-5 and np.abs(trc[:, 0] / rtc[:, 0] - 1).max() < 1e-5
 
 
