@@ -44,6 +44,9 @@ CONFIGS = {
     'baseline_c2_1920x1080_n64': (1920, 1080, 64, 0, 10, 5, 4),
     # the same image, the reference's WHOLE J-parameter run (200 iterations: an hour of CPU) and 60 closed-form iterations
     'baseline_c2full_1920x1080_n64': (1920, 1080, 64, 0, 200, 60, 4),
+    # BASELINE config 5's VIEW COUNT (256 neighbours + self: five 64-bit mask words per pixel, strips of up to 257 levels) on a
+    # small image, short runs: the many-view regime against the reference itself
+    'baseline_c5views_480x360_n256': (480, 360, 256, 0, 8, 4, 2),
 }
 
 

@@ -279,6 +279,22 @@ def test_baseline_config1_in_full_oracle_vs_reference():
     helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 1, {T_closed} iterations')
 
 
+def test_baseline_config5_view_count_oracle_vs_reference():
+    """BASELINE config 5's view count -- 256 neighbours + self, up to 257 observations of a pixel -- on a 480x360 image
+    (tests/golden/baseline_c5views_480x360_n256.npz, 14.9 M observations): the reference's match sets of all 257 views bit for
+    bit and its first 8 (J parameter) / 4 (closed form) iterations."""
+    b = helpers.load_baseline(helpers.BASELINE_C5VIEWS)
+    sc = b.scene
+    assert len(sc.views) == 257
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    J1, _, _ = oracle.fit(sc.height, sc.width, samples, J0, num_iter=1)
+    helpers.check_baseline_fit(b, 'param_1', J1, None, 1e-7, 0, 0, 'oracle, 257 views, 1 iteration')
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, 257 views, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, 257 views, {T_closed} iterations')
+
+
 def test_baseline_config1_extensions_oracle_vs_reference():
     """The two extensions of the path at config-1 size (tests/golden/baseline_c1_extensions.npz): the reference's own
     --light-model run (100 iterations, autograd) and two reference modules with tied water parameters (40 iterations)."""
