@@ -47,6 +47,8 @@ CONFIGS = {
     # BASELINE config 5's VIEW COUNT (256 neighbours + self: five 64-bit mask words per pixel, strips of up to 257 levels) on a
     # small image, short runs: the many-view regime against the reference itself
     'baseline_c5views_480x360_n256': (480, 360, 256, 0, 8, 4, 2),
+    # an image whose sides are no multiples of the engine's 16 x 16 tiles (ragged last tile column and row), in full
+    'baseline_odd_333x207_n8': (333, 207, 8, 3, 60, 30, 1),
 }
 
 

@@ -142,6 +142,7 @@ BASELINE_C1 = 'baseline_c1_640x480_n4'
 BASELINE_C2 = 'baseline_c2_1920x1080_n64'
 BASELINE_C2FULL = 'baseline_c2full_1920x1080_n64'
 BASELINE_C5VIEWS = 'baseline_c5views_480x360_n256'
+BASELINE_ODD = 'baseline_odd_333x207_n8'
 
 
 def scene_digests(scene):

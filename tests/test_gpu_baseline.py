@@ -65,6 +65,18 @@ def test_config1_in_full_engine_vs_reference():
 
 
 @pytest.mark.timeout(900)
+def test_odd_image_size_engine_vs_reference():
+    """333x207 (ragged last tile column and row), 8 neighbours + self, against the reference itself: match maps bit for bit, the
+    whole J after its 60 J-parameter and 30 closed-form iterations."""
+    b = helpers.load_baseline(helpers.BASELINE_ODD)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    e = engine_run(b, T_param, T_closed)
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, 333x207, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, 333x207, {T_param} iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, 333x207, {T_closed} iterations')
+
+
+@pytest.mark.timeout(900)
 def test_config5_view_count_engine_vs_reference():
     """BASELINE config 5's view count (256 neighbours + self: five mask words per pixel, strips of up to 257 levels = 65 chunks)
     on a 480x360 image against the reference itself: all 257 match maps bit for bit, 8 J-parameter and 4 closed-form iterations."""

@@ -279,6 +279,18 @@ def test_baseline_config1_in_full_oracle_vs_reference():
     helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 1, {T_closed} iterations')
 
 
+def test_baseline_odd_image_size_oracle_vs_reference():
+    """An image whose sides are no multiples of 16 (333x207, 8 neighbours + self; tests/golden/baseline_odd_333x207_n8.npz):
+    the reference's match sets bit for bit, its 60 J-parameter and 30 closed-form iterations, the whole J."""
+    b = helpers.load_baseline(helpers.BASELINE_ODD)
+    sc = b.scene
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, 333x207, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, 333x207, {T_closed} iterations')
+
+
 def test_baseline_config5_view_count_oracle_vs_reference():
     """BASELINE config 5's view count -- 256 neighbours + self, up to 257 observations of a pixel -- on a 480x360 image
     (tests/golden/baseline_c5views_480x360_n256.npz, 14.9 M observations): the reference's match sets of all 257 views bit for
