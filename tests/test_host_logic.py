@@ -500,6 +500,26 @@ def test_area_resize_without_opencv():
     assert abs(loader._resize_rgb(ramp, 120, 72)[10, d, 0] - (4 + 0.296875)) < 1e-5
 
 
+def test_cubic_and_area_resize_against_torch():
+    """A second, independent implementation of the two published kernels (OpenCV itself is not in this image): torch's
+    bicubic interpolation uses the same A = -0.75 cubic, half-pixel centres and border replication as cv2.INTER_CUBIC (weights
+    in float64 there, float32 in OpenCV and in the restatement: 1e-6), and its 'area' mode is INTER_AREA for integer factors."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    img = rng.random((17, 23, 3))
+    t = torch.tensor(img).permute(2, 0, 1)[None]
+    for (w, h) in ((46, 34), (37, 41), (24, 18), (92, 51)):
+        ours = loader._resize_cubic(img, w, h)
+        ref = F.interpolate(t, size=(h, w), mode='bicubic', align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(ours - ref).max() < 2e-6, (w, h, np.abs(ours - ref).max())
+    big = rng.random((36, 60, 3))
+    tb = torch.tensor(big).permute(2, 0, 1)[None]
+    for (w, h) in ((30, 18), (20, 12), (15, 9)):
+        ours = loader._resize_area(big, w, h)
+        ref = F.interpolate(tb, size=(h, w), mode='area')[0].permute(1, 2, 0).numpy()
+        assert np.abs(ours - ref).max() < 1e-7, (w, h)   # (the block mean's 1 / (fx fy) is a float32 constant in OpenCV: 3e-8 at factor 3)
+
+
 def test_png_writer_keeps_every_pixel(tmp_path, monkeypatch):
     """sucre._save_png (the CLI's output files, sucre.py:116-121): lossless for RGB through the zlib writer, PIL for
     other modes and on request; a decoder must give back the very pixels."""
