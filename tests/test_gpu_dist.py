@@ -67,6 +67,29 @@ def test_bench_launches_its_own_ranks(extra):
 
 
 @pytest.mark.timeout(600)
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- with two ranks on this box's one GPU (gloo instead of RCCL, which refuses
+    two ranks on one device): rank 0 prints the one JSON line, and it saw both ranks."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['SUCRE_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--width', '320',
+           '--height', '240', '--neighbours', '8', '--num-iter', '6', '--no-cpu-baseline', '--solo-images', '1']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=str(ROOT))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['warmup'] == 1 and rec['config']['ranks_seen'] == 2
+    assert rec['value'] > 0 and rec['scaling'] == 'weak' and rec['config']['dist_backend'] == 'gloo'
+
+
+@pytest.mark.timeout(600)
 def test_bench_json_line_keeps_the_contract():
     """`python bench.py` at N = 1: one JSON line with every key of the driver's contract, the roofline block and (on a
     tiny sample) the CPU baseline leg."""
