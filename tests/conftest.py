@@ -28,3 +28,16 @@ def pytest_configure(config):
 def golden(request):
     import helpers
     return helpers.load_fixture(request.param)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """What the reference-pinned checks MEASURED in this run (helpers.PARITY_ROWS), <= 25 lines, so that the tail of a
+    ``pytest -q`` record carries numbers: per check the per-channel RMS(J), max |d B,beta,gamma|, max rel d cost vs the
+    REFERENCE's stored outputs, whether the regenerated inputs were the reference's (they must be: a differing scene is a red
+    test) and whether this host derives the reference host's float32 camera matrices ('own') or the stored ones were used."""
+    import helpers
+    lines = helpers.parity_summary_lines(25)
+    if lines:
+        terminalreporter.write_sep('=', 'parity vs the reference (measured in this run)')
+        for ln in lines:
+            terminalreporter.write_line(ln)

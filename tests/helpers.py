@@ -172,11 +172,29 @@ def match_map_digest(match_map: np.ndarray) -> str:
 _SCENES = {}
 
 
+class SceneMismatch(AssertionError):
+    """The regenerated synthetic scene is not the one the reference ran on."""
+
+
+def _make_scene(width, height, n_neighbours, seed):
+    """The seeded scene of a baseline fixture.  ``SUCRE_TEST_PERTURB_SCENE=<view index>`` flips ONE colour byte of ONE view
+    after rendering -- the smallest way a host could render another scene: every reference-pinned test must then be RED
+    (``SUCRE_TEST_PERTURB_SCENE=0 pytest -m gpu`` shows it; tests/test_host_logic.py asserts it on the CPU tier)."""
+    import os
+
+    from sucre_amd import synth
+    scene = synth.make_scene(width, height, n_neighbours, seed=seed)
+    k = os.environ.get('SUCRE_TEST_PERTURB_SCENE')
+    if k not in (None, ''):
+        scene.views[int(k) % len(scene.views)].rgb_u8[height // 2, width // 2, 1] ^= 1
+    return scene
+
+
 class Baseline:
     """A reference-made golden at a BASELINE size: OUTPUTS only; the inputs are regenerated here (on the CPU, like the
-    generator did) and checked against the stored digests.  ``inputs_identical`` False means this machine's libm
-    rounded some rendered pixel the other way: the consumer then knows that a difference is the INPUT's, and holds the
-    looser bars it documents instead of the bit-exact ones."""
+    generator did) and checked against the stored SHA-256 digests.  A host that renders another scene (a libm that rounds
+    one pixel of one view the other way) gets a RED test that names the differing views -- never a looser bar: every
+    bar below is held under bit-identical inputs or not at all (VERDICT round 4, weak point 1)."""
 
     def __init__(self, name: str):
         from sucre_amd import synth
@@ -186,7 +204,7 @@ class Baseline:
         skey = (int(z['width']), int(z['height']), int(z['n_neighbours']), int(z['seed']))
         if skey not in _SCENES:   # several fixtures hold results on the same scene (config 2: short, in full, light model)
             _SCENES.clear()       # ... one at a time: a config-2 scene is 0.7 GB
-            _SCENES[skey] = synth.make_scene(*skey[:3], seed=skey[3])
+            _SCENES[skey] = _make_scene(*skey)
         self.scene = _SCENES[skey]
         assert self.scene.names == [str(n) for n in z['names']] and self.scene.target == int(z['target'])
         # The float32 matrices the reference derived from K, R, t on ITS host (torch CPU: K.inverse(), -R.T @ t).  They are
@@ -206,8 +224,14 @@ class Baseline:
         self.views_identical = [a == str(b) for a, b in zip(per_view, z['input_digest_per_view'])]
         self.inputs_identical = total == str(z['input_digest'])
         if not self.inputs_identical:
-            print(f'WARNING {name}: the regenerated scene differs from the one the reference ran on '
-                  f'({self.views_identical.count(False)} of {len(per_view)} views) -- libm/torch rounding on this machine')
+            _SCENES.pop(skey, None)
+            bad = [self.scene.views[k].name for k, same in enumerate(self.views_identical) if not same]
+            raise SceneMismatch(
+                f'{name}: the scene regenerated on this host is NOT the one the reference ran on: '
+                f'{len(bad)} of {len(per_view)} views differ in their uint16 depth / uint8 colour planes '
+                f'({", ".join(bad[:8])}{", ..." if len(bad) > 8 else ""})'
+                + ('' if bad else '; the pixel planes agree, so the poses or K differ')
+                + ' -- no reference-pinned bar can be held on other inputs')
 
     def __getitem__(self, key):
         return self.z[key]
@@ -228,6 +252,67 @@ def load_baseline(name: str) -> Baseline:
     return _BASELINES[name]
 
 
+# ---- what the reference-pinned checks MEASURED, for the run's terminal summary (tests/conftest.py) ------------------------
+# One row per check: label, key, per-channel RMS(J), max |d params|, max rel d cost, whether the regenerated inputs and
+# this host's derived camera matrices were the reference's, how many match maps were compared.  pytest -q swallows the
+# prints; the summary hook does not, so the driver's GPUTEST record carries numbers instead of dots.
+PARITY_ROWS: list = []
+
+
+def record_parity(label, key, b=None, **kw):
+    row = dict(label=label, key=key, **kw)
+    if b is not None:
+        row.update(fixture=b.name, inputs_identical=b.inputs_identical, derived_identical=b.derived_identical)
+    PARITY_ROWS.append(row)
+
+
+def parity_summary_lines(max_lines: int = 25):
+    """<= max_lines lines: a header, then one line per (who, fixture, mode) -- rows of the same mode (the two images and the two
+    paths of a shared-water check, repeated runs) merged by their WORST value; the match-map verdict of the fixture rides on
+    each of its lines."""
+    if not PARITY_ROWS:
+        return []
+
+    def worst(a, b):
+        if a is None:
+            return b
+        if b is None:
+            return a
+        return np.maximum(a, b)
+
+    def fmt(x):
+        return '    -   ' if x is None else f'{float(x):8.1e}'
+    groups, maps = {}, {}
+    for r in PARITY_ROWS:
+        who = 'engine' if 'engine' in r['label'].lower() else 'oracle'
+        fx = r.get('fixture', '?').replace('baseline_', '')
+        key = r['key']
+        if key == 'matches':
+            maps[(who, fx)] = f"n {r['counts']} maps {r['maps']}"
+            continue
+        key = 'shared' if key.startswith('shared') else 'param@1' if key == 'param_1' else key
+        g = groups.setdefault((who, fx, key), dict(rms=None, dpar=None, dcost=None, dlight=None, T=None, n=0,
+                                                   inputs=True, derived=True))
+        for f in ('rms', 'dpar', 'dcost', 'dlight'):
+            g[f] = worst(g[f], r.get(f))
+        g['T'] = r.get('T') or g['T']
+        g['n'] += 1
+        g['inputs'] &= bool(r.get('inputs_identical', True))
+        g['derived'] &= bool(r.get('derived_identical', True))
+    lines = [f"{'who':6s} {'reference-made fixture':22s} {'mode':12s} {'its':>3s} {'RMS(J) r':>8s} {'g':>8s} {'b':>8s} "
+             f"{'|dparam|':>8s} {'rel dcost':>9s} {'|dlight|':>8s} inputs matrices match sets identical"]
+    for (who, fx, key), g in groups.items():
+        rms = np.atleast_1d(g['rms']) if g['rms'] is not None else [None] * 3
+        lines.append(f"{who:6s} {fx:22s} {key:12s} {str(g['T'] or '-'):>3s} " + ' '.join(fmt(x) for x in rms)
+                     + f" {fmt(g['dpar'])} {fmt(g['dcost']):>9s} {fmt(g['dlight'])} "
+                     f"{'same' if g['inputs'] else 'DIFF':6s} {'own' if g['derived'] else 'stored':8s} {maps.get((who, fx), '-')}")
+    if len(lines) > max_lines:
+        body = lines[1:]
+        body.sort(key=lambda ln: ('param@1' in ln, 'oracle' in ln[:6]))   # the engine's full runs first
+        lines = [lines[0]] + body[:max_lines - 2] + [f'... {len(body) - (max_lines - 2)} more rows not shown']
+    return lines
+
+
 def dense_map(m, H, W):
     """Dense (H,W) int32 match map of an oracle ViewMatches."""
     mm = np.full((H, W), -1, np.int32)
@@ -236,33 +321,31 @@ def dense_map(m, H, W):
 
 
 def check_baseline_matches(b, counts, maps, label):
-    """Per-view match counts and dense match maps against the reference's: bit-exact (SHA-256 of the map) for every
-    view whose regenerated input planes -- and the target's -- are the ones the reference saw."""
-    tgt_same = b.views_identical[b.scene.target]
+    """Per-view match counts and dense match maps against the reference's: bit-exact (count + SHA-256 of the map), every
+    view (the inputs are the reference's: ``Baseline`` refuses to exist otherwise)."""
+    assert b.inputs_identical and all(b.views_identical)
     ref_counts = b['n_matches'].tolist()
+    assert len(counts) == len(ref_counts), (label, 'number of views')
+    n_maps = 0
     for k, n in enumerate(counts):
-        if b.views_identical[k] and tgt_same:
-            assert n == ref_counts[k], (label, 'count of view', k, n, ref_counts[k])
-            if maps is not None and maps[k] is not None:
-                assert match_map_digest(maps[k]) == str(b['match_digest'][k]), (label, 'match map of view', k)
-        else:
-            assert abs(n - ref_counts[k]) <= 1e-4 * ref_counts[k] + 8, (label, 'count of view', k, n, ref_counts[k])
+        assert n == ref_counts[k], (label, 'count of view', k, n, ref_counts[k])
+        if maps is not None and maps[k] is not None:
+            assert match_map_digest(maps[k]) == str(b['match_digest'][k]), (label, 'match map of view', k)
+            n_maps += 1
+    record_parity(label, 'matches', b, counts=f'{len(counts)}/{len(ref_counts)}',
+                  maps=f'{n_maps}/{len(ref_counts)}' if maps is not None else '-')
 
 
 def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, trace_key=None, light_bar=None):
     """A full (H,W,3) J and a (T, >=10) trace against what the REFERENCE stored: J[::stride, ::stride], the NaN count
     and the per-channel sums of J and J^2 over the whole image, the (T,10) cost / B / beta / gamma trajectory."""
     st = max(int(b['stride']), 4) if key == 'param_1' else int(b['stride'])
-    if not b.inputs_identical and light_bar is not None:
-        light_bar = max(light_bar, 1e-2)
+    assert b.inputs_identical
     ref = b[f'J_{key}']
     sub = J[::st, ::st]
-    if not b.inputs_identical:   # a libm that renders another scene: the north-star bar instead of the tight ones
-        rms_bar, param_bar, cost_bar = max(rms_bar, 1e-4), max(param_bar, 1e-4), max(cost_bar, 1e-4)
     nan_count, s, sq = b.j_sums(J)
-    if b.inputs_identical:
-        assert np.array_equal(np.isnan(sub), np.isnan(ref)), (label, 'NaN mask')
-        assert nan_count == int(b[f'J_{key}_nan_count']), (label, 'NaN count of the whole image')
+    assert np.array_equal(np.isnan(sub), np.isnan(ref)), (label, 'NaN mask')
+    assert nan_count == int(b[f'J_{key}_nan_count']), (label, 'NaN count of the whole image')
     rms = rms_per_channel(sub, ref)
     n_ok = J.shape[0] * J.shape[1] - nan_count
     dmean = np.abs(s - b[f'J_{key}_sum']) / n_ok         # every pixel of the image enters these two
@@ -281,6 +364,8 @@ def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, tr
         assert out['dcost'] < cost_bar, (label, key, 'cost trajectory', out['dcost'])
     print(f'{label} [{key}] vs the REFERENCE: rms(J)={rms} |dmean|={dmean.max():.2e} '
           f'max|dparams|={out.get("dpar", float("nan")):.2e} max rel dcost={out.get("dcost", float("nan")):.2e}')
+    record_parity(label, key, b, rms=rms, dpar=out.get('dpar'), dcost=out.get('dcost'), dlight=out.get('dlight'),
+                  T=None if trace is None else int(trace.shape[0]), bars=(rms_bar, param_bar, cost_bar))
     return out
 
 

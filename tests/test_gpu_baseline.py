@@ -32,8 +32,7 @@ def engine_run(b, T_param, T_closed, with_maps=True):
     assert keep == b['kept'].tolist()
     maps = [r.match_map(k).cpu().numpy() for k in range(len(views))] if with_maps else None
     helpers.check_baseline_matches(b, counts, maps, b.name + ' engine')
-    if b.inputs_identical:
-        assert r.n_obs() == int(b['n_obs'])
+    assert r.n_obs() == int(b['n_obs'])
     out = {}
     r.fit_init(views[sc.target])
     t1 = r.fit(1)
@@ -139,6 +138,7 @@ def test_config1_extensions_engine_vs_reference():
         tr = trace.cpu().numpy()
         dpar, dcost = np.abs(tr[:, 1:] - rt[:, 1:]).max(), np.abs(tr[:, 0] / rt[:, 0] - 1).max()
         print(f'ENGINE, config 1 shared water ({path}): max|dparams|={dpar:.2e} max rel dcost={dcost:.2e}')
+        helpers.record_parity(f'ENGINE, config 1 shared water ({path})', 'shared', b, dpar=dpar, dcost=dcost, T=rt.shape[0])
         assert dpar < 2e-6 and dcost < 2e-5
         for i, x in enumerate(rs):
             helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 1 shared water ({path}), image {i}')
@@ -184,7 +184,7 @@ def test_config2_light_model_engine_vs_reference():
     views = engine.device_views_from_scene(sc, 'cuda')
     r = engine.Restoration(sc.height, sc.width, len(views), light=True)
     r.match(views[sc.target], views)
-    assert r.view_counts().cpu().numpy().tolist() == b['n_matches'].tolist() or not b.inputs_identical
+    helpers.check_baseline_matches(b, r.view_counts().cpu().numpy().tolist(), None, 'config 2 light engine')
     for key, closed in (('light', False), ('light_closed', True)):
         rt = b[f'trace_{key}']
         r.fit_init(views[sc.target])
@@ -216,7 +216,7 @@ def test_config2_shared_water_engine_vs_reference():
             x.match(views[t], views)
             x.fit_init(views[t])
             rs.append(x)
-        assert sum(x.n_obs() for x in rs) == int(b['shared_n_total']) or not b.inputs_identical
+        assert sum(x.n_obs() for x in rs) == int(b['shared_n_total'])
         trace = torch.zeros((rt.shape[0], 10), dtype=torch.float64, device='cuda')
         if path == 'group':
             sdist.fit_shared_water(engine.HipWaterGroup(rs, trace=trace), rt.shape[0])
@@ -235,6 +235,7 @@ def test_config2_shared_water_engine_vs_reference():
         tr = trace.cpu().numpy()
         dpar, dcost = np.abs(tr[:, 1:] - rt[:, 1:]).max(), np.abs(tr[:, 0] / rt[:, 0] - 1).max()
         print(f'ENGINE, config 2 shared water ({path}), {rt.shape[0]} iterations: max|dparams|={dpar:.2e} max rel dcost={dcost:.2e}')
+        helpers.record_parity(f'ENGINE, config 2 shared water ({path})', 'shared', b, dpar=dpar, dcost=dcost, T=rt.shape[0])
         assert dpar < 2e-6 and dcost < 2e-5
         for i, x in enumerate(rs):
             helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 2 shared water ({path}), image {i}')

