@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
     const uint32_t lb = (uint32_t)level_bytes(fmt);
     const uint64_t st = state_off + (uint64_t)strip * (kStateFloats * 4);
     PlanItem *out = plan + (size_t)wid * stride + start;
-    strips[(size_t)wid * kmax + k] = StripEntry{strip, nu | ((nfull - nu) << 8) | (r << 16)};
+    strips[(size_t)wid * kmax + k] = StripEntry{strip, strip_counts(nu, nfull - nu, r)};
     *out++ = PlanItem{(uint32_t)(st >> 6), item_shape(3u * kStripPx * 4u, false)};
     for (uint32_t g = 0; g < nfull; ++g)
         *out++ = PlanItem{(uint32_t)((comp_off + (m.lvoff + (uint64_t)g * kGroupLv) * lb) >> 6), item_shape((uint32_t)chunk_bytes(fmt), true)};
@@ -520,7 +520,7 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         if (kExpPrio == 1) set_prio(gen + k);
         const uint32_t strip = se.x, counts = se.y;
         if (k + 1u < K) se = strips[k + 1u];
-        const uint32_t nu = counts & 255u, nm = (counts >> 8) & 255u, r = (counts >> 16) & 7u;
+        const uint32_t nu = counts_unmasked(counts), nm = counts_masked(counts), r = counts_tail(counts);
         on_J(step());
         for (uint32_t g = 0; g < nu; ++g) on_chunk(step(), false);
         for (uint32_t g = 0; g < nm; ++g) on_chunk(step(), true);

@@ -83,6 +83,9 @@ __host__ __device__ inline DealShares deal_shares(int mode, uint32_t blocks) {
     bool weighted = blocks == 256u * G && G <= (uint32_t)kMaxGen;
     for (uint32_t g = 0; weighted && g < G; ++g) weighted = (mode ? closed[g] : fit[g]) >= 1u && (mode ? closed[g] : fit[g]) <= kDealDen;
     weighted = weighted && (mode ? closed[0] : fit[0]) == kDealDen;   // somebody takes part in every round
+    bool all_equal = true;   // equal shares ARE the plain deal (the product default): one generation, so that deal_rounds -- hence
+    for (uint32_t g = 0; g < G && g < (uint32_t)kMaxGen; ++g) all_equal = all_equal && (mode ? closed[g] : fit[g]) == kDealDen;   // the plan space -- is not G x too large
+    weighted = weighted && !all_equal;
     sh.G = weighted ? G : 1u;
     for (int g = 0; g < kMaxGen; ++g) sh.p[g] = weighted && (uint32_t)g < G ? (mode ? closed[g] : fit[g]) : kDealDen;
     return sh;
@@ -132,8 +135,18 @@ struct PlanItem {
 };
 struct StripEntry {
     uint32_t strip;   // index of the strip (state block, StripMeta)
-    uint32_t counts;  // [7:0] full chunks without an empty slot, [15:8] full chunks that need the z > 0 test, [18:16] levels of the short last chunk
+    uint32_t counts;  // [11:0] full chunks without an empty slot, [23:12] full chunks that need the z > 0 test, [26:24] levels of the short last chunk
 };
+// A strip has at most kMaxViews levels = kMaxViews / 4 full chunks: both chunk counts must hold that many (until round 4 the
+// fields were 8 bits wide: a strip of 1024 levels or more decoded as nu = 0, nm = 1 and the wave's item stream desynchronised).
+constexpr uint32_t kCountBits = 12;
+static_assert(kMaxViews / kGroupLv < (1 << kCountBits), "StripEntry.counts: a strip's full chunks must fit their field");
+__host__ __device__ constexpr uint32_t strip_counts(uint32_t unmasked, uint32_t masked, uint32_t tail) { return unmasked | (masked << kCountBits) | (tail << (2 * kCountBits)); }
+__host__ __device__ constexpr uint32_t counts_unmasked(uint32_t c) { return c & ((1u << kCountBits) - 1u); }
+__host__ __device__ constexpr uint32_t counts_masked(uint32_t c) { return (c >> kCountBits) & ((1u << kCountBits) - 1u); }
+__host__ __device__ constexpr uint32_t counts_tail(uint32_t c) { return (c >> (2 * kCountBits)) & 7u; }
+static_assert(counts_unmasked(strip_counts(kMaxViews / kGroupLv, 0, 3)) == kMaxViews / kGroupLv && counts_masked(strip_counts(0, kMaxViews / kGroupLv, 3)) == kMaxViews / kGroupLv
+              && counts_masked(strip_counts(kMaxViews / kGroupLv, 0, 3)) == 0 && counts_tail(strip_counts(1023, 1, 3)) == 3, "StripEntry.counts round trip at the largest strip");
 
 struct Layout {
     int H, W, n_views, tiles_x, tiles_y, n_tiles;

@@ -186,6 +186,7 @@ class Restoration:
         if self.light and obs_format != 'f32':
             raise NotImplementedError('the artificial-light model keeps float32 camera points: obs_format must be f32')
         self.obs_format = obs_format
+        self._streams_used: dict = {}
         self._fmt = _lib.OBS_FORMATS[obs_format]
         self._fmt_flag = _lib.FIT_OBS_U16MM if self._fmt == _lib.OBS_U16MM else 0
         self.H, self.W, self.n_views = int(height), int(width), int(n_views)
@@ -215,6 +216,13 @@ class Restoration:
 
     # -- plumbing -----------------------------------------------------------------------------------------
     @property
+    def _sp(self) -> C.c_void_p:
+        """The current HIP stream, remembered as one this workspace has work queued on (``return_restoration`` leaves an event
+        on exactly these for the workspace's next owner)."""
+        st = torch.cuda.current_stream(self.device)
+        self._streams_used[st.cuda_stream] = st
+        return C.c_void_p(st.cuda_stream)
+
     def _ext_mode(self) -> int:
         return _lib.EXT_POINTS_COLOUR if self.both else _lib.EXT_COLOUR if self.float_colour else _lib.EXT_POINTS
 
@@ -262,12 +270,12 @@ class Restoration:
                 lws = C.c_void_p(self.lws.data_ptr())
                 fn = (self.lib.sucre_match_views_light_fcolour if self.both else
                       self.lib.sucre_match_views_fcolour if self.float_colour else self.lib.sucre_match_views_light)
-                _lib.check(fn(ws, lws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()), 0, n, _stream_ptr()))
-                _lib.check(self.lib.sucre_finalize_matches_ext(ws, lws, H, W, n, float(min_cover), self._ext_mode, _stream_ptr()))
+                _lib.check(fn(ws, lws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()), 0, n, self._sp()))
+                _lib.check(self.lib.sucre_finalize_matches_ext(ws, lws, H, W, n, float(min_cover), self._ext_mode, self._sp()))
             else:
                 _lib.check(self.lib.sucre_match_views(ws, H, W, n, C.byref(tgt), C.c_void_p(self._views_dev.data_ptr()),
-                                                      0, n, _stream_ptr()))
-                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
+                                                      0, n, self._sp()))
+                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, self._sp()))
 
     def import_matches(self, target: DeviceView, lists: list, min_cover: float = -1.0) -> None:
         """Fills the store from explicit per-view match lists instead of matching: ``lists[k] = (u1, v1, z, rgb_u8)``
@@ -301,15 +309,15 @@ class Restoration:
                     _lib.check(self.lib.sucre_import_view_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, k,
                                                               C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
                                                               C.c_void_p(z.data_ptr()), rgbp, C.c_void_p(ext.data_ptr()),
-                                                              u1.numel(), ext_mode, _stream_ptr()))
+                                                              u1.numel(), ext_mode, self._sp()))
                 else:
                     _lib.check(self.lib.sucre_import_view(ws, H, W, n, k, C.c_void_p(u1.data_ptr()), C.c_void_p(v1.data_ptr()),
-                                                          C.c_void_p(z.data_ptr()), rgbp, u1.numel(), _stream_ptr()))
+                                                          C.c_void_p(z.data_ptr()), rgbp, u1.numel(), self._sp()))
             if self.lws is not None:
                 _lib.check(self.lib.sucre_finalize_matches_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
-                                                               float(min_cover), self._ext_mode, _stream_ptr()))
+                                                               float(min_cover), self._ext_mode, self._sp()))
             else:
-                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, _stream_ptr()))
+                _lib.check(self.lib.sucre_finalize_matches_fmt(ws, H, W, n, float(min_cover), self._fmt, self._sp()))
 
     def match_map(self, k: int) -> torch.Tensor:
         """(H,W) int32: linear pixel index v2*W2+u2 in view k matched to every target pixel, -1 = none
@@ -320,7 +328,7 @@ class Restoration:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_match_map(self.H, self.W, self.n_views, C.byref(tgt),
                                                 C.c_void_p(self._views_dev.data_ptr()), int(k),
-                                                C.c_void_p(out.data_ptr()), _stream_ptr()))
+                                                C.c_void_p(out.data_ptr()), self._sp()))
         return out
 
     def view_counts(self) -> torch.Tensor:
@@ -349,7 +357,7 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_export_view(ws, H, W, n, int(k), C.c_void_p(z.data_ptr()),
-                                                  C.c_void_p(rgb.data_ptr()), _stream_ptr()))
+                                                  C.c_void_p(rgb.data_ptr()), self._sp()))
         return z, rgb
 
     def export_view_ext(self, k: int) -> torch.Tensor:
@@ -360,7 +368,7 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_export_view_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, int(k),
-                                                      C.c_void_p(out.data_ptr()), _stream_ptr()))
+                                                      C.c_void_p(out.data_ptr()), self._sp()))
         return out
 
     def check_store(self) -> torch.Tensor:
@@ -371,7 +379,7 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_check_store(ws, H, W, n, C.c_void_p(verdict.data_ptr()),
-                                                  C.c_void_p(scratch.data_ptr()), _stream_ptr()))
+                                                  C.c_void_p(scratch.data_ptr()), self._sp()))
         return verdict
 
     # -- fit (sucre.py:36-82, 124-157) --------------------------------------------------------------------------
@@ -396,10 +404,10 @@ class Restoration:
             if self.light or self.float_colour:
                 _lib.check(self.lib.sucre_fit_init_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n,
                                                          None if self.float_colour else C.c_void_p(target.rgb.data_ptr()),
-                                                         C.c_void_p(target.depth.data_ptr()), p0c, j0p, _stream_ptr()))
+                                                         C.c_void_p(target.depth.data_ptr()), p0c, j0p, self._sp()))
             else:
                 _lib.check(self.lib.sucre_fit_init(ws, H, W, n, C.c_void_p(target.rgb.data_ptr()),
-                                                   C.c_void_p(target.depth.data_ptr()), p0c, j0p, _stream_ptr()))
+                                                   C.c_void_p(target.depth.data_ptr()), p0c, j0p, self._sp()))
         self.steps_done = 0
 
     def fit(self, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
@@ -421,11 +429,11 @@ class Restoration:
             if ext:
                 _lib.check(self.lib.sucre_fit_run_light(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self.steps_done,
                                                         int(num_iter), float(lr), float(betas[0]), float(betas[1]),
-                                                        float(eps), flags, tp, _stream_ptr()))
+                                                        float(eps), flags, tp, self._sp()))
             else:
                 _lib.check(self.lib.sucre_fit_run(ws, H, W, n, self.steps_done, int(num_iter), float(lr),
                                                   float(betas[0]), float(betas[1]), float(eps), flags, tp,
-                                                  _stream_ptr()))
+                                                  self._sp()))
         self.steps_done += int(num_iter)
         if trace is not None and self.float_colour and not self.light:
             trace = trace[:, :10]   # the light columns are constants here
@@ -436,9 +444,9 @@ class Restoration:
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
             if self.light or self.float_colour:
-                _lib.check(self.lib.sucre_update_J_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self._ext_flag, _stream_ptr()))
+                _lib.check(self.lib.sucre_update_J_ext(ws, C.c_void_p(self.lws.data_ptr()), H, W, n, self._ext_flag, self._sp()))
             else:
-                _lib.check(self.lib.sucre_update_J_fmt(ws, H, W, n, self._fmt, _stream_ptr()))
+                _lib.check(self.lib.sucre_update_J_fmt(ws, H, W, n, self._fmt, self._sp()))
 
     def params(self) -> torch.Tensor:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
@@ -451,7 +459,7 @@ class Restoration:
         out = torch.empty((self.H, self.W, 3), dtype=torch.float32, device=self.device)
         ws, H, W, n = self._geom
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.sucre_export_J(ws, H, W, n, C.c_void_p(out.data_ptr()), _stream_ptr()))
+            _lib.check(self.lib.sucre_export_J(ws, H, W, n, C.c_void_p(out.data_ptr()), self._sp()))
         return out
 
 
@@ -528,19 +536,19 @@ class HipWaterBackend:
     def set_n_obs_total(self, n: int) -> None:
         ws, H, W, nv = self.r._geom
         with torch.cuda.device(self.r.device):
-            _lib.check(self.r.lib.sucre_set_n_obs_total(ws, H, W, nv, int(n), _stream_ptr()))
+            _lib.check(self.r.lib.sucre_set_n_obs_total(ws, H, W, nv, int(n), self.r._sp()))
 
     def grad(self, step: int) -> torch.Tensor:
         ws, H, W, nv = self.r._geom
         with torch.cuda.device(self.r.device):
-            _lib.check(self.r.lib.sucre_fit_grad(ws, H, W, nv, int(step), *self.hyper, self.flags, _stream_ptr()))
+            _lib.check(self.r.lib.sucre_fit_grad(ws, H, W, nv, int(step), *self.hyper, self.flags, self.r._sp()))
         return self._sums
 
     def step(self, step: int) -> None:
         ws, H, W, nv = self.r._geom
         row = C.c_void_p(self.trace[step - 1].data_ptr()) if self.trace is not None else None
         with torch.cuda.device(self.r.device):
-            _lib.check(self.r.lib.sucre_fit_step(ws, H, W, nv, int(step), *self.hyper, row, _stream_ptr()))
+            _lib.check(self.r.lib.sucre_fit_step(ws, H, W, nv, int(step), *self.hyper, row, self.r._sp()))
         self.r.steps_done = int(step)
 
 
@@ -574,7 +582,7 @@ class HipWaterGroup:
         p0 = np.full(9, 0.1, np.float32) if params0 is None else np.asarray(params0, np.float32).reshape(9)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_group_init(C.c_void_p(self.buf.data_ptr()), n, table, (C.c_float * 9)(*p0.tolist()),
-                                                 _stream_ptr()))
+                                                 self._sp()))
         off = self.lib.sucre_group_sums_offset()
         self._sums = self.buf[off:off + 96].view(torch.float64)
 
@@ -586,6 +594,12 @@ class HipWaterGroup:
 
     def set_n_obs_total(self, n: int) -> None:
         self.total = int(n)
+
+    def _sp(self) -> C.c_void_p:   # a group launch touches every image's workspace
+        sp = None
+        for r in self.rs:
+            sp = r._sp()
+        return sp
 
     def _trace_ptr(self):
         return C.c_void_p(self.trace.data_ptr()) if self.trace is not None else None
@@ -602,7 +616,7 @@ class HipWaterGroup:
                 for r in self.rs:
                     r.update_J()
             _lib.check(self.lib.sucre_group_iter(C.c_void_p(self.buf.data_ptr()), len(self.rs), int(step), *self.hyper,
-                                                 self.flags, self.total, self._trace_ptr(), _stream_ptr()))
+                                                 self.flags, self.total, self._trace_ptr(), self._sp()))
         return self._sums
 
     def step(self, step: int) -> None:
@@ -613,7 +627,7 @@ class HipWaterGroup:
     def finish(self) -> None:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sucre_group_finish(C.c_void_p(self.buf.data_ptr()), len(self.rs), self.steps_done, *self.hyper,
-                                                   self.total, self._trace_ptr(), _stream_ptr()))
+                                                   self.total, self._trace_ptr(), self._sp()))
             if self.closed:
                 for r in self.rs:
                     r.update_J()     # the final update_J of sucre.py:156 from the final parameters
@@ -621,7 +635,12 @@ class HipWaterGroup:
 
 _POOL: dict = {}
 _STREAMS: dict = {}
-_SLOT = 0          # the in-flight slot the calling code is working for (see in_flight_slot)
+_TLS = threading.local()   # .slot: the in-flight slot the calling THREAD is working for (see in_flight_slot); the CLI runs
+                           # decode, plan and writer pools next to the main thread: a module global would leak a slot into them
+
+
+def current_slot() -> int:
+    return getattr(_TLS, 'slot', 0)
 
 
 def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
@@ -638,7 +657,7 @@ def acquire_restoration(height: int, width: int, n_views: int, device='cuda', li
     # capacities come in steps, so targets whose surviving view counts differ a little share one workspace
     n = int(n_views)
     cap = (n + 7) // 8 * 8 if n <= 256 else (n + 31) // 32 * 32   # (65 views -> 72, not 96: +11 % HBM per slot, not +48 %)
-    key = (int(height), int(width), str(dev), bool(light), _SLOT, obs_format, bool(float_colour), tag)
+    key = (int(height), int(width), str(dev), bool(light), current_slot(), obs_format, bool(float_colour), tag)
     have = _POOL.get(key)
     if have is None or have.capacity < n:
         _POOL.pop(key, None)   # release the smaller workspace before allocating the larger one
@@ -678,12 +697,14 @@ def lease_restoration(height: int, width: int, n_views: int, device='cuda', ligh
 
 
 def return_restoration(r: Restoration) -> None:
-    """Hands a leased workspace back.  Its last owner's launches may still be queued (on the caller's stream or on an
-    in-flight slot's): one event per such stream is left on the workspace for the next owner to wait for."""
+    """Hands a leased workspace back.  Its last owner's launches may still be queued: one event per stream the workspace
+    was ever launched on (``Restoration._sp`` remembers them -- a user stream included; this function may run from a
+    ``weakref.finalize`` on any thread, whose current stream says nothing) is left on it for the next owner to wait for."""
     r._keepalive = []
     try:
         with torch.cuda.device(r.device):
-            streams = [torch.cuda.current_stream(r.device)] + [s for (d, _), s in _STREAMS.items() if d == str(r.device)]
+            streams = list(r._streams_used.values())
+            r._streams_used = {}
             events = []
             for s in streams:
                 ev = torch.cuda.Event()
@@ -709,7 +730,6 @@ def in_flight_slot(index: int, device='cuda', wait_for_caller: bool = True):
     inputs are complete when they are handed over (``sfm.Image.device_view`` publishes a view only once its upload has
     landed); recording that dependency on the default stream costs the host up to 10 ms per image when other threads
     keep that stream busy with blocking copies (measured in the CLI, tools/cli_timeline.py)."""
-    global _SLOT
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
@@ -719,12 +739,12 @@ def in_flight_slot(index: int, device='cuda', wait_for_caller: bool = True):
     stream = _STREAMS[key]
     if wait_for_caller:
         stream.wait_stream(torch.cuda.current_stream(dev))   # inputs uploaded / allocations freed on the caller's stream
-    prev, _SLOT = _SLOT, int(index)
+    prev, _TLS.slot = current_slot(), int(index)
     try:
         with torch.cuda.stream(stream):
             yield stream
     finally:
-        _SLOT = prev
+        _TLS.slot = prev
 
 
 def release_pool() -> None:

@@ -422,7 +422,8 @@ class MatchesData:
         # engine's free list and handed back when the container is dropped -- image after image of a kept-matches run
         # reuses one allocation (and its pinned staging buffer) instead of allocating ~2 GB per image.
         import weakref
-        resto = engine.lease_restoration(height, width, len(lists), device=device, light=light, float_colour=not integral)
+        # (obs_format spelled out: a list-backed container is the reference's lossless MatchesData whatever SUCRE_OBS_FORMAT says)
+        resto = engine.lease_restoration(height, width, len(lists), device=device, light=light, obs_format='f32', float_colour=not integral)
         weakref.finalize(self, engine.return_restoration, resto)
         resto.import_matches(None, lists)
         self.restoration = resto

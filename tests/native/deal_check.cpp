@@ -36,6 +36,25 @@ int main() {
                 for (int v : seen) if (v != 1) ++bad;
                 ++cases;
             }
+    // StripEntry.counts: every strip height up to kMaxViews levels with every split into unmasked / masked full chunks that the
+    // plan kernel can write (8-bit fields wrapped at 1024 levels)
+    for (uint32_t levels = 0; levels <= (uint32_t)kMaxViews; ++levels) {
+        const uint32_t nfull = levels >> 2, r = levels & 3u;
+        for (uint32_t nu : {0u, nfull / 2u, nfull}) {
+            const uint32_t c = strip_counts(nu, nfull - nu, r);
+            if (counts_unmasked(c) != nu || counts_masked(c) != nfull - nu || counts_tail(c) != r) ++bad;
+        }
+        ++cases;
+    }
+    // equal shares on the full grid reserve ceil(n_strips / W) strips per wave, not G times that
+    for (int mode = 0; mode < 2; ++mode) {
+        const uint32_t blocks = 256u * (uint32_t)(mode ? kClosedWaves : kFitWaves), W = blocks * 4u;
+        const DealShares sh = deal_shares(mode, blocks);
+        bool equal = true;
+        for (uint32_t g = 0; g < (uint32_t)(mode ? kClosedWaves : kFitWaves); ++g) equal = equal && sh.p[g] == kDealDen;
+        if (equal && (sh.G != 1u || deal_rounds(W, 131072u, sh) != (131072u + W - 1u) / W)) ++bad;
+        ++cases;
+    }
     std::printf("%d cases, %d violations\n", cases, bad);
     return bad != 0;
 }

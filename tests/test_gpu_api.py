@@ -808,3 +808,51 @@ def test_matches_file_written_like_the_reference_is_consumed(golden):
     closed = sucre.SUCRe(image=target, use_closed_form=True).to('cuda')
     closed.update_J(md)
     assert helpers.rms_per_channel(closed.J.cpu().numpy(), golden['J_closed_init']).max() < 1e-6
+
+
+def test_in_flight_slot_is_per_thread_and_a_returned_workspace_knows_its_streams(golden):
+    """ ``engine.in_flight_slot`` sets the slot of the CALLING thread only -- the CLI's decode / plan / writer
+    pools must not inherit it -- and a leased workspace handed back remembers the streams it was launched on, a user stream
+    included, so that its next owner waits for exactly that work (return_restoration may run from a finalizer on any thread)."""
+    import threading
+    from sucre_amd import engine
+    seen = {}
+    gate, done = threading.Event(), threading.Event()
+
+    def other():
+        gate.wait(10)
+        seen['other'] = engine.current_slot()
+        done.set()
+    th = threading.Thread(target=other)
+    th.start()
+    with engine.in_flight_slot(1):
+        assert engine.current_slot() == 1
+        gate.set()
+        done.wait(10)
+    th.join()
+    assert seen['other'] == 0 and engine.current_slot() == 0
+    sc = golden.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    user = torch.cuda.Stream()
+    r = engine.lease_restoration(sc.height, sc.width, len(views))
+    with torch.cuda.stream(user):
+        r.match(views[sc.target], views)
+        r.fit_init(views[sc.target])
+        r.fit(3)
+    assert user.cuda_stream in r._streams_used
+    t = threading.Thread(target=engine.return_restoration, args=(r,))   # as a finalizer would: another thread, another current stream
+    t.start(); t.join()
+    evs = r.__dict__.get('_idle_after')
+    assert evs and len(evs) == 1 and not r._streams_used
+    r2 = engine.lease_restoration(sc.height, sc.width, len(views))
+    assert r2 is r and '_idle_after' not in r2.__dict__
+    r2.match(views[sc.target], views)     # on the default stream: ordered behind the user stream's fit by the event
+    r2.fit_init(views[sc.target])
+    tr = r2.fit(3).cpu().numpy()
+    torch.cuda.synchronize()
+    ref = engine.Restoration(sc.height, sc.width, len(views))
+    ref.match(views[sc.target], views)
+    ref.fit_init(views[sc.target])
+    assert np.array_equal(tr, ref.fit(3).cpu().numpy())
+    engine.return_restoration(r2)
+    engine.release_pool()

@@ -631,6 +631,39 @@ def test_six_hundred_views_of_a_small_image():
         assert np.abs(tr[:, 0] / to[:, 0] - 1).max() < (1e-4 if closed else 1e-5)          # closed form amplifies
 
 
+@pytest.mark.timeout(900)
+def test_strips_of_more_than_a_thousand_levels():
+    """1200 views of a 64x48 image: pixels with more than 1024 observations, i.e. strips of 256 and more full chunks.  Until
+    round 4 the plan packed a strip's chunk counts into 8-bit fields (StripEntry.counts): such a strip decoded as 'no unmasked
+    chunk, one masked chunk', the wave's item stream desynchronised and J came out silently wrong.  Matching
+    bit-exact; both fit modes against the oracle; the u16mm store too (its own kernel instantiation)."""
+    from sucre_amd import engine, synth
+    scene = synth.make_scene(64, 48, 1199, seed=78, spacing=0.002)
+    r, views, samples = _check_matching(scene)
+    per_pixel = np.zeros((48, 64), np.int64)
+    for u1, v1, _, _ in samples:
+        np.add.at(per_pixel, (v1.astype(np.int64), u1.astype(np.int64)), 1)
+    assert per_pixel.max() >= 1100 and (per_pixel >= 1024).sum() >= 64, per_pixel.max()   # whole strips above the old limit
+    tgt = scene.views[scene.target]
+    for closed in (False, True):
+        J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
+        Jo, po, to = oracle.fit(48, 64, samples, J0, num_iter=4, use_closed_form=closed)
+        r.fit_init(views[scene.target])
+        tr = r.fit(4, use_closed_form=closed).cpu().numpy()
+        J = r.J().cpu().numpy()
+        assert np.array_equal(np.isnan(J), np.isnan(Jo))
+        assert helpers.rms_per_channel(J, Jo).max() < (1e-4 if closed else 1e-5)
+        assert np.abs(tr[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
+        assert np.abs(tr[:, 0] / to[:, 0] - 1).max() < (1e-4 if closed else 1e-5)
+    r16 = engine.Restoration(48, 64, len(views), obs_format='u16mm')
+    r16.match(views[scene.target], views)
+    r16.fit_init(views[scene.target])
+    tr16 = r16.fit(4).cpu().numpy()
+    assert np.abs(tr16[:, 1:] - to[:, 1:]).max() < 1e-2 and np.isfinite(tr16).all()
+    J16 = r16.J().cpu().numpy()
+    assert np.array_equal(np.isnan(J16), np.isnan(J))
+
+
 # ---- round 3: knee scenes pinned by the reference's own summation-order spread; closed-form shared water ----------------
 
 @pytest.mark.parametrize('name', helpers.KNEE_FIXTURES)
