@@ -215,7 +215,6 @@ class Restoration:
         self.steps_done = 0
 
     # -- plumbing -----------------------------------------------------------------------------------------
-    @property
     def _sp(self) -> C.c_void_p:
         """The current HIP stream, remembered as one this workspace has work queued on (``return_restoration`` leaves an event
         on exactly these for the workspace's next owner)."""
@@ -223,6 +222,7 @@ class Restoration:
         self._streams_used[st.cuda_stream] = st
         return C.c_void_p(st.cuda_stream)
 
+    @property
     def _ext_mode(self) -> int:
         return _lib.EXT_POINTS_COLOUR if self.both else _lib.EXT_COLOUR if self.float_colour else _lib.EXT_POINTS
 

@@ -788,3 +788,17 @@ def test_a_perturbed_scene_is_a_red_test(monkeypatch):
     # ... and the helpers hold no escape hatch any more
     src = (Path(helpers.__file__)).read_text() + (Path(helpers.__file__).parent / 'test_gpu_baseline.py').read_text()
     assert 'not b.inputs_identical' not in src and 'max(rms_bar' not in src
+
+
+def test_engine_plumbing_attributes_are_what_their_callers_expect():
+    """No GPU needed: the launch helpers of engine.Restoration are called as methods (``self._sp()``) and its layout helpers
+    are read as properties (``self._geom``, ``self._ext_mode``, ``self._ext_flag``) at ~40 call sites that only run on a GPU."""
+    from sucre_amd import engine
+    R = engine.Restoration
+    assert callable(inspect.getattr_static(R, '_sp')) and not isinstance(inspect.getattr_static(R, '_sp'), property)
+    for name in ('_geom', '_ext_mode', '_ext_flag'):
+        assert isinstance(inspect.getattr_static(R, name), property), name
+    assert callable(inspect.getattr_static(engine.HipWaterGroup, '_sp'))
+    src = inspect.getsource(engine)
+    assert '_stream_ptr()' not in inspect.getsource(R), 'Restoration launches go through self._sp() (stream bookkeeping)'
+    assert engine.current_slot() == 0 and '_SLOT' not in src
