@@ -645,9 +645,11 @@ def test_strips_of_more_than_a_thousand_levels():
         np.add.at(per_pixel, (v1.astype(np.int64), u1.astype(np.int64)), 1)
     assert per_pixel.max() >= 1100 and (per_pixel >= 1024).sum() >= 64, per_pixel.max()   # whole strips above the old limit
     tgt = scene.views[scene.target]
+    to_param = None
     for closed in (False, True):
         J0 = None if closed else oracle.init_J(tgt.rgb_u8.numpy(), tgt.depth_f32().numpy())
         Jo, po, to = oracle.fit(48, 64, samples, J0, num_iter=4, use_closed_form=closed)
+        to_param = to if to_param is None else to_param
         r.fit_init(views[scene.target])
         tr = r.fit(4, use_closed_form=closed).cpu().numpy()
         J = r.J().cpu().numpy()
@@ -659,7 +661,8 @@ def test_strips_of_more_than_a_thousand_levels():
     r16.match(views[scene.target], views)
     r16.fit_init(views[scene.target])
     tr16 = r16.fit(4).cpu().numpy()
-    assert np.abs(tr16[:, 1:] - to[:, 1:]).max() < 1e-2 and np.isfinite(tr16).all()
+    # (ranges rounded to millimetres: lossy by design, held to 1e-3 on the parameters of these four steps)
+    assert np.abs(tr16[:, 1:] - to_param[:, 1:]).max() < 1e-3 and np.isfinite(tr16).all()
     J16 = r16.J().cpu().numpy()
     assert np.array_equal(np.isnan(J16), np.isnan(J))
 
