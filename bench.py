@@ -63,6 +63,9 @@ def parse():
                         '1 = 640x480, 4 neighbours; 2 = 1920x1080, 64 neighbours (the default workload, the one the metric is '
                         'quoted on); 3 = --batch-images 32; 4 = --shared-water --batch-images 64 (the 512-image scene, 64 images '
                         'per rank, one all-reduce per iteration); 5 = 3840x2160, 256 neighbours, --obs-format u16mm')
+    p.add_argument('--digest', action='store_true',
+                   help='config.J_sha256_per_rank: SHA-256 of the last J every rank produced (per-image mode shards with no '
+                        'collective: a rank\'s J must be the bits a 1-GPU run of the same image gives)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-views', type=int, default=65, help='views in the CPU-baseline sample (65 = all of config 2)')
     p.add_argument('--cpu-iters', type=int, default=100, help='Adam iterations in the CPU-baseline sample (~15 s of CPU '
@@ -486,6 +489,16 @@ def main():
             traffic, prof = rec['hbm_bytes_per_launch'], (tf.name, rec)
             break
 
+    digests = None
+    if args.digest:
+        import hashlib
+        torch.cuda.synchronize()
+        mine = hashlib.sha256(J_out[0].cpu().numpy().tobytes()).hexdigest()
+        if world > 1:
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
+        else:
+            digests = [mine]
     if world > 1:
         seen = torch.ones(1, dtype=torch.int64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(seen)
@@ -542,6 +555,7 @@ def main():
                        'images_per_s_per_gpu': args.steps * len(jobs) / elapsed, 'fit_ms_alone': fit_ms,
                        'ms_per_image': elapsed / args.steps / len(jobs) * 1e3,
                        'ms_per_image_per_rank': {'min': min(per_rank), 'max': max(per_rank), 'all': per_rank},
+                       'J_sha256_per_rank': digests,
                        'pack_view_ms_per_image': pack_ms,
                        'pack_view_note': 'sucre_pack_view of all views of one image: cached per view, paid before the timed region '
                                          '(amortised over a survey\'s targets); add it to ms_per_image for one image taken alone',

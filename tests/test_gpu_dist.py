@@ -49,7 +49,7 @@ def test_two_processes_shared_water_hip_backend(golden, tmp_path):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('extra', [[], ['--shared-water'], ['--shared-water', '--batch-images', '2', '--use-closed-form']],
+@pytest.mark.parametrize('extra', [['--digest'], ['--shared-water'], ['--shared-water', '--batch-images', '2', '--use-closed-form']],
                          ids=['per-image', 'shared-water', 'shared-water-group-closed'])
 def test_bench_launches_its_own_ranks(extra):
     """`python bench.py --gpus 2` with no launcher environment starts two ranks itself and rank 0 prints one JSON
@@ -64,6 +64,11 @@ def test_bench_launches_its_own_ranks(extra):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['config']['ranks_seen'] == 2 and len(rec['config']['devices']) == 2
     assert rec['value'] > 0 and rec['scaling'] == 'weak'
+    per_rank = rec['config']['ms_per_image_per_rank']
+    assert len(per_rank['all']) == 2 and per_rank['min'] <= per_rank['max']   # a straggler would show here
+    if '--digest' in extra:   # every rank restored its own image (seed = rank): two different J, each reported
+        d = rec['config']['J_sha256_per_rank']
+        assert len(d) == 2 and d[0] != d[1] and all(len(x) == 64 for x in d)
 
 
 @pytest.mark.timeout(600)
