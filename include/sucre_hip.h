@@ -239,6 +239,23 @@ int sucre_group_iter(void *group_dev, int n_images, int step, double lr, double 
 int sucre_group_finish(void *group_dev, int n_images, int step, double lr, double beta1, double beta2, double eps,
                        uint64_t n_obs_total, double *trace_dev, void *stream);
 
+/*
+ * Independent images, ONE launch per iteration: the loop over the images of a scene (sucre.py:243-261, one SUCRe module and one
+ * sucre.adam call per image, nothing shared) with the iterations of n_images images advancing together.  Every image keeps
+ * its own B, beta, gamma, J, Adam state and log; its results are bit for bit those of sucre_fit_run on it alone -- the
+ * launch only spares small images the per-launch cost they are dominated by (BASELINE config 1) and fills the end of one
+ * image's pass with the next image's beginning.  All images have one size (H, W: one launch grid); their view counts may
+ * differ (n_views[i] = what image i's workspace was laid out for).  They must have been matched / imported, finalized and
+ * initialised (sucre_fit_init) and stand at the same step t0.
+ * ws / trace_dev / n_views: HOST arrays of n_images entries (trace_dev itself or any of its entries may be NULL; an entry is
+ * that image's (T, 10) float64 device log as in sucre_fit_run); batch_dev: sucre_batch_bytes(n_images) bytes of device memory,
+ * 256-byte aligned, that the call fills (the image table the launches read) and that must stay untouched until they have run.
+ * flags as in sucre_fit_run.
+ */
+size_t sucre_batch_bytes(int n_images);
+int sucre_fit_run_batch(void *batch_dev, int n_images, void *const *ws, double *const *trace_dev, int H, int W, const int *n_views,
+                        int t0, int T, double lr, double beta1, double beta2, double eps, unsigned flags, void *stream);
+
 /* SUCRe.update_J(force_update=True) (sucre.py:66-77): closed-form J from the current parameters. */
 int sucre_update_J(void *ws, int H, int W, int n_views, void *stream);
 int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream);

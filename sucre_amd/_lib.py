@@ -63,6 +63,8 @@ SIGNATURES = {
     'sucre_group_init': (_i, [_vp, _i, C.POINTER(GroupImage), C.POINTER(C.c_float), _vp]),
     'sucre_group_iter': (_i, [_vp, _i, _i, _d, _d, _d, _d, C.c_uint, _u64, _vp, _vp]),
     'sucre_group_finish': (_i, [_vp, _i, _i, _d, _d, _d, _d, _u64, _vp, _vp]),
+    'sucre_batch_bytes': (C.c_size_t, [_i]),
+    'sucre_fit_run_batch': (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, C.POINTER(_i), _i, _i, _d, _d, _d, _d, C.c_uint, _vp]),
     'sucre_update_J': (_i, [_vp, _i, _i, _i, _vp]),
     'sucre_update_J_fmt': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'sucre_export_J': (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 #include "launch.h"
 
@@ -311,6 +312,41 @@ int sucre_group_finish(void *group_dev, int n_images, int step, double lr, doubl
     double *row = (trace_dev && step >= 1) ? trace_dev + (size_t)(step - 1) * 10 : nullptr;
     return check_hip(launch_group_finish(group_dev, n_images, step, adam_coef(step >= 1 ? step : 1, lr, beta1, beta2, eps), n_obs_total,
                                          row, static_cast<hipStream_t>(stream)), "sucre_group_finish");
+}
+
+/* ---- independent images, one launch per iteration ---------------------------------------------------------------- */
+
+size_t sucre_batch_bytes(int n_images) { return n_images > 0 ? batch_bytes(n_images) : 0; }
+
+int sucre_fit_run_batch(void *batch_dev, int n_images, void *const *ws, double *const *trace_dev, int H, int W, const int *n_views,
+                        int t0, int T, double lr, double beta1, double beta2, double eps, unsigned flags, void *stream) {
+    if (!batch_dev || !aligned(batch_dev, 256)) return fail(SUCRE_ERR_ARG, "batch buffer is NULL or not 256-byte aligned");
+    if (n_images < 1 || !ws || !n_views) return fail(SUCRE_ERR_ARG, "need at least one image (ws and n_views arrays)");
+    if (n_images > 4096) return fail(SUCRE_ERR_RANGE, "n_images=%d: at most 4096 images per batch", n_images);
+    std::vector<Layout> layouts((size_t)n_images);
+    for (int i = 0; i < n_images; ++i) {
+        if (int rc = check_ws(ws[i], H, W, n_views[i], &layouts[(size_t)i])) return rc;
+        for (int j = 0; j < i; ++j)
+            if (ws[j] == ws[i]) return fail(SUCRE_ERR_ARG, "images %d and %d share a workspace", j, i);
+        if (trace_dev && trace_dev[i] && !aligned(trace_dev[i], 8)) return fail(SUCRE_ERR_ARG, "trace of image %d must be 8-byte aligned", i);
+    }
+    if (t0 < 0 || T < 0) return fail(SUCRE_ERR_RANGE, "t0=%d T=%d must be >= 0", t0, T);
+    if (int rc = check_adam(t0 + 1, lr, beta1, beta2, eps)) return rc;
+    if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_OBS_U16MM | SUCRE_FIT_KEEP_J)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
+    auto s = static_cast<hipStream_t>(stream);
+    const int fmt = (flags & SUCRE_FIT_OBS_U16MM) ? SUCRE_OBS_U16MM : SUCRE_OBS_F32;
+    if (int rc = check_hip(launch_batch_set(batch_dev, n_images, reinterpret_cast<uint8_t *const *>(ws), trace_dev, layouts.data(), flags, s),
+                           "sucre_fit_run_batch/table")) return rc;
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && t0 == 0 && T > 0)   // as sucre_fit_run: the one-pass kernel starts from a solved J
+        for (int i = 0; i < n_images; ++i)
+            if (int rc = check_hip(launch_update_J(layouts[(size_t)i], static_cast<uint8_t *>(ws[i]), fmt, s), "sucre_fit_run_batch/initial update_J")) return rc;
+    for (int it = 0; it < T; ++it)
+        if (int rc = check_hip(launch_batch_iter(layouts[0], batch_dev, n_images, adam_coef(t0 + it + 1, lr, beta1, beta2, eps), flags, it, s),
+                               "sucre_fit_run_batch")) return rc;
+    if ((flags & SUCRE_FIT_CLOSED_FORM) && !(flags & SUCRE_FIT_KEEP_J))
+        for (int i = 0; i < n_images; ++i)
+            if (int rc = check_hip(launch_update_J(layouts[(size_t)i], static_cast<uint8_t *>(ws[i]), fmt, s), "sucre_fit_run_batch/update_J")) return rc;
+    return SUCRE_OK;
 }
 
 size_t sucre_select_scratch_bytes(void) { return select_scratch_bytes(); }

@@ -48,6 +48,16 @@ __device__ __forceinline__ Water load_water(const float *__restrict__ params) {
     return w;
 }
 
+// The same for a caller that keeps other things in vector registers across the pass: every value made wave-uniform
+// explicitly, so that the nine parameters live in scalar registers.
+__device__ __forceinline__ float uniform_f(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ Water load_water_uniform(const float *params) {
+    Water w = load_water(params);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { w.B[c] = uniform_f(w.B[c]); w.nb[c] = uniform_f(w.nb[c]); w.ng[c] = uniform_f(w.ng[c]); }
+    return w;
+}
+
 constexpr float kInv255 = (float)(1.0 / 255.0);
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1027,6 +1037,77 @@ __global__ __launch_bounds__(64) void group_init_kernel(GroupHeader *g, const Pa
     for (int i = t; i < (int)(sizeof(g->ticket) / sizeof(unsigned)); i += 64) g->ticket[i] = 0u;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Independent images in ONE launch per iteration (the reference's per-image mode, sucre.py:243-261: every image has its own
+// B, beta, gamma, J and its own Adam state; nothing is shared).  A launch per image and iteration is what a small image pays
+// for most: at 640x480 x 5 views (BASELINE config 1) a launch moves 31 MB and lasts 17 us, 0.24 of the HBM peak, each wave with
+// less than one strip to work on.  Here every wave walks its item list of image 0, then of image 1, ...; after each image the
+// workgroup leaves its partial in THAT image's workspace and arrives on THAT image's tickets, so the image's last arriver
+// reduces its sums, steps its nine parameters and writes its log row while everybody else is already streaming the next
+// image: the launch gap, the ramp-up and the reduction tail are paid once per launch instead of once per image.  Every image
+// sees exactly the operations of its own fit_grad_kernel / fit_closed_kernel launch in the same order (same plan, same
+// grid, same reduction tree), so its results are the bits of fitting it alone (tests/test_gpu_batch.py).
+// All images of a batch have one size (H, W: one grid); their view counts -- hence their workspace layouts -- may differ.
+// ---------------------------------------------------------------------------------------------------------------
+struct BatchOffsets {
+    uint64_t plan, strips, count, params, n_obs_total, state, partials, ticket, gpart, sums, format;
+    uint32_t stride, kmax;
+    int n_groups;
+};
+struct BatchEntry { uint8_t *ws; double *trace; BatchOffsets o; };   // trace: the image's (T, 10) log, or NULL
+
+template <int kMode, int kFmt>
+__global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
+                                                                                           const AdamCoef co, int row) {
+    __shared__ FitLds lds;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    for (int i = 0; i < n_images; ++i) {
+        uint8_t *ws = uniform_ptr(images[i].ws);   // between images nothing of this wave is in flight: ordinary loads are harmless
+        double *trace = uniform_ptr(images[i].trace);
+        const BatchOffsets &o = images[i].o;
+        float *pstate = reinterpret_cast<float *>(ws + o.params);
+        const uint64_t *n_obs_total = reinterpret_cast<const uint64_t *>(ws + o.n_obs_total);
+        const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + o.format);
+        const Water w = load_water_uniform(pstate);
+        const RangeCodes rc = range_codes(store_fmt);
+        const bool fmt_ok = store_matches<kFmt>(store_fmt);
+        const uint32_t n_mine = fmt_ok ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + o.count)[wid]) : 0u;
+        const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + o.plan) + (size_t)wid * o.stride);
+        const StripEntry *strips = uniform_ptr(reinterpret_cast<const StripEntry *>(ws + o.strips) + (size_t)wid * o.kmax);
+        float *state = reinterpret_cast<float *>(ws + o.state);
+        float s[kNumSums];
+        if (kMode == 0) {
+            const float gscale = uniform_f(-2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total)));
+            Acc acc;
+            zero_acc(acc);
+            if (!fmt_ok) acc.cost = __builtin_nanf("");
+            float sBeta[3] = {0.f, 0.f, 0.f};
+            grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta, rc);
+            const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
+#pragma unroll
+            for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
+        } else {
+            ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
+            closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, fmt_ok, cs, rc);
+            const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
+#pragma unroll
+            for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
+        }
+        finish_launch<true>(lds, s, reinterpret_cast<float *>(ws + o.partials), co, reinterpret_cast<unsigned *>(ws + o.ticket),
+                            reinterpret_cast<double *>(ws + o.gpart), o.n_groups, reinterpret_cast<double *>(ws + o.sums), pstate, n_obs_total,
+                            trace ? trace + (size_t)row * 10 : nullptr);
+    }
+}
+
+constexpr int kBatchSet = 8;
+struct BatchEntries { BatchEntry e[kBatchSet]; };
+__global__ void batch_set_kernel(BatchEntry *dst, const BatchEntries src, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = src.e[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void reduce_groups_kernel(const float *partials, int n_blocks, double *gpart,
                                                             int n_groups) {
     reduce_group(partials, n_blocks, blockIdx.x, gpart, n_groups);
@@ -1182,6 +1263,47 @@ hipError_t launch_export_J(const Layout &L, const uint8_t *ws, float *J, hipStre
     hipLaunchKernelGGL(export_J_kernel, dim3(L.n_tiles), dim3(256), 0, s,
                        reinterpret_cast<const float *>(ws + L.off_state), L.H, L.W, L.tiles_x,
                        reinterpret_cast<const uint32_t *>(ws + L.off_invperm), J);
+    return hipGetLastError();
+}
+
+size_t batch_bytes(int n_images) { return align_up((size_t)n_images * sizeof(BatchEntry), 256); }
+
+// The image table of a batch for one J mode (the plans differ between the modes): entry i = image i's workspace, log and
+// the offsets of its own layout.
+hipError_t launch_batch_set(void *batch, int n_images, uint8_t *const *ws, double *const *trace, const Layout *layouts, unsigned flags,
+                            hipStream_t s) {
+    const int mode = (flags & SUCRE_FIT_CLOSED_FORM) ? 1 : 0;
+    for (int i0 = 0; i0 < n_images; i0 += kBatchSet) {
+        BatchEntries src;
+        const int n = n_images - i0 < kBatchSet ? n_images - i0 : kBatchSet;
+        for (int j = 0; j < kBatchSet; ++j) {
+            const Layout &L = layouts[j < n ? i0 + j : i0];
+            BatchOffsets o;
+            o.plan = L.off_plan[mode]; o.strips = L.off_plan_strips[mode]; o.count = L.off_plan_count[mode];
+            o.params = L.off_params; o.n_obs_total = L.off_n_obs_total; o.state = L.off_state; o.partials = L.off_partials;
+            o.ticket = L.off_ticket; o.gpart = L.off_gpartials; o.sums = L.off_sums; o.format = L.off_total_chunks + sizeof(uint64_t);
+            o.stride = (uint32_t)L.plan_stride[mode]; o.kmax = (uint32_t)L.plan_kmax[mode]; o.n_groups = L.fit_groups[mode];
+            src.e[j] = BatchEntry{j < n ? ws[i0 + j] : nullptr, (j < n && trace) ? trace[i0 + j] : nullptr, o};
+        }
+        hipLaunchKernelGGL(batch_set_kernel, dim3(1), dim3(64), 0, s, static_cast<BatchEntry *>(batch) + i0, src, n);
+    }
+    return hipGetLastError();
+}
+
+// One iteration of every image of the batch: one launch (row = the iteration's row in every image's log).  L: any image's
+// layout (the grid is a function of the image size).
+hipError_t launch_batch_iter(const Layout &L, void *batch, int n_images, const AdamCoef &co, unsigned flags, int row, hipStream_t s) {
+    const int mode = (flags & SUCRE_FIT_CLOSED_FORM) ? 1 : 0;
+    const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
+    const dim3 grid(L.fit_blocks[mode]), block(256);
+    auto *b = static_cast<const BatchEntry *>(batch);
+    if (mode) {
+        if (u16) hipLaunchKernelGGL((batch_iter_kernel<1, 1>), grid, block, 0, s, b, n_images, co, row);
+        else hipLaunchKernelGGL((batch_iter_kernel<1, 0>), grid, block, 0, s, b, n_images, co, row);
+    } else {
+        if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n_images, co, row);
+        else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n_images, co, row);
+    }
     return hipGetLastError();
 }
 

@@ -66,6 +66,12 @@ hipError_t launch_group_iter(void *group, int n_images, int step, const AdamCoef
 hipError_t launch_group_finish(void *group, int n_images, int step, const AdamCoef &co_prev, uint64_t n_obs_total,
                                double *trace_prev, hipStream_t s);
 
+// independent images, one launch per iteration (fit.hip)
+size_t batch_bytes(int n_images);
+hipError_t launch_batch_set(void *batch, int n_images, uint8_t *const *ws, double *const *trace, const Layout *layouts, unsigned flags,
+                            hipStream_t s);
+hipError_t launch_batch_iter(const Layout &L, void *batch, int n_images, const AdamCoef &co, unsigned flags, int row, hipStream_t s);
+
 // output stage (plot.hip)
 size_t select_scratch_bytes();
 hipError_t launch_select_ranks(const float *J, int H, int W, int n_ranks, const uint64_t *ranks, float *out, void *scratch,

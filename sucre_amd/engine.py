@@ -463,6 +463,46 @@ class Restoration:
         return out
 
 
+def fit_batch(restorations: list, num_iter: int = 200, lr: float = 0.05, use_closed_form: bool = False, betas=(0.9, 0.999),
+              eps: float = 1e-8, record_trace: bool = True, keep_J: bool = False) -> list:
+    """``Restoration.fit`` for several INDEPENDENT images at once -- the reference's loop over images (sucre.py:243-261) with
+    the iterations of all of them advancing together, one launch per iteration (``sucre_fit_run_batch``).  Every image keeps
+    its own B, beta, gamma, J, Adam state and trace, bit for bit what ``fit`` gives it alone; what the batch saves is the
+    per-launch cost (small images are dominated by it) and the idle end of every image's pass.  The images must have one
+    size, sit on one device, stand at the same step and use the same observation format; their view counts may differ.
+    Returns the list of (num_iter, 10) device traces (or of None)."""
+    rs = list(restorations)
+    assert rs, 'no image'
+    r0 = rs[0]
+    for r in rs:
+        if r.light or r.float_colour:
+            raise NotImplementedError('fit_batch: the extension-plane modes (light model, float32 colours) are fitted one by one')
+        assert (r.H, r.W, str(r.device), r.obs_format, r.steps_done) == (r0.H, r0.W, str(r0.device), r0.obs_format, r0.steps_done), \
+            'one image size, device, observation format and step per batch'
+    assert len({r.ws.data_ptr() for r in rs}) == len(rs), 'every image needs its own workspace'
+    n = len(rs)
+    traces = [torch.zeros((num_iter, 10), dtype=torch.float64, device=r0.device) if record_trace else None for _ in rs]
+    flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | r0._fmt_flag
+    if keep_J and use_closed_form:
+        flags |= _lib.FIT_KEEP_J
+    lib = r0.lib
+    table = torch.empty(lib.sucre_batch_bytes(n), dtype=torch.uint8, device=r0.device)
+    ws = (C.c_void_p * n)(*[r.ws.data_ptr() for r in rs])
+    tr = (C.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in traces])
+    nv = (C.c_int * n)(*[int(r.n_views) for r in rs])
+    with torch.cuda.device(r0.device):
+        sp = None
+        for r in rs:
+            sp = r._sp()
+        _lib.check(lib.sucre_fit_run_batch(C.c_void_p(table.data_ptr()), n, ws, tr, r0.H, r0.W, nv, r0.steps_done, int(num_iter),
+                                           float(lr), float(betas[0]), float(betas[1]), float(eps), flags, sp))
+    for r, t in zip(rs, traces):
+        r.steps_done += int(num_iter)
+        r.trace = t
+        r._keepalive.append(table)   # the launches read the table: it lives as long as the workspaces' current image
+    return traces
+
+
 def select_ranks(J: torch.Tensor, ranks: list[int]) -> torch.Tensor:
     """(3, len(ranks)) float32: per channel of the (H,W,3) float32 device image ``J``, the values at the given 0-based
     ranks among the valid pixels (no NaN in any channel), ascending -- exact order statistics by radix select on the

@@ -84,6 +84,19 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.sucre_pack_view(ws, ws, 0, 64, ws, None) == -1 and b'image size' in lib.sucre_last_error()
     assert lib.sucre_pack_view(ws, None, 48, 64, ws, None) == -1 and b'NULL' in lib.sucre_last_error()
     assert lib.sucre_pack_view(ws, ws, 48, 64, C.c_void_p(260), None) == -1 and b'8-byte aligned' in lib.sucre_last_error()
+    # round 5: independent images in one launch per iteration
+    assert lib.sucre_batch_bytes(0) == 0 and lib.sucre_batch_bytes(3) % 256 == 0 and lib.sucre_batch_bytes(100) >= 1600
+    two = (C.c_void_p * 2)(256, 512)
+    same = (C.c_void_p * 2)(256, 256)
+    nv = (C.c_int * 2)(3, 5)
+    assert lib.sucre_fit_run_batch(None, 2, two, None, 48, 64, nv, 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1 and b'batch buffer' in lib.sucre_last_error()
+    assert lib.sucre_fit_run_batch(ws, 0, two, None, 48, 64, nv, 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1
+    assert lib.sucre_fit_run_batch(ws, 2, two, None, 48, 64, None, 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1
+    assert lib.sucre_fit_run_batch(ws, 2, same, None, 48, 64, nv, 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1 and b'share a workspace' in lib.sucre_last_error()
+    assert lib.sucre_fit_run_batch(ws, 2, two, None, 48, 64, (C.c_int * 2)(3, 0), 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1 and b'invalid geometry' in lib.sucre_last_error()
+    assert lib.sucre_fit_run_batch(ws, 2, two, None, 48, 64, nv, 0, -1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -2
+    assert lib.sucre_fit_run_batch(ws, 2, two, None, 48, 64, nv, 0, 1, 0.05, 0.9, 0.999, 1e-8, 64, None) == -1 and b'flags' in lib.sucre_last_error()
+    assert lib.sucre_fit_run_batch(ws, 2, (C.c_void_p * 2)(256, 260), None, 48, 64, nv, 0, 1, 0.05, 0.9, 0.999, 1e-8, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
