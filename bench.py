@@ -49,6 +49,10 @@ def parse():
     p.add_argument('--images-in-flight', type=int, default=2,
                    help='consecutive images (steps) kept in flight on their own HIP streams + workspaces '
                         '(engine.in_flight_slot); 1 = strictly one image at a time')
+    p.add_argument('--fit-batch', type=int, default=1,
+                   help='independent images fitted together, ONE launch per iteration for all of them (sucre_fit_run_batch; every '
+                        'image keeps its own parameters and gets the bits of being fitted alone): consecutive images of the timed '
+                        'region are taken in chunks of this many (1 = one launch per image and iteration)')
     p.add_argument('--obs-format', choices=['f32', 'u16mm', 'f32plain'], default='f32',
                    help="observation store: f32 = float32 ranges, lossless, 7 B/obs by SURVEY 8(d) (configs 1-4; the library keeps "
                         "them as 24-bit offsets, 6 B/obs, when the image's ranges allow it -- same bits); f32plain = the float32 "
@@ -281,8 +285,10 @@ def main():
     # images in flight: slot s = own workspace + own HIP stream; image i goes to slot i % S, so consecutive images
     # overlap (the launches of one fit depend on each other; a second image fills their ramp-up and tails)
     S = 1 if args.shared_water else max(1, args.images_in_flight)
-    restos = [engine.Restoration(H, W, n_views, device=device, light=args.light_model, obs_format=args.obs_format)
-              for _ in range(S)]
+    B = 1 if (args.shared_water or args.light_model) else max(1, args.fit_batch)   # images per fit launch (own workspace each)
+    slots = [[engine.Restoration(H, W, n_views, device=device, light=args.light_model, obs_format=args.obs_format)
+              for _ in range(B)] for _ in range(S)]
+    restos = [sl[0] for sl in slots]
     streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(device)]
     resto = restos[0]
     J_out = [None] * S
@@ -297,11 +303,15 @@ def main():
         group_restos = [resto] + [engine.Restoration(H, W, n_views, device=device, obs_format=args.obs_format)
                                   for _ in range(len(jobs) - 1)]
 
-    def step(record):
+    def step(record, n_steps=1):
+        """``n_steps`` steps of the workload: n_steps x len(jobs) images, consecutive images ``--fit-batch`` at a time."""
         if group_restos is not None:
-            return shared_water_step(record)
-        for tgt, views in jobs:
-            restore_one(tgt, views, record)
+            for _ in range(n_steps):
+                shared_water_step(record)
+            return
+        images = list(jobs) * n_steps
+        for c in range(0, len(images), B):
+            restore_chunk(images[c:c + B], record)
 
     def shared_water_step(record):
         for r, (tgt, views) in zip(group_restos, jobs):
@@ -318,13 +328,32 @@ def main():
         for r in group_restos:
             J_out[0] = r.J()
 
-    def restore_one(tgt, views, record, slot=None):
+    def restore_chunk(chunk, record, slot=None):
         nonlocal submitted
         if slot is None:
             slot = submitted % S
             submitted += 1
         with torch.cuda.stream(streams[slot]):
-            restore_on(restos[slot], slot, tgt, views, record)
+            if B == 1:
+                restore_on(restos[slot], slot, *chunk[0], record)
+            else:
+                restore_batch_on(slots[slot][:len(chunk)], slot, chunk, record)
+
+    def restore_one(tgt, views, record, slot=None):
+        restore_chunk([(tgt, views)] * B, record, slot)
+
+    def restore_batch_on(rs, slot, chunk, record):
+        for r, (tgt, views) in zip(rs, chunk):
+            r.match(tgt, views, min_cover=1e-6)
+            r.fit_init(tgt)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        engine.fit_batch(rs, T, use_closed_form=args.use_closed_form, record_trace=True)
+        if record:
+            e1.record()
+            fit_events.append((e0, e1))
+        J_out[slot] = [r.J() for r in rs][0]
 
     def restore_on(resto, slot, tgt, views, record):
         resto.match(tgt, views, min_cover=1e-6)
@@ -369,18 +398,16 @@ def main():
         torch.cuda.synchronize()
         pack_ms = p0.elapsed_time(p1)
     note(rank, 'warmup', f'scene resident, {len(jobs)} image(s) x {n_views} views per step')
-    for slot in range(args.warmup * len(jobs), S):   # setup: slots the W warmup steps will not reach run once too
+    for slot in range((args.warmup * len(jobs) + B - 1) // B, S):   # setup: slots the W warmup steps will not reach run once too
         restore_one(*jobs[0], False, slot=slot)
-    for _ in range(args.warmup):
-        step(False)
+    step(False, args.warmup)
     note(rank, 'barrier before the timed region')
     barrier()
     note(rank, 'timed region')
     base = torch.cuda.Event(enable_timing=True)
     base.record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    step(True, args.steps)
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0
     note(rank, 'barrier after the timed region', f'own time {own_elapsed / args.steps * 1e3:.2f} ms/step, n_obs {resto.n_obs()}')
@@ -401,7 +428,7 @@ def main():
     else:
         per_rank = [own_ms_per_image]
     # what this rank holds in HBM for the fit: every workspace (one per in-flight slot, or one per image of a shared-water group)
-    held = group_restos if group_restos is not None else restos
+    held = group_restos if group_restos is not None else [r for sl in slots for r in sl]
     workspace_bytes = sum(r.ws.numel() + (r.lws.numel() if r.lws is not None else 0) for r in held)
     timed_region_iter_ms = None
     if S > 1:
@@ -428,6 +455,7 @@ def main():
         with torch.cuda.stream(streams[0]):
             # (one untimed image first: the match stage of the first image after the barrier was seen at 3.5 ms instead of
             # 1.0 -- the GPU had idled through the host's bookkeeping between the timed region and here)
+            solo_chunk = (list(jobs) * B)[:B]   # --fit-batch: the launch is the unit -- one chunk of B images at a time
             for i in range(1 + max(1, args.solo_images)):
                 tgt, views = jobs[0]
                 m0, m1, f0, f1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
@@ -435,9 +463,14 @@ def main():
                 restos[0].match(tgt, views, min_cover=1e-6)
                 m1.record()
                 restos[0].fit_init(tgt)
+                for r, (tg, vs) in list(zip(slots[0], solo_chunk))[1:]:
+                    r.match(tg, vs, min_cover=1e-6)
+                    r.fit_init(tg)
                 f0.record()
                 if args.shared_water:
                     sdist.fit_shared_water(engine.HipWaterGroup([restos[0]], use_closed_form=args.use_closed_form), T)
+                elif B > 1:
+                    engine.fit_batch(slots[0][:B], T, use_closed_form=args.use_closed_form, record_trace=True)
                 else:
                     restos[0].fit(T, use_closed_form=args.use_closed_form, record_trace=True)
                 f1.record()
@@ -454,8 +487,10 @@ def main():
     obs_passes = 2 if (args.use_closed_form and args.light_model) else 1  # light + closed form: J pass, then gradient pass
     state_bytes = 12 * H * W if args.use_closed_form else STATE_BYTES_PER_PX * H * W
     obs_bytes = 5 if args.obs_format == 'u16mm' else OBS_BYTES   # c = 5 B/obs for config 5
-    launch_obs = sum(r.n_obs() for r in group_restos) if group_restos is not None else n_obs   # observations one launch streams
-    launch_images = len(group_restos) if group_restos is not None else 1
+    # observations one launch streams: a shared-water group's, a --fit-batch chunk's, or the one image's
+    launch_obs = (sum(r.n_obs() for r in group_restos) if group_restos is not None
+                  else sum(r.n_obs() for r in slots[0][:B]) if B > 1 else n_obs)
+    launch_images = len(group_restos) if group_restos is not None else B
     algo_bytes = (obs_bytes + (12 if args.light_model else 0)) * launch_obs + state_bytes * launch_images  # A_fit / T
     achieved = algo_bytes / (iter_ms * 1e-3) / 1e9
     # What the store really holds: an 'f32' store whose ranges fit is kept as 24-bit codes by the device's own
@@ -477,6 +512,8 @@ def main():
         tag = f'shared{args.batch_images}'
     else:
         tag = ('light_closed' if args.use_closed_form else 'light') if args.light_model else ('closed' if args.use_closed_form else 'jparam')
+        if B > 1:
+            tag += f'_batch{B}'
         if args.obs_format == 'u16mm':
             tag = 'u16mm_4k' if (tag, W, H) == ('jparam', 3840, 2160) else tag + '_u16mm'
     traffic = prof = None
@@ -510,7 +547,7 @@ def main():
 
     if rank == 0:
         kernel = ('group_iter_kernel' if group_restos is not None else 'light_grad_kernel' if args.light_model
-                  else 'fit_closed_kernel' if args.use_closed_form else 'fit_grad_kernel')
+                  else 'batch_iter_kernel' if B > 1 else 'fit_closed_kernel' if args.use_closed_form else 'fit_grad_kernel')
         roof = {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'frac_is': 'ALGORITHMIC work rate: SURVEY 8(d) bytes (7 B/obs at configs 1-4, 5 B at config 5, +12 B light model, + state) '
@@ -551,7 +588,7 @@ def main():
                                       else ', per-image water parameters (no collective)'),
                        'baseline_config': baseline_config(args),
                        'workspace_bytes_per_rank': workspace_bytes,
-                       'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S,
+                       'n_obs': n_obs, 'mean_cover': float(cover.mean()), 'images_in_flight': S, 'fit_batch': B,
                        'images_per_s_per_gpu': args.steps * len(jobs) / elapsed, 'fit_ms_alone': fit_ms,
                        'ms_per_image': elapsed / args.steps / len(jobs) * 1e3,
                        'ms_per_image_per_rank': {'min': min(per_rank), 'max': max(per_rank), 'all': per_rank},
