@@ -84,7 +84,7 @@ def parse():
 
 # BASELINE.json "configs", by their 1-based position
 CONFIG_PRESETS = {
-    1: dict(width=640, height=480, neighbours=4),
+    1: dict(width=640, height=480, neighbours=4, fit_batch=32),   # small images: 32 consecutive steps share one launch per iteration
     2: dict(),
     3: dict(batch_images=32),
     4: dict(shared_water=True, batch_images=64),
@@ -96,7 +96,7 @@ def baseline_config(args):
     """The BASELINE.json configuration (1-based) the flags amount to, or None for any other workload."""
     for number, preset in CONFIG_PRESETS.items():
         want = dict(width=1920, height=1080, neighbours=64, batch_images=1, shared_water=False, obs_format='f32')
-        want.update(preset)
+        want.update({k: v for k, v in preset.items() if k != 'fit_batch'})   # (how the steps are launched does not change the workload)
         if all(getattr(args, k) == v for k, v in want.items()) and not args.light_model:
             return number
     return None
@@ -584,6 +584,7 @@ def main():
                                    + ('closed-form J' if args.use_closed_form else 'J as parameter')
                                    + (', artificial-light model' if args.light_model else '')
                                    + (', compact observations (u16 mm ranges, 5 B/obs)' if args.obs_format == 'u16mm' else '')
+                                   + (f', {B} consecutive images per fit launch (independent fits, sucre_fit_run_batch)' if B > 1 else '')
                                    + (', shared water parameters (1 all-reduce/iteration)' if args.shared_water
                                       else ', per-image water parameters (no collective)'),
                        'baseline_config': baseline_config(args),

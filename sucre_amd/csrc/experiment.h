@@ -88,3 +88,12 @@ constexpr int kExpPrio = SUCRE_EXP_PRIO;
 #ifndef SUCRE_DEAL_CLOSED
 #define SUCRE_DEAL_CLOSED 64, 64, 64, 64
 #endif
+
+// fit.hip batch_iter_kernel, timing only (results meaningless): where an image's ~14 us inside a batch launch of 640x480 images
+// go.  1: no last-arriver tail (the workgroup's partial is stored, nobody reduces or steps); 2: no pass (every wave is told it
+// has no strip: the hand-in chain alone); 3: the hand-in without its barriers and atomics (partial store only, as 1, and no
+// wave sums).  tools/exp/batch_ablation.sh.
+#ifndef SUCRE_EXP_BATCH
+#define SUCRE_EXP_BATCH 0
+#endif
+constexpr int kExpBatch = SUCRE_EXP_BATCH;

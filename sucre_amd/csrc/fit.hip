@@ -465,7 +465,35 @@ __device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t
 // One STEP per item: wait for the LDS reads of the item whose slot is about to be overwritten, issue item i + kAhead into
 // it, fetch the descriptor of item i + kAhead + 1 (scalar load, used one step later), wait for item i.  The wait is an
 // immediate: vmcnt(2 kAhead), or vmcnt(2 kAhead + kStores) for the first kAhead items behind a strip's stores.
-template <int kFmt, int kStores, bool kMoments, class OnJ, class OnChunk, class OnTail, class OnEnd>
+// One item -> ring slot at byte offset slot_off of the wave's ring.
+template <int kFmt>
+__device__ __forceinline__ void issue_item(const ItemRegs it, uint32_t ring0, uint32_t slot_off, const uint8_t *__restrict__ ws, int lane, bool z24) {
+    // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch)
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t voffB_full = (64u + min((uint32_t)lane, (z24 ? full_chunk_b(kStoreZ24) : full_chunk_b(kFmt)) - 1u)) * 16u;
+    const uint8_t *src = ws + ((uint64_t)it.x << 6);
+    const uint32_t slot = ring0 + slot_off;
+    if (it.y & kShapeFull) {
+        dma_item(src, slot, slot + 1024u, lane16, voffB_full);
+    } else {
+        const uint32_t a_last = it.y & 127u, b_last = (it.y >> 8) & 127u, b_base = (it.y >> 16) & 127u;
+        dma_item(src, slot, slot + ((a_last + 1u) << 4), min((uint32_t)lane, a_last) << 4, (b_base + min((uint32_t)lane, b_last)) << 4);
+    }
+}
+
+// The first kAhead items of a wave's stream on their own (batch launches issue the NEXT image's while the workgroup is still
+// handing in this image's sums; stream_strips<..., kPrimed = true> then starts behind them).  The wave's ring must be idle.
+template <int kFmt>
+__device__ __forceinline__ void prime_stream(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t K, const uint8_t *__restrict__ ws, int wave,
+                                             int lane, bool z24) {
+    if (K == 0) return;
+    const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
+    const ConstItems items = const_items(plan);
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) issue_item<kFmt>(items[q], ring0, (uint32_t)(q * kSlot), ws, lane, z24);
+}
+
+template <int kFmt, int kStores, bool kMoments, bool kPrimed = false, class OnJ, class OnChunk, class OnTail, class OnEnd>
 __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
                                               uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, bool z24, OnJ on_J,
                                               OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
@@ -474,22 +502,12 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
     const uint8_t *ringp = &lds.ring[wave][0][0];
     const ConstItems items = const_items(plan);
     const ConstItems strips = const_items(strip_list);
-    // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch)
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    const uint32_t voffB_full = (64u + min((uint32_t)lane, (z24 ? full_chunk_b(kStoreZ24) : full_chunk_b(kFmt)) - 1u)) * 16u;
-    auto issue = [&](const ItemRegs it, uint32_t slot_off) {
-        const uint8_t *src = ws + ((uint64_t)it.x << 6);
-        const uint32_t slot = ring0 + slot_off;
-        if (it.y & kShapeFull) {
-            dma_item(src, slot, slot + 1024u, lane16, voffB_full);
-        } else {
-            const uint32_t a_last = it.y & 127u, b_last = (it.y >> 8) & 127u, b_base = (it.y >> 16) & 127u;
-            dma_item(src, slot, slot + ((a_last + 1u) << 4), min((uint32_t)lane, a_last) << 4, (b_base + min((uint32_t)lane, b_last)) << 4);
-        }
-    };
+    auto issue = [&](const ItemRegs it, uint32_t slot_off) { issue_item<kFmt>(it, ring0, slot_off, ws, lane, z24); };
     // the first kAhead items (a wave with a strip has at least 1 + kAhead + 1 entries: its items, the trailing ones, the spare)
+    if (!kPrimed) {
 #pragma unroll
-    for (int q = 0; q < kAhead; ++q) issue(items[q], (uint32_t)(q * kSlot));
+        for (int q = 0; q < kAhead; ++q) issue(items[q], (uint32_t)(q * kSlot));
+    }
     ItemRegs nxt = items[kAhead];      // item i + kAhead, issued at the top of step i
     uint32_t i = 0;                    // the item being consumed
     uint32_t cs = 0u;                  // byte offset of its slot in the wave's ring; item i + kAhead goes to the slot before it
@@ -682,12 +700,12 @@ __device__ __forceinline__ void finish_from_wave_sums(FitLds &lds, float *partia
 
 // One wave's share of a J-parameter iteration on one image (sucre.py:142-148 with J among the parameters): streams
 // the wave's items, steps J of every strip, and keeps adding the lane's shares of the global sums to acc / sBeta.
-template <int kFmt>
+template <int kFmt, bool kPrimed = false>
 __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                           const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
                                           const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3], const RangeCodes &rc) {
     float J[3] = {0.f, 0.f, 0.f};
-    stream_strips<kFmt, 9, true>(
+    stream_strips<kFmt, 9, true, kPrimed>(
         lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
@@ -783,13 +801,13 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
 // SUCRe.update_J alone (sucre.py:66-77, 156): J = sum (I - b) a / sum a^2 from the current parameters, nothing else.
 struct ClosedSums { float sB[3], sGZ[3], sBeta[3], cost; };
 
-template <int kFmt, bool kJOnly>
+template <int kFmt, bool kJOnly, bool kPrimed = false>
 __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                             const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
                                             const Water &w, bool fmt_ok, ClosedSums &cs, const RangeCodes &rc) {
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
-    stream_strips<kFmt, 3, false>(
+    stream_strips<kFmt, 3, false, kPrimed>(
         lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
@@ -1041,12 +1059,12 @@ __global__ __launch_bounds__(64) void group_init_kernel(GroupHeader *g, const Pa
 // Independent images in ONE launch per iteration (the reference's per-image mode, sucre.py:243-261: every image has its own
 // B, beta, gamma, J and its own Adam state; nothing is shared).  A launch per image and iteration is what a small image pays
 // for most: at 640x480 x 5 views (BASELINE config 1) a launch moves 31 MB and lasts 17 us, 0.24 of the HBM peak, each wave with
-// less than one strip to work on.  Here every wave walks its item list of image 0, then of image 1, ...; after each image the
-// workgroup leaves its partial in THAT image's workspace and arrives on THAT image's tickets, so the image's last arriver
-// reduces its sums, steps its nine parameters and writes its log row while everybody else is already streaming the next
-// image: the launch gap, the ramp-up and the reduction tail are paid once per launch instead of once per image.  Every image
-// sees exactly the operations of its own fit_grad_kernel / fit_closed_kernel launch in the same order (same plan, same
-// grid, same reduction tree), so its results are the bits of fitting it alone (tests/test_gpu_batch.py).
+// less than one strip to work on.  Here every wave walks its item list of image 0, then of image 1, ... by itself (no barrier
+// between images; the next image's first items are in flight while the wave adds up this image's sums), the workgroup leaves
+// its partial of EVERY image at the launch's end, and a second small launch reduces and steps all images at once: the launch
+// gap, the ramp-up and the reduction tail are paid once per batch instead of once per image.  Every image sees exactly the
+// operations of its own fit_grad_kernel / fit_closed_kernel launch in the same order (same plan, same grid, same reduction
+// tree), so its results are the bits of fitting it alone (tests/test_gpu_batch.py).
 // All images of a batch have one size (H, W: one grid); their view counts -- hence their workspace layouts -- may differ.
 // ---------------------------------------------------------------------------------------------------------------
 struct BatchOffsets {
@@ -1056,49 +1074,210 @@ struct BatchOffsets {
 };
 struct BatchEntry { uint8_t *ws; double *trace; BatchOffsets o; };   // trace: the image's (T, 10) log, or NULL
 
+// The launch's end, once for ALL its images (what finish_from_wave_sums does per launch): the waves' sums of every image wait
+// in LDS and the workgroup stores its partial of every image when it has walked them all.  A second, small launch
+// (batch_tail_kernel) then reduces them in two levels and steps every image's parameters, ONE THREAD per (image, quantity):
+// the single-thread forms below add the same numbers in the same association as reduce_group / reduce_total's shuffle
+// trees, so an image's bits are those of its own launch.
+// (Handing every image in by itself, its own arrival chain behind its own pass, cost 5.6 of an image's 14 us at 640x480 --
+// the workgroup has nothing in flight while its stores drain and its arrival returns; tools/exp/batch_ablation.sh.)
+constexpr int kBatchMax = 32;   // images per launch (their waves' sums wait in 5 KB of LDS)
+static_assert((kFitGrid + kGroup - 1) / kGroup <= 64 && (kClosedGrid + kGroup - 1) / kGroup <= 64, "reduce_total_thread: one group per lane");
+
+struct BatchLds {
+    FitLds fit;
+    float wsum[kBatchMax][4][kNumSums];
+};
+
+// wave_sum_fixed's tree as ONE thread adds it: lane 0 of the tree ends up with, level by level, v[l] + v[l + off] for off = 32,
+// 16, ... 1 -- the same additions in the same association, so the same bits (zeros included: x + 0.0 is not always x).
+template <int kOff, class F>
+__device__ __forceinline__ double tree_node(F &v, int l) {
+    if constexpr (kOff == 64) return v(l);
+    else return tree_node<2 * kOff>(v, l) + tree_node<2 * kOff>(v, l + kOff);   // lane l at this level: its own sum + lane l + off's
+}
+template <class F>
+__device__ __forceinline__ double tree_sum64(F v) { return tree_node<1>(v, 0); }
+
+// reduce_group for one (image, quantity) by one thread.
+__device__ __forceinline__ void reduce_group_thread(const float *partials, int n_blocks, int g, int q, double *gpart, int n_groups) {
+    const float *row = partials + (size_t)q * n_blocks + (size_t)g * kGroup;
+    const int have = min(kGroup, n_blocks - g * kGroup);
+    static_assert(kGroup == 32, "the lanes beyond the group hold zeros in reduce_group");
+    const double y = tree_sum64([&](int l) {
+        return (l < kGroup && l < have) ? (double)__hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    });
+    __hip_atomic_store(gpart + (size_t)q * n_groups + g, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// reduce_total for one (image, quantity) by one thread: lane l's running sum over the groups l, l + 64, ..., then the tree.
+__device__ __forceinline__ double reduce_total_thread(const double *gpart, int n_groups, int q) {
+    const double *row = gpart + (size_t)q * n_groups;   // (n_groups <= 64: kFitGrid / kGroup = 40; lane l's loop has one turn at most)
+    return tree_sum64([&](int l) {
+        double x = 0.0;
+        if (l < n_groups) x += __hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return x;
+    });
+}
+
+// What a wave needs to know of one image of the batch.  Everything is read through the constant address space (scalar loads
+// the compiler tracks itself; nothing of it is written during the launch: the parameters are stepped by the tail launch), and
+// the NEXT image's is asked for before this image's pass, so that no wave waits for a chain of dependent loads between two
+// images (measured: 2.2 us per image with nothing else to do, tools/exp/batch_ablation.sh).
+template <class T>
+__device__ __forceinline__ T cload(const void *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+struct BatchView {
+    uint8_t *ws;
+    const PlanItem *plan;
+    const StripEntry *strips;
+    float *state;
+    uint32_t n_mine;
+    RangeCodes rc;
+    bool fmt_ok;
+    Water w;
+    float gscale;
+};
+
+template <int kFmt>
+__device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ images, int i, uint32_t wid) {
+    BatchView v;
+    const BatchEntry *e = uniform_ptr(images + i);
+    v.ws = cload<uint8_t *>(&e->ws);
+    const uint64_t o_format = cload<uint64_t>(&e->o.format), o_count = cload<uint64_t>(&e->o.count), o_plan = cload<uint64_t>(&e->o.plan),
+                   o_strips = cload<uint64_t>(&e->o.strips), o_params = cload<uint64_t>(&e->o.params), o_n = cload<uint64_t>(&e->o.n_obs_total),
+                   o_state = cload<uint64_t>(&e->o.state);
+    const uint32_t stride = cload<uint32_t>(&e->o.stride), kmax = cload<uint32_t>(&e->o.kmax);
+    const uint32_t f0 = cload<uint32_t>(v.ws + o_format), f1 = cload<uint32_t>(v.ws + o_format + 4);
+    v.rc.z24 = f0 == (uint32_t)kStoreZ24;
+    v.rc.zoff = f1;
+    v.fmt_ok = kFmt == kStoreU16 ? f0 == (uint32_t)kStoreU16 : (f0 == (uint32_t)kStoreF32 || f0 == (uint32_t)kStoreZ24);
+    v.n_mine = v.fmt_ok ? cload<uint32_t>(v.ws + o_count + 4ull * wid) : 0u;
+    if (kExpBatch == 2) v.n_mine = 0u;
+    v.plan = reinterpret_cast<const PlanItem *>(v.ws + o_plan) + (size_t)wid * stride;
+    v.strips = reinterpret_cast<const StripEntry *>(v.ws + o_strips) + (size_t)wid * kmax;
+    v.state = reinterpret_cast<float *>(v.ws + o_state);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {   // load_water, from scalar loads
+        v.w.B[c] = cload<float>(v.ws + o_params + 4 * c);
+        v.w.nb[c] = -cload<float>(v.ws + o_params + 4 * (3 + c)) * kLog2e;
+        v.w.ng[c] = -cload<float>(v.ws + o_params + 4 * (6 + c)) * kLog2e;
+    }
+    v.gscale = -2.0f * ((1.0f / 3.0f) / (float)cload<uint64_t>(v.ws + o_n));
+    return v;
+}
+
 template <int kMode, int kFmt>
 __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
                                                                                            const AdamCoef co, int row) {
-    __shared__ FitLds lds;
+    __shared__ BatchLds blds;
+    FitLds &lds = blds.fit;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    // Every wave walks the images by itself -- no barrier between them: its ten sums of an image go to LDS and the next
+    // image's first items are already in flight.
+    BatchView v = batch_view<kFmt>(images, 0, wid);
+    prime_stream<kFmt>(lds, v.plan, v.n_mine, v.ws, wave, lane, v.rc.z24);
     for (int i = 0; i < n_images; ++i) {
-        uint8_t *ws = uniform_ptr(images[i].ws);   // between images nothing of this wave is in flight: ordinary loads are harmless
-        double *trace = uniform_ptr(images[i].trace);
-        const BatchOffsets &o = images[i].o;
-        float *pstate = reinterpret_cast<float *>(ws + o.params);
-        const uint64_t *n_obs_total = reinterpret_cast<const uint64_t *>(ws + o.n_obs_total);
-        const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + o.format);
-        const Water w = load_water_uniform(pstate);
-        const RangeCodes rc = range_codes(store_fmt);
-        const bool fmt_ok = store_matches<kFmt>(store_fmt);
-        const uint32_t n_mine = fmt_ok ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + o.count)[wid]) : 0u;
-        const PlanItem *plan = uniform_ptr(reinterpret_cast<const PlanItem *>(ws + o.plan) + (size_t)wid * o.stride);
-        const StripEntry *strips = uniform_ptr(reinterpret_cast<const StripEntry *>(ws + o.strips) + (size_t)wid * o.kmax);
-        float *state = reinterpret_cast<float *>(ws + o.state);
+        BatchView vn = v;
+        if (i + 1 < n_images) vn = batch_view<kFmt>(images, i + 1, wid);   // on its way while this image is walked
         float s[kNumSums];
         if (kMode == 0) {
-            const float gscale = uniform_f(-2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total)));
             Acc acc;
             zero_acc(acc);
-            if (!fmt_ok) acc.cost = __builtin_nanf("");
+            if (!v.fmt_ok) acc.cost = __builtin_nanf("");
             float sBeta[3] = {0.f, 0.f, 0.f};
-            grad_pass<kFmt>(lds, plan, strips, n_mine, ws, state, wave, lane, w, gscale, co, acc, sBeta, rc);
+            grad_pass<kFmt, true>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.gscale, co, acc, sBeta, v.rc);
             const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
         } else {
-            ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, fmt_ok ? 0.f : __builtin_nanf("")};
-            closed_pass<kFmt, false>(lds, plan, strips, n_mine, ws, state, wave, lane, w, fmt_ok, cs, rc);
+            ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, v.fmt_ok ? 0.f : __builtin_nanf("")};
+            closed_pass<kFmt, false, true>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.fmt_ok, cs, v.rc);
             const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
         }
-        finish_launch<true>(lds, s, reinterpret_cast<float *>(ws + o.partials), co, reinterpret_cast<unsigned *>(ws + o.ticket),
-                            reinterpret_cast<double *>(ws + o.gpart), o.n_groups, reinterpret_cast<double *>(ws + o.sums), pstate, n_obs_total,
-                            trace ? trace + (size_t)row * 10 : nullptr);
+        if (i + 1 < n_images) {   // the wave's ring is idle: the pass has consumed its last item and drained its trailing ones
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            prime_stream<kFmt>(lds, vn.plan, vn.n_mine, vn.ws, wave, lane, vn.rc.z24);
+        }
+        wave_sums(s);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < kNumSums; ++q) blds.wsum[i][wave][q] = s[q];
+        }
+        v = vn;
+    }
+    // ---- the launch's end: the workgroup's partial of every image, the four waves in fixed order ----
+    const int n_blocks = gridDim.x;
+    __syncthreads();
+    for (int idx = t; idx < n_images * kNumSums; idx += 256) {
+        const int i = idx / kNumSums, q = idx - i * kNumSums;
+        float *partials = reinterpret_cast<float *>(images[i].ws + images[i].o.partials);
+        __hip_atomic_store(partials + (size_t)q * n_blocks + blockIdx.x,
+                           ((blds.wsum[i][0][q] + blds.wsum[i][1][q]) + blds.wsum[i][2][q]) + blds.wsum[i][3][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ... and the second launch of a batch iteration: one workgroup per reduction group.  Thread (image, quantity) -- sixteen
+// threads to an image, sixteen images to a round -- adds its group's partials; the workgroup that arrives last takes every
+// image's total, its step on B, beta, gamma and its log row.  (As the tail of the launch above these trees wanted more
+// registers than its waves have: the kernel spilled.)
+__global__ __launch_bounds__(256) void batch_tail_kernel(const BatchEntry *__restrict__ images, int n_images, int n_blocks, const AdamCoef co, int row) {
+    __shared__ double stot[16][kNumSums];
+    __shared__ int is_last;
+    const int t = threadIdx.x, g = blockIdx.x, n_groups = gridDim.x;
+    for (int i0 = 0; i0 < n_images; i0 += 16) {
+        const int i = i0 + (t >> 4), q = t & 15;
+        if (i < n_images && q < kNumSums)
+            reduce_group_thread(reinterpret_cast<const float *>(images[i].ws + images[i].o.partials), n_blocks, g, q,
+                                reinterpret_cast<double *>(images[i].ws + images[i].o.gpart), n_groups);
+    }
+    if (kExpBatch == 1) return;   // (timing experiment, experiment.h)
+    unsigned *ticket = reinterpret_cast<unsigned *>(images[0].ws + images[0].o.ticket);   // the batch's arrival counter: the first image's
+    if (!arrive_last(ticket, (unsigned)n_groups, &is_last)) return;
+    for (int i0 = 0; i0 < n_images; i0 += 16) {
+        const int i = i0 + (t >> 4), q = t & 15, ii = t >> 4;
+        const bool mine = i < n_images && q < kNumSums;
+        uint8_t *ws = mine ? images[i].ws : nullptr;
+        if (mine) {
+            const BatchOffsets &o = images[i].o;
+            const double y = reduce_total_thread(reinterpret_cast<const double *>(ws + o.gpart), n_groups, q);
+            __hip_atomic_store(reinterpret_cast<double *>(ws + o.sums) + q, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stot[ii][q] = y;
+        }
+        __syncthreads();
+        // water_step (sucre.py:148-152), thread q of an image in the role of lane q
+        float p = 0.f, m = 0.f, v = 0.f;
+        double grad = 0.0;
+        float *pstate = nullptr;
+        if (mine && q < 9) {
+            const BatchOffsets &o = images[i].o;
+            pstate = reinterpret_cast<float *>(ws + o.params);
+            const float scale = (1.0f / 3.0f) / (float)(*reinterpret_cast<const uint64_t *>(ws + o.n_obs_total));
+            const int c = q % 3;
+            if (q < 3) grad = -2.0 * (double)scale * stot[ii][c];
+            else if (q < 6) grad = 2.0 * (double)scale * stot[ii][6 + c];
+            else grad = -2.0 * (double)scale * (double)pstate[c] * stot[ii][3 + c];   // B before its step
+            p = pstate[q]; m = pstate[9 + q]; v = pstate[18 + q];
+        }
+        __syncthreads();   // every B of the round is read before any is overwritten
+        if (mine) {
+            double *trace = images[i].trace;
+            if (q < 9) {
+                adam_update(p, m, v, (float)grad, co);
+                pstate[q] = p; pstate[9 + q] = m; pstate[18 + q] = v;
+                if (trace) trace[(size_t)row * 10 + 1 + q] = (double)p;
+            } else if (trace) {
+                trace[(size_t)row * 10] = stot[ii][9];
+            }
+        }
+        __syncthreads();   // the round's totals are spent before the next round's arrive
     }
 }
 
@@ -1296,13 +1475,17 @@ hipError_t launch_batch_iter(const Layout &L, void *batch, int n_images, const A
     const int mode = (flags & SUCRE_FIT_CLOSED_FORM) ? 1 : 0;
     const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
     const dim3 grid(L.fit_blocks[mode]), block(256);
-    auto *b = static_cast<const BatchEntry *>(batch);
-    if (mode) {
-        if (u16) hipLaunchKernelGGL((batch_iter_kernel<1, 1>), grid, block, 0, s, b, n_images, co, row);
-        else hipLaunchKernelGGL((batch_iter_kernel<1, 0>), grid, block, 0, s, b, n_images, co, row);
-    } else {
-        if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n_images, co, row);
-        else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n_images, co, row);
+    for (int i0 = 0; i0 < n_images; i0 += kBatchMax) {   // at most kBatchMax images per launch (their sums wait in LDS)
+        auto *b = static_cast<const BatchEntry *>(batch) + i0;
+        const int n = n_images - i0 < kBatchMax ? n_images - i0 : kBatchMax;
+        if (mode) {
+            if (u16) hipLaunchKernelGGL((batch_iter_kernel<1, 1>), grid, block, 0, s, b, n, co, row);
+            else hipLaunchKernelGGL((batch_iter_kernel<1, 0>), grid, block, 0, s, b, n, co, row);
+        } else {
+            if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n, co, row);
+            else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n, co, row);
+        }
+        hipLaunchKernelGGL(batch_tail_kernel, dim3(L.fit_groups[mode]), block, 0, s, b, n, L.fit_blocks[mode], co, row);
     }
     return hipGetLastError();
 }
