@@ -625,6 +625,7 @@ def test_experiment_variants_compile(tmp_path):
         'tlight1': '-DSUCRE_EXP_LIGHT_WATER_PASS1 -DSUCRE_EXP_NOCOMPUTE',
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
+        'tbatch': '-DSUCRE_EXP_BATCH=2',
     }
     objects = {'texactdiv': 'match', 'tlight1': 'light', 'tlight2': 'light', 'tscatter': 'compact'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here
