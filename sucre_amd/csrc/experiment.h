@@ -85,8 +85,13 @@ constexpr int kExpPrio = SUCRE_EXP_PRIO;
 #ifndef SUCRE_DEAL_FIT
 #define SUCRE_DEAL_FIT 64, 64, 64, 64, 64
 #endif
+// The closed-form kernel (four generations, instruction-bound) takes the unequal deal as its product default (round 5): alone a
+// launch takes 140.8-142.3 instead of 148.4 us (same box, tools/exp/ab_vs.sh; 0.51 instead of 0.49 of the HBM peak by SURVEY
+// 8(d)'s bytes) and an image restored alone 29.4 instead of 30.9 ms; with two images in flight 75.6-75.9 against 75.9 Mpix/s --
+// unlike the J-parameter kernel it loses nothing there.  (64,54,44,34: 143.5 us; 64,44,28,12: 139-140 us alone but 75.0 Mpix/s
+// in flight; 64,56,40,24: 140.9.)
 #ifndef SUCRE_DEAL_CLOSED
-#define SUCRE_DEAL_CLOSED 64, 64, 64, 64
+#define SUCRE_DEAL_CLOSED 64, 48, 32, 20
 #endif
 
 // fit.hip batch_iter_kernel, timing only (results meaningless): where an image's ~14 us inside a batch launch of 640x480 images

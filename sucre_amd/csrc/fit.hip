@@ -1427,7 +1427,12 @@ hipError_t launch_plan(const Layout &L, uint8_t *ws, hipStream_t s) {
     auto *meta = reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta);
     const uint32_t W0 = (uint32_t)L.fit_blocks[0] * 4u, W1 = (uint32_t)L.fit_blocks[1] * 4u;
     const uint32_t Wmax = W0 < W1 ? W1 : W0;
-    const uint32_t Kmax = (uint32_t)(L.plan_kmax[0] > L.plan_kmax[1] ? L.plan_kmax[0] : L.plan_kmax[1]);   // strips of the busiest wave (of either mode)
+    // Thread (wave, k) writes the items of the wave's k-th strip: ~17 scattered 8-byte stores.  A wave of the launch holds the
+    // threads of 64 / Kmax fit waves; with every lane active each of its store instructions touches 64 cache lines, and the
+    // kernel's time is those instructions (32 us per image at Kmax = 8 against 9 us at 32 slots per fit wave, most of them
+    // idle): the threads are spread so that at most a quarter of a wave's lanes write.
+    uint32_t Kmax = (uint32_t)(L.plan_kmax[0] > L.plan_kmax[1] ? L.plan_kmax[0] : L.plan_kmax[1]);   // strips of the busiest wave (of either mode)
+    if (Kmax < 32u) Kmax = 32u;   // thread slots per fit wave (k >= the wave's strip count: nothing to do)
     hipLaunchKernelGGL(plan_kernel, dim3((Wmax * Kmax + 255u) / 256u, 2), dim3(256), 0, s, meta, L.n_strips,
                        reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2, W0, W1, Kmax,
                        (uint32_t)L.plan_stride[0], (uint32_t)L.plan_stride[1], (uint32_t)L.plan_kmax[0], (uint32_t)L.plan_kmax[1],

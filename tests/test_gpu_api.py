@@ -816,6 +816,7 @@ def test_in_flight_slot_is_per_thread_and_a_returned_workspace_knows_its_streams
     included, so that its next owner waits for exactly that work (return_restoration may run from a finalizer on any thread)."""
     import threading
     from sucre_amd import engine
+    engine.release_pool()   # no idle workspace of an earlier test on the free list
     seen = {}
     gate, done = threading.Event(), threading.Event()
 
