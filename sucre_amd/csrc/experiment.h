@@ -102,3 +102,21 @@ constexpr int kExpPrio = SUCRE_EXP_PRIO;
 #define SUCRE_EXP_BATCH 0
 #endif
 constexpr int kExpBatch = SUCRE_EXP_BATCH;
+
+// fit.hip, closed-form kernel: a chunk's 24 exponentials in two batches of twelve (two levels each) instead of one of 24 --
+// twelve registers fewer in flight, which is what the kernel lacks to fit five waves per SIMD (SUCRE_CLOSED_WAVES=5).
+// Measured (round 5, same box, tools/exp/ab_vs.sh, config 2, launch alone): product 146.5-147.9 us; two batches at 4 waves per
+// SIMD 152-153; at 5 waves with the unequal deal 150.5; at 5 waves with equal shares 158-160.  Neither the smaller batches nor
+// the fifth wave pays: the 24 exponentials back to back at four waves stay.
+#ifdef SUCRE_EXP_HALF_EXPS
+constexpr bool kExpHalfExps = true;
+#else
+constexpr bool kExpHalfExps = false;
+#endif
+// ... and for such occupancy experiments the closed-form instantiation of batch_iter_kernel (which needs more registers than
+// five waves leave) compiled to nothing.
+#ifdef SUCRE_EXP_NO_BATCH_CLOSED
+constexpr bool kExpNoBatchClosed = true;
+#else
+constexpr bool kExpNoBatchClosed = false;
+#endif

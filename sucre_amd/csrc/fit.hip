@@ -193,6 +193,32 @@ __device__ __forceinline__ void accumulate_chunk(const float (&zz)[kGroupLv], co
         acc.q[8][0] += (zz[0] + zz[1]) + (zz[2] + zz[3]) + (float)(cc[0] ^ cc[1] ^ cc[2]);
         return;
     }
+    if (kExpHalfExps) {   // (experiment.h: the chunk's exponentials in two batches of twelve -- twelve registers fewer in flight)
+#pragma unroll
+        for (int h = 0; h < kGroupLv; h += 2) {
+            float ea[2][3], eg[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ea[j][c] = zz[h + j] * w.nb[c]; eg[j][c] = zz[h + j] * w.ng[c]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { ea[j][c] = fast_exp2(ea[j][c]); eg[j][c] = fast_exp2(eg[j][c]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float z = zz[h + j];
+                const bool valid = !kMasked || z > 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    closed_terms(z, ea[j][c], eg[j][c], (cc[c] >> (8 * (h + j))) & 255u, valid, w.B[c], Jp[c], acc.q[0][c], acc.q[1][c],
+                                 acc.q[2][c], acc.q[3][c], acc.q[4][c], acc.q[5][c], acc.q[6][c], acc.q[7][c], acc.q[8][c]);
+            }
+        }
+        return;
+    }
     Exps e;
     chunk_exps(zz, w, e);
 #pragma unroll
@@ -876,7 +902,7 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const Water w = load_water(pstate);
+    const Water w = load_water_uniform(pstate);   // scalar registers: the 27 accumulators need the vector ones
     const RangeCodes rc = range_codes(obs_format);
     const bool fmt_ok = store_matches<kFmt>(obs_format);
     // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
@@ -972,7 +998,7 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_i
         }
     }
     __syncthreads();
-    const Water w = load_water(wpar);
+    const Water w = load_water_uniform(wpar);
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)n_obs_total);
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     Acc acc;
@@ -1172,6 +1198,7 @@ __device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ i
 template <int kMode, int kFmt>
 __global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
                                                                                            const AdamCoef co, int row) {
+    if (kExpNoBatchClosed && kMode == 1) return;   // (experiment.h: occupancy experiments on the closed-form kernel alone)
     __shared__ BatchLds blds;
     FitLds &lds = blds.fit;
     const int t = threadIdx.x;

@@ -626,6 +626,7 @@ def test_experiment_variants_compile(tmp_path):
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
         'tbatch': '-DSUCRE_EXP_BATCH=2',
+        'thalf': '-DSUCRE_EXP_HALF_EXPS -DSUCRE_CLOSED_WAVES=5 -DSUCRE_EXP_NO_BATCH_CLOSED -DSUCRE_DEAL_CLOSED=64,48,32,20,10',
     }
     objects = {'texactdiv': 'match', 'tlight1': 'light', 'tlight2': 'light', 'tscatter': 'compact'}   # the source a knob lives in (default: fit)
     for macro in re.findall(r'#\s*if(?:n?def)\s+(SUCRE_[A-Z_0-9]+)', header):   # every knob of the header is exercised here
