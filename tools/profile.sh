@@ -6,8 +6,8 @@
 # the SQ counters.  tools/summarize_prof.py condenses them into profiles/<tag>_<mode>_{kernel_stats.csv,traffic.json,
 # summary.txt}; raw per-dispatch dumps stay on the box.
 set -u
-TAG=${1:-r04}; shift || true
-MODES=${*:-"jparam jparam_inflight2 closed light light_closed u16mm_4k shared4"}
+TAG=${1:-r05}; shift || true
+MODES=${*:-"jparam jparam_inflight2 closed light light_closed u16mm_4k shared4 jparam_batch32"}
 export TMPDIR=/tmp
 mode_args() {
   case $1 in
@@ -18,6 +18,7 @@ mode_args() {
     light_closed) echo "--light-model --use-closed-form" ;;
     u16mm_4k) echo "--width 3840 --height 2160 --neighbours 256 --obs-format u16mm" ;;
     shared4) echo "--shared-water --batch-images 4" ;;
+    jparam_batch32) echo "--config 1" ;;   # BASELINE config 1 (640x480, 4 neighbours), 32 consecutive images per fit launch
     *) echo "unknown mode $1" >&2; exit 2 ;;
   esac
 }
@@ -37,11 +38,13 @@ for MODE in $MODES; do
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
   else
     STEPS="--steps 2 --warmup 1"; [ $MODE = u16mm_4k ] && STEPS="--steps 1 --warmup 1 --solo-images 1"
+    [ $MODE = jparam_batch32 ] && STEPS="--steps 64 --warmup 32"
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $STEPS --no-cpu-baseline --images-in-flight 1 $M > $OUT/bench_trace.log 2>&1
     PMC="--steps 1 --warmup 0 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M"
     # (shared4: with --warmup 0 bench.py's set-up pass fits ONE image through the group kernel; --warmup 1 skips it, so that
     # every group_iter_kernel dispatch in the averages walks all four images)
     [ $MODE = shared4 ] && PMC="--steps 1 --warmup 1 --no-cpu-baseline --images-in-flight 1 --num-iter 10 $M"
+    [ $MODE = jparam_batch32 ] && PMC="--steps 32 --warmup 32 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M"
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > $OUT/bench_pmc_fetch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > $OUT/bench_pmc_sq.log 2>&1

@@ -19,7 +19,7 @@ dest = root / 'summaries'
 dest.mkdir(exist_ok=True)
 DOMINANT = {'jparam': 'fit_grad_kernel<true, 0>', 'jparam_inflight2': 'fit_grad_kernel<true, 0>', 'closed': 'fit_closed_kernel<true, 0, false>',
             'light': 'light_grad_kernel<false, false', 'light_closed': 'light_grad_kernel<true, false', 'u16mm_4k': 'fit_grad_kernel<true, 1>',
-            'shared4': 'group_iter_kernel<0, 0>'}
+            'shared4': 'group_iter_kernel<0, 0>', 'jparam_batch32': 'batch_iter_kernel<0, 0>'}
 MATCH_STAGE = ('match_kernel', 'view_partial_kernel', 'view_total_kernel', 'pixel_count_kernel', 'bin_scan_kernel',
                'permute_kernel', 'strip_table_kernel', 'strip_levels_kernel', 'tile_offset_kernel', 'strip_offset_kernel',
                'scatter_kernel', 'plan_kernel')
