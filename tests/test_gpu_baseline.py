@@ -64,6 +64,31 @@ def test_config1_in_full_engine_vs_reference():
 
 
 @pytest.mark.timeout(900)
+def test_config1_in_full_through_the_batch_launch_vs_reference():
+    """BASELINE config 1 against the reference itself once more, through ``sucre_fit_run_batch`` (what ``bench.py --config 1``
+    times): three workspaces holding the config-1 image, all 200 iterations of both J modes in one launch per iteration --
+    every one of the three must be the reference's J and trajectory (and they are bit-identical to each other)."""
+    from sucre_amd import engine
+    b = helpers.load_baseline(helpers.BASELINE_C1)
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    rs = [engine.Restoration(sc.height, sc.width, len(views)) for _ in range(3)]
+    for r in rs:
+        r.match(views[sc.target], views)
+    assert rs[0].n_obs() == int(b['n_obs'])
+    for key, closed, T, bars in (('param', False, int(b['T_param']), (1e-6, 2e-6, 2e-5)), ('closed', True, int(b['T_closed']), (2e-5, 2e-5, 2e-5))):
+        for r in rs:
+            r.fit_init(views[sc.target])
+        traces = engine.fit_batch(rs, T, use_closed_form=closed)
+        torch.cuda.synchronize()
+        J0 = rs[0].J().cpu().numpy()
+        for i, r in enumerate(rs):
+            J = r.J().cpu().numpy()
+            assert np.array_equal(np.nan_to_num(J), np.nan_to_num(J0)) and np.array_equal(traces[i].cpu().numpy(), traces[0].cpu().numpy())
+        helpers.check_baseline_fit(b, key, J0, traces[0].cpu().numpy(), *bars, f'ENGINE (batch launch), config 1 in full, {T} iterations')
+
+
+@pytest.mark.timeout(900)
 def test_odd_image_size_engine_vs_reference():
     """333x207 (ragged last tile column and row), 8 neighbours + self, against the reference itself: match maps bit for bit, the
     whole J after its 60 J-parameter and 30 closed-form iterations."""
