@@ -76,15 +76,18 @@ def parse():
                                                              'work on 16 cores together with the matching)')
     args = p.parse_args()
     preset = CONFIG_PRESETS.get(args.config, {})
+    given = {a.dest for a in p._actions for opt in a.option_strings
+             if any(tok == opt or tok.startswith(opt + '=') for tok in sys.argv[1:])}
     for key, val in preset.items():
-        if getattr(args, key) == p.get_default(key):   # a flag given explicitly keeps its value
+        if key not in given:   # a flag given explicitly keeps its value (also when that value is the default)
             setattr(args, key, val)
     return args
 
 
 # BASELINE.json "configs", by their 1-based position
 CONFIG_PRESETS = {
-    1: dict(width=640, height=480, neighbours=4, fit_batch=32),   # small images: 32 consecutive steps share one launch per iteration
+    # small images: 32 consecutive steps share one launch per iteration (steps / warmup in whole launches unless given)
+    1: dict(width=640, height=480, neighbours=4, fit_batch=32, steps=64, warmup=32),
     2: dict(),
     3: dict(batch_images=32),
     4: dict(shared_water=True, batch_images=64),
@@ -96,7 +99,7 @@ def baseline_config(args):
     """The BASELINE.json configuration (1-based) the flags amount to, or None for any other workload."""
     for number, preset in CONFIG_PRESETS.items():
         want = dict(width=1920, height=1080, neighbours=64, batch_images=1, shared_water=False, obs_format='f32')
-        want.update({k: v for k, v in preset.items() if k != 'fit_batch'})   # (how the steps are launched does not change the workload)
+        want.update({k: v for k, v in preset.items() if k not in ('fit_batch', 'steps', 'warmup')})   # (how the steps are launched does not change the workload)
         if all(getattr(args, k) == v for k, v in want.items()) and not args.light_model:
             return number
     return None
@@ -404,6 +407,7 @@ def main():
 
     n_obs = resto.n_obs()
     n_fits = len(fit_events)
+    chunk_fill = 1.0 if group_restos is not None else args.steps * len(jobs) / (n_fits * B)   # images per timed launch / B
     own_ms_per_image = own_elapsed / args.steps / len(jobs) * 1e3
     if world > 1:   # a straggler shows in the JSON line: every rank's own time per image, not only the slowest's
         per_rank = [None] * world
@@ -564,8 +568,9 @@ def main():
                              f'tools/profile.sh runs rocprofv3 in; includes the ~1.5 us launch gaps') if solo_fit else
                             'HIP events around the lock-step iterations of the timed region',
                 'timed_region_ms_per_launch': timed_region_iter_ms,
-                'timed_region_frac': algo_bytes / (timed_region_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                'timed_region_stored_bytes_frac': stored_bytes / (timed_region_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # (a --fit-batch run whose last chunk is short: the timed region's launches hold chunk_fill x B images on average)
+                'timed_region_frac': chunk_fill * algo_bytes / (timed_region_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'timed_region_stored_bytes_frac': chunk_fill * stored_bytes / (timed_region_iter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'obs_passes_per_launch': obs_passes}
         if prof is not None:
             name, rec = prof
