@@ -125,3 +125,25 @@ def test_batch_refuses_what_it_cannot_do():
     c.fit(1)
     with pytest.raises(AssertionError):   # not at the same step
         engine.fit_batch([a, c], 2)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('closed', [False, True], ids=['J-parameter', 'closed-form'])
+def test_more_images_than_one_launch_holds(closed):
+    """Forty 96x64 images (a launch holds 32: two launches + two tail launches per iteration), each a different target of one
+    survey: bitwise the one-by-one fits."""
+    from sucre_amd import engine, synth
+    survey = synth.make_survey(96, 64, 8, 7, seed=9)
+    idxs = [j * 8 + i for j in range(1, 6) for i in range(0, 8)]
+    assert len(idxs) == 40
+    pairs = _targets(survey, engine, idxs, 4)
+    want = [_alone(r, tgt, 6, closed) for r, tgt in pairs]
+    for r, tgt in pairs:
+        r.fit_init(tgt)
+    traces = engine.fit_batch([r for r, _ in pairs], 6, use_closed_form=closed)
+    torch.cuda.synchronize()
+    for i, ((r, _), (J, p, tr)) in enumerate(zip(pairs, want)):
+        assert np.array_equal(traces[i].cpu().numpy(), tr), i
+        assert np.array_equal(r.params().cpu().numpy(), p), i
+        Jb = r.J().cpu().numpy()
+        assert np.array_equal(np.isnan(Jb), np.isnan(J)) and np.array_equal(Jb[~np.isnan(Jb)], J[~np.isnan(J)]), i
