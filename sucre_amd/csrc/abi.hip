@@ -529,6 +529,9 @@ int sucre_fit_run_light(void *ws, void *lws, int H, int W, int n_views, int t0, 
     if (trace_dev && !aligned(trace_dev, 8)) return fail(SUCRE_ERR_ARG, "trace must be 8-byte aligned");
     if (flags & ~(SUCRE_FIT_CLOSED_FORM | SUCRE_FIT_EXT_COLOUR | SUCRE_FIT_KEEP_J | SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "unknown fit flags 0x%x", flags);
     if ((flags & SUCRE_FIT_EXT_COLOUR) && (flags & SUCRE_FIT_EXT_BOTH)) return fail(SUCRE_ERR_ARG, "SUCRE_FIT_EXT_COLOUR and SUCRE_FIT_EXT_BOTH exclude each other");
+    if (T > 0)   // which strips every wave of the gradient launches works on (layout.h, the deal): written once per call
+        if (int rc = check_hip(launch_light_deal(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), flags,
+                                                 static_cast<hipStream_t>(stream)), "sucre_fit_run_light/deal")) return rc;
     for (int it = 0; it < T; ++it) {
         const AdamCoef co = adam_coef(t0 + it + 1, lr, beta1, beta2, eps);
         if (int rc = check_hip(launch_light_iter(L, static_cast<uint8_t *>(ws), static_cast<uint8_t *>(lws), co, flags,

@@ -78,12 +78,16 @@ constexpr bool kExpWaveTimes = false;
 constexpr int kExpPrio = SUCRE_EXP_PRIO;
 
 // layout.h: the work a wave of each workgroup generation is dealt, in 64ths of what a wave of generation 0 (the oldest) gets;
-// the first must be 64.  64 everywhere = equal shares (the product).  Measured (tools/exp/wave_times.py, ab_solo.sh): with
+// the first must be 64.  64 everywhere = equal shares.  Measured (tools/exp/wave_times.py, ab_solo.sh, round 4): with
 // 64,44,24,14,5 a J-parameter launch ALONE on the GPU takes 126 instead of 134 us (its waves then end within 20 us of each
 // other instead of 75), but with two images in flight -- the default -- the second launch's workgroups arrive as the first one's
-// leave, no longer one generation per CU, and an image takes 25.1 instead of 24.4 ms.
+// leave, no longer one generation per CU, and an image takes 25.1 instead of 24.4 ms.  Round 5 (tools/exp/ab_vs.sh, one box,
+// two rounds each; launch alone / Mpix/s with two images in flight): equal shares 131.9-132.1 us / 84.91-84.95;
+// **64,50,38,28,20: 127.3-128.0 / 84.89-85.06** (the product: nothing lost in flight, 3.3 % gained alone);
+// 64,56,48,40,32: 131.3 / 84.3; 64,48,36,28,22: 128.1-128.7 / 84.5-84.7; 64,52,40,28,16: 125.7-125.9 / 84.54-84.57;
+// 64,48,34,22,12: 125.2-125.6 / 84.2-84.6; 64,46,30,20,10: 125.2-125.5 / 84.3; 64,44,24,14,5: 126.2-126.6 / 81.4-81.5.
 #ifndef SUCRE_DEAL_FIT
-#define SUCRE_DEAL_FIT 64, 64, 64, 64, 64
+#define SUCRE_DEAL_FIT 64, 50, 38, 28, 20
 #endif
 // The closed-form kernel (four generations, instruction-bound) takes the unequal deal as its product default (round 5): alone a
 // launch takes 140.8-142.3 instead of 148.4 us (same box, tools/exp/ab_vs.sh; 0.51 instead of 0.49 of the HBM peak by SURVEY

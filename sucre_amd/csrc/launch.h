@@ -87,6 +87,7 @@ int64_t light_params_offset(const Layout &L);
 uint8_t *light_ext_dense(const Layout &L, uint8_t *lws);
 uint8_t *light_ext_comp(const Layout &L, uint8_t *lws);
 hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params19, hipStream_t s);
+hipError_t launch_light_deal(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s);   // once per fit call, before launch_light_iter
 hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const AdamCoef &co, unsigned flags,
                              double *trace_row, hipStream_t s);
 hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s);

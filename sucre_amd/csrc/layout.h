@@ -91,6 +91,23 @@ __host__ __device__ inline DealShares deal_shares(int mode, uint32_t blocks) {
     return sh;
 }
 
+// The same for a kernel that sizes its grid at run time (light.hip): G resident workgroups per CU, shares by generation from the
+// table the fit kernels' measurements suggest (G = 4: the closed-form kernel's, G = 5: the J-parameter kernel's); any other grid
+// gets the plain deal.
+__host__ __device__ inline DealShares deal_shares_resident(uint32_t blocks) {
+    const uint32_t four[kMaxGen] = {SUCRE_DEAL_CLOSED}, five[kMaxGen] = {SUCRE_DEAL_FIT};
+    DealShares sh;
+    const bool g4 = blocks == 1024u && kClosedWaves == 4, g5 = blocks == 1280u && kFitWaves == 5;
+    sh.G = g4 ? 4u : g5 ? 5u : 1u;
+    bool all_equal = true;
+    for (int g = 0; g < kMaxGen; ++g) {
+        sh.p[g] = (g4 && g < 4) ? four[g] : (g5 && g < 5) ? five[g] : kDealDen;
+        all_equal = all_equal && sh.p[g] == kDealDen;
+    }
+    if (all_equal || sh.p[0] != kDealDen) { sh.G = 1u; for (int g = 0; g < kMaxGen; ++g) sh.p[g] = kDealDen; }
+    return sh;
+}
+
 // Calls f(k, strip) for the wave's strips in its working order; returns how many there are.  levels(strip) = the strip's level
 // count (StripMeta.levels; device data: the deal is made where the plan is written).  W % G == 0 (deal_shares).
 template <class L, class F>

@@ -30,9 +30,11 @@ struct LightLayout {
     size_t off_dexp;                      // double [6][12]: d exp(hat xi)[G_i], rows 0..2 of the 4x4 derivative (with the geometry)
     size_t off_partials;                  // float [26][n_blocks]
     size_t off_sums;                      // double [26]
+    size_t off_deal;                      // uint32 [8192] strips per wave, then [8 n_strips] the waves' strip lists (light_deal_kernel)
     size_t off_ext2_dense, off_ext2_comp; // second set of planes (float32 colours next to camera points); only with ext_sets = 2
     size_t total;
 };
+constexpr uint32_t kLightMaxWaves = 8192;   // 8 waves per SIMD x 4 SIMDs x 256 CUs
 
 // ext_sets = 2 appends the second set at the END, so every other offset is the same in both kinds of workspace
 static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1) {
@@ -46,6 +48,7 @@ static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1)
     X->off_dexp = take(72 * sizeof(double));
     X->off_partials = take((size_t)kLightSums * L.n_blocks * sizeof(float));
     X->off_sums = take(kLightSums * sizeof(double));
+    X->off_deal = take(((size_t)kLightMaxWaves + (size_t)kMaxGen * L.n_strips + kLightMaxWaves) * sizeof(uint32_t));
     X->off_ext2_dense = X->off_ext2_comp = 0;
     if (ext_sets > 1) {
         X->off_ext2_dense = take(chunks * kExtChunk);
@@ -354,7 +357,8 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                                                          const float *__restrict__ pstate, const float *__restrict__ geom,
                                                          const uint64_t *__restrict__ n_obs_total,
                                                          float *__restrict__ state, float *__restrict__ partials,
-                                                         const AdamCoef co) {
+                                                         const AdamCoef co, const uint32_t *__restrict__ deal_count,
+                                                         const uint32_t *__restrict__ deal_strips, uint32_t deal_kmax) {
     __shared__ float wsum[4][kLightSums];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -379,11 +383,20 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
 #pragma unroll
     for (int q = 0; q < kLightSums; ++q) acc.s[q] = 0.f;
 
+    // The wave's strips: from the deal light_deal_kernel wrote for THIS grid (layout.h: on a full grid the waves of the
+    // workgroups that arrive first on their CU get larger shares -- the SIMD issues its oldest wave first), or the plain
+    // boustrophedon deal when there is no table (update_J).
     const uint32_t W = (uint32_t)n_blocks * 4u, wid = blockIdx.x * 4u + (uint32_t)wave;
-    for (uint32_t k = 0;; ++k) {
-        const uint32_t strip = k * W + ((k & 1u) ? W - 1u - wid : wid);   // boustrophedon deal, as in fit.hip
-        if (k * W >= (uint32_t)n_strips) break;
-        if (strip >= (uint32_t)n_strips) continue;
+    const uint32_t n_mine = deal_count ? __builtin_amdgcn_readfirstlane(deal_count[wid]) : 0xffffffffu;
+    for (uint32_t k = 0; k < n_mine; ++k) {
+        uint32_t strip;
+        if (deal_count) {
+            strip = __builtin_amdgcn_readfirstlane(deal_strips[(size_t)wid * deal_kmax + k]);
+        } else {
+            strip = k * W + ((k & 1u) ? W - 1u - wid : wid);
+            if (k * W >= (uint32_t)n_strips) break;
+            if (strip >= (uint32_t)n_strips) continue;
+        }
         const StripMeta sm = meta[strip];
         const uint32_t n = sm.levels, nch = (n + 3u) >> 2;
         const uint8_t *sobs = comp + sm.lvoff * (uint64_t)level_bytes(0);
@@ -591,6 +604,16 @@ __global__ void light_params_upload_kernel(float *dst, const LightParams19 p) {
     if (threadIdx.x < kLightParams) dst[threadIdx.x] = p.v[threadIdx.x];
 }
 
+// The deal of a gradient launch of `n_blocks` workgroups, written once per sucre_fit_run_light call: one thread per wave.
+__global__ __launch_bounds__(256) void light_deal_kernel(const StripMeta *__restrict__ meta, int n_strips, uint32_t W, uint32_t kmax,
+                                                         const DealShares sh, uint32_t *__restrict__ count, uint32_t *__restrict__ strips) {
+    const uint32_t wid = blockIdx.x * 256u + threadIdx.x;
+    if (wid >= W) return;
+    uint32_t *mine = strips + (size_t)wid * kmax;
+    count[wid] = deal_walk(wid, W, (uint32_t)n_strips, sh, [&](uint32_t s) { return meta[s].levels; },
+                           [&](uint32_t k, uint32_t strip) { if (k < kmax) mine[k] = strip; });
+}
+
 size_t light_workspace_bytes(const Layout &L, int ext_sets) {
     LightLayout X;
     make_light_layout(L, &X, ext_sets);
@@ -669,25 +692,58 @@ static int resident_grid(K kernel, const Layout &L) {
     return L.n_blocks < grid ? L.n_blocks : grid;
 }
 
+// What a gradient launch's deal is: its grid (the resident workgroups of ITS instantiation), the shares, the strips reserved
+// per wave.
+struct LightDeal { int grid; DealShares sh; uint32_t kmax; };
+
+template <class K>
+static LightDeal light_deal_of(K kernel, const Layout &L) {
+    LightDeal d;
+    d.grid = resident_grid(kernel, L);
+    d.sh = deal_shares_resident((uint32_t)d.grid);
+    d.kmax = deal_rounds((uint32_t)d.grid * 4u, (uint32_t)L.n_strips, d.sh);
+    return d;
+}
+
+// kDeal 0: launch with the table light_deal_kernel wrote; 1: write that table; 2: launch without one (plain deal).
 template <bool kClosed, bool kJOnly, bool kColour, bool kBoth = false>
 static int launch_light_grad_c(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
-                               hipStream_t s) {
-    const int grid = resident_grid(light_grad_kernel<kClosed, kJOnly, kColour, kBoth>, L);
-    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour, kBoth>), dim3(grid), dim3(256), 0, s, ws + L.off_comp,
+                               hipStream_t s, int deal_mode) {
+    const LightDeal d = light_deal_of(light_grad_kernel<kClosed, kJOnly, kColour, kBoth>, L);
+    uint32_t *count = reinterpret_cast<uint32_t *>(lws + X.off_deal), *strips = count + kLightMaxWaves;
+    const bool fits = (uint32_t)d.grid * 4u <= kLightMaxWaves && (size_t)d.grid * 4u * d.kmax <= (size_t)kMaxGen * L.n_strips + kLightMaxWaves;
+    if (deal_mode == 1) {
+        if (fits)
+            hipLaunchKernelGGL(light_deal_kernel, dim3(((uint32_t)d.grid * 4u + 255u) / 256u), dim3(256), 0, s,
+                               reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips, (uint32_t)d.grid * 4u, d.kmax, d.sh, count, strips);
+        return d.grid;
+    }
+    const bool table = deal_mode == 0 && fits;
+    hipLaunchKernelGGL((light_grad_kernel<kClosed, kJOnly, kColour, kBoth>), dim3(d.grid), dim3(256), 0, s, ws + L.off_comp,
                        lws + X.off_ext_comp, kBoth ? light_ext2_comp(L, lws) : nullptr,
                        reinterpret_cast<const StripMeta *>(ws + L.off_strip_meta), L.n_strips,
                        reinterpret_cast<const float *>(lws + X.off_params), reinterpret_cast<const float *>(lws + X.off_geom),
                        reinterpret_cast<const uint64_t *>(ws + L.off_n_obs_total),
-                       reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(lws + X.off_partials), co);
-    return grid;
+                       reinterpret_cast<float *>(ws + L.off_state), reinterpret_cast<float *>(lws + X.off_partials), co,
+                       table ? count : nullptr, table ? strips : nullptr, d.kmax);
+    return d.grid;
 }
 
 template <bool kClosed, bool kJOnly>
 static int launch_light_grad(const Layout &L, const LightLayout &X, uint8_t *ws, uint8_t *lws, const AdamCoef &co,
-                             unsigned flags, hipStream_t s) {
-    if (flags & SUCRE_FIT_EXT_BOTH) return launch_light_grad_c<kClosed, kJOnly, false, true>(L, X, ws, lws, co, s);
-    if (flags & SUCRE_FIT_EXT_COLOUR) return launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s);
-    return launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s);
+                             unsigned flags, hipStream_t s, int deal_mode) {
+    if (flags & SUCRE_FIT_EXT_BOTH) return launch_light_grad_c<kClosed, kJOnly, false, true>(L, X, ws, lws, co, s, deal_mode);
+    if (flags & SUCRE_FIT_EXT_COLOUR) return launch_light_grad_c<kClosed, kJOnly, true>(L, X, ws, lws, co, s, deal_mode);
+    return launch_light_grad_c<kClosed, kJOnly, false>(L, X, ws, lws, co, s, deal_mode);
+}
+
+// Once per sucre_fit_run_light call, before its iterations: the deal of the gradient launches those iterations will make.
+hipError_t launch_light_deal(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s) {
+    LightLayout X;
+    make_light_layout(L, &X);
+    if (flags & SUCRE_FIT_CLOSED_FORM) launch_light_grad<true, false>(L, X, ws, lws, AdamCoef{}, flags, s, 1);
+    else launch_light_grad<false, false>(L, X, ws, lws, AdamCoef{}, flags, s, 1);
+    return hipGetLastError();
 }
 
 hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s) {
@@ -695,7 +751,7 @@ hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, uns
     make_light_layout(L, &X);
     hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(512), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
                        reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp));
-    launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, flags, s);
+    launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, flags, s, 2);
     return hipGetLastError();
 }
 
@@ -703,8 +759,8 @@ hipError_t launch_light_iter(const Layout &L, uint8_t *ws, uint8_t *lws, const A
                              double *trace_row, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
-    const int grid = (flags & SUCRE_FIT_CLOSED_FORM) ? launch_light_grad<true, false>(L, X, ws, lws, co, flags, s)
-                                                     : launch_light_grad<false, false>(L, X, ws, lws, co, flags, s);
+    const int grid = (flags & SUCRE_FIT_CLOSED_FORM) ? launch_light_grad<true, false>(L, X, ws, lws, co, flags, s, 0)
+                                                     : launch_light_grad<false, false>(L, X, ws, lws, co, flags, s, 0);
     hipLaunchKernelGGL(light_tail_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const float *>(lws + X.off_partials), grid,
                        reinterpret_cast<double *>(lws + X.off_sums), reinterpret_cast<float *>(lws + X.off_params),
                        reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp),

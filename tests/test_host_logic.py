@@ -655,7 +655,7 @@ def test_the_deal_gives_every_strip_to_exactly_one_wave(tmp_path):
     if shutil.which('g++') is None:
         pytest.skip('no g++ on this machine')
     csrc = ROOT / 'sucre_amd' / 'csrc'
-    for name, flags in (('equal', []), ('unequal', ['-DSUCRE_DEAL_FIT=64,44,24,14,5', '-DSUCRE_DEAL_CLOSED=64,48,32,20'])):
+    for name, flags in (('product', []), ('equal', ['-DSUCRE_DEAL_FIT=64,64,64,64,64', '-DSUCRE_DEAL_CLOSED=64,64,64,64']), ('unequal', ['-DSUCRE_DEAL_FIT=64,44,24,14,5', '-DSUCRE_DEAL_CLOSED=64,48,32,20'])):
         exe = tmp_path / f'deal_{name}'
         out = subprocess.run(['g++', '-std=c++17', '-O1', f'-I{csrc}', f'-I{ROOT / "include"}', *flags, str(ROOT / 'tests' / 'native' / 'deal_check.cpp'), '-o', str(exe)],
                              capture_output=True, text=True)
