@@ -98,10 +98,9 @@ constexpr int kExpPrio = SUCRE_EXP_PRIO;
 #define SUCRE_DEAL_CLOSED 64, 48, 32, 20
 #endif
 
-// fit.hip batch_iter_kernel, timing only (results meaningless): where an image's ~14 us inside a batch launch of 640x480 images
-// go.  1: no last-arriver tail (the workgroup's partial is stored, nobody reduces or steps); 2: no pass (every wave is told it
-// has no strip: the hand-in chain alone); 3: the hand-in without its barriers and atomics (partial store only, as 1, and no
-// wave sums).  tools/exp/batch_ablation.sh.
+// fit.hip batch launches, timing only (results meaningless): where an image's time inside a batch launch of 640x480 images
+// goes.  1: the tail launch reduces the groups but nobody takes the totals or steps; 2: no pass (every wave is told it has no
+// strip: descriptors, wave sums and the hand-in alone).  tools/exp/batch_ablation.sh.
 #ifndef SUCRE_EXP_BATCH
 #define SUCRE_EXP_BATCH 0
 #endif
