@@ -147,3 +147,39 @@ def test_more_images_than_one_launch_holds(closed):
         assert np.array_equal(r.params().cpu().numpy(), p), i
         Jb = r.J().cpu().numpy()
         assert np.array_equal(np.isnan(Jb), np.isnan(J)) and np.array_equal(Jb[~np.isnan(Jb)], J[~np.isnan(J)]), i
+
+
+@pytest.mark.timeout(900)
+def test_randomised_batches():
+    """Ten random batches: image size (ragged tiles included), number of images (1 .. 9), view counts per image, J mode, store
+    format, iterations and the split of the call sequence all drawn from a seeded generator -- every image bitwise what it gets
+    alone."""
+    from sucre_amd import engine, synth
+    rng = np.random.default_rng(20251003)
+    for case in range(10):
+        W, H = int(rng.integers(40, 200)), int(rng.integers(32, 150))
+        n_img = int(rng.integers(1, 10))
+        closed = bool(rng.integers(0, 2))
+        fmt = 'u16mm' if rng.integers(0, 4) == 0 else 'f32'
+        T = int(rng.integers(2, 9))
+        split = int(rng.integers(0, T))
+        survey = synth.make_survey(W, H, 5, 4, seed=int(rng.integers(0, 1000)))
+        idxs = [int(i) for i in rng.choice(20, size=n_img, replace=False)]
+        nv = {i: int(rng.integers(1, 9)) for i in idxs}
+        pairs = _targets(survey, engine, idxs, 0, fmt, views_of=nv)
+        want = [_alone(r, tgt, T, closed, split=split or None) for r, tgt in pairs]
+        for r, tgt in pairs:
+            r.fit_init(tgt)
+        rs = [r for r, _ in pairs]
+        if split:
+            t1 = engine.fit_batch(rs, split, use_closed_form=closed)
+            t2 = engine.fit_batch(rs, T - split, use_closed_form=closed)
+            got = [torch.cat([a, b]) for a, b in zip(t1, t2)]
+        else:
+            got = engine.fit_batch(rs, T, use_closed_form=closed)
+        torch.cuda.synchronize()
+        for i, (r, (J, p, tr)) in enumerate(zip(rs, want)):
+            label = (case, W, H, n_img, closed, fmt, T, split, i)
+            assert np.array_equal(got[i].cpu().numpy(), tr, equal_nan=True), label
+            assert np.array_equal(r.params().cpu().numpy(), p, equal_nan=True), label
+            assert np.array_equal(r.J().cpu().numpy(), J, equal_nan=True), label
