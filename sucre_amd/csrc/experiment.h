@@ -17,7 +17,9 @@ constexpr bool kExpNoLoad = true;
 constexpr bool kExpNoLoad = false;
 #endif
 
-// Waves per SIMD the fit kernels are compiled for (= workgroups per CU of their persistent grids).
+// Waves per SIMD the fit kernels are compiled for (= workgroups per CU of their persistent grids).  J-parameter kernel, same
+// box, two rounds (round 5): 5 waves 126.6-127.1 us alone / 85.7 Mpix/s; 6 waves (77 registers; deal 64,52,42,32,24,16)
+// 126.1-126.4 / 85.8-85.9; 6 waves with equal shares 130.4-130.7 / 85.4-85.6; round 4: 4 waves = 5 waves.  Not occupancy.
 #ifndef SUCRE_FIT_WAVES
 #define SUCRE_FIT_WAVES 5
 #endif

@@ -920,6 +920,11 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
 
 struct Params9 { float v[9]; };
 
+// The group / batch kernels carry a few registers more than fit_grad_kernel: when an experiment build gives that one six waves per
+// SIMD (SUCRE_FIT_WAVES=6) they keep five (their launches then run their last sixth of workgroups in a second round: timing
+// experiments on fit_grad_kernel only).
+constexpr int kGroupFitWaves = kFitWaves > 5 ? 5 : kFitWaves;
+
 // ---------------------------------------------------------------------------------------------------------------
 // Shared water parameters (north-star extension): every image of this rank -- and, through one
 // all-reduce of the ten sums, of every other rank -- steps B, beta, gamma together.  One iteration is ONE launch and
@@ -976,7 +981,7 @@ __device__ __forceinline__ void group_water_step(const double *__restrict__ sums
 }
 
 template <int kMode, int kFmt>
-__global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void group_iter_kernel(GroupHeader *g, int n_images, uint64_t n_obs_total,
+__global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void group_iter_kernel(GroupHeader *g, int n_images, uint64_t n_obs_total,
                                                                                            const AdamCoef co_prev, const AdamCoef co, int apply,
                                                                                            int in, int out, double *trace_prev, int n_groups,
                                                                                            const GroupImage *__restrict__ images) {
@@ -1196,7 +1201,7 @@ __device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ i
 }
 
 template <int kMode, int kFmt>
-__global__ __launch_bounds__(256, kMode ? kClosedWaves : kFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
+__global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
                                                                                            const AdamCoef co, int row) {
     if (kExpNoBatchClosed && kMode == 1) return;   // (experiment.h: occupancy experiments on the closed-form kernel alone)
     __shared__ BatchLds blds;
