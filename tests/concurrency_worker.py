@@ -1,6 +1,7 @@
 """One of two processes that fit the same image on the one GPU at the same time (tests/test_gpu_dist.py): workgroups
 of a launch then start at different times and memory latencies stretch, which is when hand-counted waits and
-hand-offs show their races.  Prints one digest per repetition: fused per-image path and single-launch group path."""
+hand-offs show their races.  Prints one digest per repetition: fused per-image path, single-launch group path and the
+batch launch (batch_iter_kernel + batch_tail_kernel) of the one image, in turn."""
 import hashlib
 import sys
 from pathlib import Path
@@ -22,8 +23,10 @@ def main(fixture: str, reps: int, T: int) -> None:
     for rep in range(reps):
         r.match(views[sc.target], views)     # matching, compaction and plans are redone every time: they are under test too
         r.fit_init(views[sc.target])
-        if rep % 2 == 0:
+        if rep % 3 == 0:
             t = r.fit(T)
+        elif rep % 3 == 2:
+            t = engine.fit_batch([r], T)[0]
         else:
             t = torch.zeros((T, 10), dtype=torch.float64, device='cuda')
             g = engine.HipWaterGroup([r], trace=t)

@@ -124,8 +124,8 @@ def test_bench_json_line_keeps_the_contract():
 @pytest.mark.timeout(600)
 def test_results_do_not_depend_on_who_else_uses_the_gpu(golden):
     """Two processes fitting at the same time (workgroups of a launch no longer start together, latencies stretch):
-    every repetition in both processes, on the fused per-image path and on the single-launch group path, must be the
-    same bits as a run alone on the GPU.  (Caught in round 2: plan items loaded by a hand-issued s_load were copied
+    every repetition in both processes, on the fused per-image path, on the single-launch group path and through the batch
+    launches (round 5), must be the same bits as a run alone on the GPU.  (Caught in round 2: plan items loaded by a hand-issued s_load were copied
     before they had landed, and group sums could be read before all four waves' stores had drained.)"""
     T, reps = 40, 12
     cmd = [sys.executable, str(ROOT / 'tests' / 'concurrency_worker.py'), golden.name, str(reps), str(T)]
@@ -134,10 +134,10 @@ def test_results_do_not_depend_on_who_else_uses_the_gpu(golden):
         line = [ln for ln in out.splitlines() if ln.startswith('DIGESTS ')]
         assert len(line) == 1, out[-2000:]
         return line[0].split()[1:]
-    alone = subprocess.run(cmd[:3] + ['2', str(T)], capture_output=True, text=True, timeout=300)
+    alone = subprocess.run(cmd[:3] + ['3', str(T)], capture_output=True, text=True, timeout=300)
     assert alone.returncode == 0, alone.stderr[-2000:]
     ref = digests(alone.stdout)
-    assert ref[0] == ref[1]                      # group of one == fused fit, bit for bit
+    assert ref[0] == ref[1] == ref[2]            # group of one == batch of one == fused fit, bit for bit
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
     outs = [p.communicate(timeout=500) for p in procs]
     for p, (so, se) in zip(procs, outs):
