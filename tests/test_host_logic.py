@@ -804,3 +804,29 @@ def test_engine_plumbing_attributes_are_what_their_callers_expect():
     src = inspect.getsource(engine)
     assert '_stream_ptr()' not in inspect.getsource(R), 'Restoration launches go through self._sp() (stream bookkeeping)'
     assert engine.current_slot() == 0 and '_SLOT' not in src
+
+
+def test_bench_presets_respect_explicit_flags(monkeypatch):
+    """``bench.py --config N`` presets: BASELINE config 1 batches 32 consecutive steps per fit launch and runs whole batches,
+    unless the caller says otherwise -- also when what the caller says equals a flag's default; how the steps are launched never
+    changes which BASELINE configuration the JSON names."""
+    import importlib
+    bench = importlib.import_module('bench')
+
+    def parse(*argv):
+        monkeypatch.setattr('sys.argv', ['bench.py', *argv])
+        return bench.parse()
+    a = parse()
+    assert (a.width, a.height, a.neighbours, a.fit_batch, a.steps, a.warmup) == (1920, 1080, 64, 1, 10, 2) and bench.baseline_config(a) == 2
+    a = parse('--config', '1')
+    assert (a.width, a.height, a.neighbours, a.fit_batch, a.steps, a.warmup) == (640, 480, 4, 32, 64, 32) and bench.baseline_config(a) == 1
+    a = parse('--config', '1', '--fit-batch', '1', '--steps', '10')
+    assert (a.fit_batch, a.steps, a.warmup) == (1, 10, 32) and bench.baseline_config(a) == 1
+    a = parse('--config', '1', '--warmup=2')
+    assert a.warmup == 2 and a.steps == 64
+    a = parse('--config', '5')
+    assert (a.width, a.height, a.neighbours, a.obs_format) == (3840, 2160, 256, 'u16mm') and bench.baseline_config(a) == 5
+    a = parse('--config', '4')
+    assert a.shared_water and a.batch_images == 64 and bench.baseline_config(a) == 4
+    a = parse('--gpus', '8', '--steps', '5', '--warmup', '1')      # the driver's own line
+    assert (a.gpus, a.steps, a.warmup, a.fit_batch) == (8, 5, 1, 1) and bench.baseline_config(a) == 2
