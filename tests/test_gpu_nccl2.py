@@ -18,8 +18,13 @@ import torch
 import helpers
 
 ROOT = Path(__file__).resolve().parent.parent
+# SUCRE_TEST_NCCL2_ON_GLOO=1: the same tests on a ONE-GPU box with both ranks on cuda:0 over gloo -- a rehearsal of the test
+# logic itself (launchers, digests, the one-process composition); the assertions about RCCL and two devices are then skipped.
+REHEARSAL = os.environ.get('SUCRE_TEST_NCCL2_ON_GLOO') == '1'
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks on one device)')]
+              pytest.mark.skipif(torch.cuda.device_count() < 2 and not REHEARSAL,
+                                 reason='needs two GPUs (RCCL refuses two ranks on one device)')]
+BACKEND = 'gloo' if REHEARSAL else 'nccl'
 
 SMALL = ['--width', '320', '--height', '240', '--neighbours', '8', '--num-iter', '6', '--no-cpu-baseline', '--solo-images', '1']
 
@@ -28,6 +33,8 @@ def _clean_env():
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'SUCRE_DIST_BACKEND')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if REHEARSAL:
+        env['SUCRE_DIST_BACKEND'] = 'gloo'
     return env
 
 
@@ -54,8 +61,8 @@ def _bench(extra, launcher=False):
 def test_per_image_mode_on_two_gpus_equals_one_gpu_bit_for_bit(launcher):
     rec = _bench(['--digest'], launcher)
     cfg = rec['config']
-    assert rec['n_gpus'] == 2 and cfg['ranks_seen'] == 2 and cfg['dist_backend'] == 'nccl'
-    assert len(set(cfg['devices'])) == 2 and 'cuda:0' in cfg['devices'][0] and 'cuda:1' in cfg['devices'][1]
+    assert rec['n_gpus'] == 2 and cfg['ranks_seen'] == 2 and cfg['dist_backend'] == BACKEND
+    assert len(set(cfg['devices'])) == 2 and 'cuda:0' in cfg['devices'][0] and (REHEARSAL or 'cuda:1' in cfg['devices'][1])
     per_rank = cfg['ms_per_image_per_rank']
     assert len(per_rank['all']) == 2 and per_rank['min'] <= per_rank['max'] and per_rank['max'] <= cfg['ms_per_image'] * 1.001 + 1e-6
     # the same two images, one after the other, in THIS process on cuda:0 (rank r's scene is seed r, rendered on its device)
@@ -78,7 +85,7 @@ def test_per_image_mode_on_two_gpus_equals_one_gpu_bit_for_bit(launcher):
 def test_bench_shared_water_on_two_gpus(extra):
     rec = _bench(extra)
     cfg = rec['config']
-    assert cfg['ranks_seen'] == 2 and cfg['dist_backend'] == 'nccl' and len(set(cfg['devices'])) == 2
+    assert cfg['ranks_seen'] == 2 and cfg['dist_backend'] == BACKEND and len(set(cfg['devices'])) == 2
     assert rec['value'] > 0 and rec['scaling'] == 'weak' and 'shared water' in cfg['workload']
 
 
@@ -99,7 +106,7 @@ def test_shared_water_trace_over_rccl_equals_the_one_process_composition(golden,
         procs.append(subprocess.Popen([sys.executable, str(ROOT / 'tests' / 'dist_worker.py'), str(tmp_path), golden.name, str(T)], env=env))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
-    assert str(r0['backend']) == 'nccl' and int(r0['world']) == 2
+    assert str(r0['backend']) == BACKEND and int(r0['world']) == 2
     assert np.array_equal(r0['trace'], r1['trace']) and np.array_equal(r0['params'], r1['params'])
     # one process, two images, the sums added by hand
     sc = golden.scene
@@ -124,7 +131,7 @@ def test_shared_water_trace_over_rccl_equals_the_one_process_composition(golden,
     torch.cuda.synchronize()
     one = trace.cpu().numpy()
     d = np.abs(r0['trace'] - one).max()
-    print(f'two ranks over RCCL vs one process: max |d trace| = {d:.2e} (bitwise: {np.array_equal(r0["trace"], one)})')
+    print(f'two ranks over {BACKEND} vs one process: max |d trace| = {d:.2e} (bitwise: {np.array_equal(r0["trace"], one)})')
     assert d < 1e-6
     for r, x in ((r0, rs[0]), (r1, rs[1])):
         assert helpers.rms_per_channel(r['J'], x.J().cpu().numpy()).max() < 1e-6
