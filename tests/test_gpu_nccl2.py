@@ -1,4 +1,5 @@
-"""Two ranks on TWO GPUs over RCCL (backend 'nccl') -- skipped on the one-GPU pool, evidence the moment a node has two.
+"""Two ranks on TWO GPUs over RCCL (backend 'nccl') -- evidence the moment a node has two; on the one-GPU pool the same tests
+run as a rehearsal over gloo (both ranks on cuda:0).
 
 What the 8-GPU scaling run relies on, in small: bench.py's own rank launcher and the torchrun contract with one GPU per rank,
 per-image mode (no collective: a rank's J is bit-identical to a 1-GPU restoration of the same image) and the shared-water
@@ -20,10 +21,9 @@ import helpers
 ROOT = Path(__file__).resolve().parent.parent
 # SUCRE_TEST_NCCL2_ON_GLOO=1: the same tests on a ONE-GPU box with both ranks on cuda:0 over gloo -- a rehearsal of the test
 # logic itself (launchers, digests, the one-process composition); the assertions about RCCL and two devices are then skipped.
-REHEARSAL = os.environ.get('SUCRE_TEST_NCCL2_ON_GLOO') == '1'
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(torch.cuda.device_count() < 2 and not REHEARSAL,
-                                 reason='needs two GPUs (RCCL refuses two ranks on one device)')]
+# On a box with ONE GPU that rehearsal is what runs (so the file never skips): two GPUs -> RCCL, one GPU -> gloo.
+REHEARSAL = os.environ.get('SUCRE_TEST_NCCL2_ON_GLOO') == '1' or torch.cuda.device_count() < 2
+pytestmark = [pytest.mark.gpu]
 BACKEND = 'gloo' if REHEARSAL else 'nccl'
 
 SMALL = ['--width', '320', '--height', '240', '--neighbours', '8', '--num-iter', '6', '--no-cpu-baseline', '--solo-images', '1']
