@@ -125,3 +125,12 @@ constexpr bool kExpNoBatchClosed = true;
 #else
 constexpr bool kExpNoBatchClosed = false;
 #endif
+
+// match.hip, timing only (the store is then garbage): match_kernel without its dense-chunk stores -- what the first pass of a
+// count-first / write-sorted matching (VERDICT r04 task 7: trade scatter_kernel's read-back for a second matching pass) would
+// cost at least: every projection, gather and ballot, no observation written.  tools/exp/ab_lib.sh countonly match_kernel.
+#ifdef SUCRE_EXP_MATCH_COUNT_ONLY
+constexpr bool kExpMatchCountOnly = true;
+#else
+constexpr bool kExpMatchCountOnly = false;
+#endif

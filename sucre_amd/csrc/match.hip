@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         } else if (lane == 63) {
             zrange[(size_t)tile * n_views + k] = make_uint2(0xffffffffu, 0u);
         }
-        if (total > 0) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
+        if (total > 0 && !kExpMatchCountOnly) {  // wave-uniform; chunks of empty (tile, view) pairs are never read
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back what its own lanes wrote: LDS
             __builtin_amdgcn_wave_barrier();                          // operations of one wave complete in order
             uint8_t *chunk = obs + (size_t)tile * tile_stride + (size_t)k * view_stride;

@@ -621,7 +621,7 @@ def test_experiment_variants_compile(tmp_path):
     variants = {
         'tablate1': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_PRIO=3 -DSUCRE_EXACT_J_ADAM=1',
         'tablate2': '-DSUCRE_EXP_NOLOAD -DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4 -DSUCRE_DEAL_FIT=64,44,24,14,5 -DSUCRE_DEAL_CLOSED=64,48,32,20',
-        'texactdiv': '-DSUCRE_EXACT_DIV=1 -DSUCRE_EXP_WAVE_TIMES',
+        'texactdiv': '-DSUCRE_EXACT_DIV=1 -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_MATCH_COUNT_ONLY',
         'tlight1': '-DSUCRE_EXP_LIGHT_WATER_PASS1 -DSUCRE_EXP_NOCOMPUTE',
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
