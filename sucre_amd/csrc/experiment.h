@@ -16,6 +16,21 @@ constexpr bool kExpNoLoad = true;
 #else
 constexpr bool kExpNoLoad = false;
 #endif
+// J-parameter kernels: the stepped J and moments are computed and not written (how much of a launch is the write stream).
+#ifdef SUCRE_EXP_NOSTORE
+constexpr bool kExpNoStore = true;
+#else
+constexpr bool kExpNoStore = false;
+#endif
+// The stepped J (and moments) written with the streaming policy (nt): 0 never, 1 always, 2 in batch launches only (the product).
+// Same box, round 5.  1080p x 65 views: 1 = 126.3-126.5 us alone against 127.2-127.4, 84.5-84.8 Mpix/s with two images in
+// flight against 85.1-85.2 (nothing to gain: 8 % of a launch's bytes).  Config 1 in launches of 32 (35 % of the bytes are these
+// stores): a launch alone 244.6-245.2 against 245.2-248.0 us, but 221.7-223.0 against 208.8-210.1 Mpix/s with two slots in
+// flight (the other slot's match kernels find their views in L2); closed form 248.5-249.7 against 241.9-245.0.
+#ifndef SUCRE_STORE_NT
+#define SUCRE_STORE_NT 2
+#endif
+constexpr int kStoreNt = SUCRE_STORE_NT;
 
 // Waves per SIMD the fit kernels are compiled for (= workgroups per CU of their persistent grids).  J-parameter kernel, same
 // box, two rounds (round 5): 5 waves 126.6-127.1 us alone / 85.7 Mpix/s; 6 waves (77 registers; deal 64,52,42,32,24,16)
@@ -134,3 +149,10 @@ constexpr bool kExpMatchCountOnly = true;
 #else
 constexpr bool kExpMatchCountOnly = false;
 #endif
+
+// fit.hip, batch launches: a wave's streams of consecutive images chained into one (StreamChain).  0 = every image's stream on
+// its own (trailing copies, drain, prime), the form of the first batch kernel -- for the same-box A/B.
+#ifndef SUCRE_EXP_BATCH_CHAIN
+#define SUCRE_EXP_BATCH_CHAIN 1
+#endif
+constexpr bool kExpBatchChain = SUCRE_EXP_BATCH_CHAIN != 0;

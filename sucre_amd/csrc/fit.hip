@@ -284,6 +284,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // PlanItem.shape: [6:0] nA - 1, [14:8] max(nB, 1) - 1, [22:16] B's first 16-byte piece (nA, or nA - 1 when nB = 0: B then
 // re-reads the item's last piece), [31] a full chunk (nA = 64 and nB = kFullB: both offsets are per-lane constants).
 constexpr uint32_t kShapeFull = 1u << 31;
+constexpr uint32_t kShapeTrail = 1u << 30;   // one of the trailing items behind a wave's last strip (nobody consumes it; a batch
+                                             // launch copies the NEXT image's first items in its place: StreamChain)
 __host__ __device__ constexpr uint32_t full_chunk_b(int fmt) { return (uint32_t)(chunk_bytes(fmt) - 1024) / 16u; }   // 48 / 16 / 32 lanes
 __host__ __device__ __forceinline__ uint32_t item_shape(uint32_t bytes, bool full_chunk) {
     const uint32_t pieces = bytes / 16u;   // every item is a multiple of 16 bytes (static_asserts below)
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
     if (mode == 0) *out++ = PlanItem{(uint32_t)((st + 3 * kStripPx * 4) >> 6), item_shape(6u * kStripPx * 4u, false)};
     if (k + 1u == K) {   // the kAhead trailing items nobody consumes (+ one spare the descriptor prefetch may touch)
         const uint64_t st0 = state_off + (uint64_t)strip0 * (kStateFloats * 4);
-        for (int j = 0; j < kAhead + 1; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false)};
+        for (int j = 0; j < kAhead + 1; ++j) *out++ = PlanItem{(uint32_t)(st0 >> 6), item_shape(3u * kStripPx * 4u, false) | kShapeTrail};
     }
 }
 
@@ -507,38 +509,65 @@ __device__ __forceinline__ void issue_item(const ItemRegs it, uint32_t ring0, ui
     }
 }
 
-// The first kAhead items of a wave's stream on their own (batch launches issue the NEXT image's while the workgroup is still
-// handing in this image's sums; stream_strips<..., kPrimed = true> then starts behind them).  The wave's ring must be idle.
-template <int kFmt>
-__device__ __forceinline__ void prime_stream(FitLds &lds, const PlanItem *__restrict__ plan, uint32_t K, const uint8_t *__restrict__ ws, int wave,
-                                             int lane, bool z24) {
-    if (K == 0) return;
-    const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
-    const ConstItems items = const_items(plan);
-#pragma unroll
-    for (int q = 0; q < kAhead; ++q) issue_item<kFmt>(items[q], ring0, (uint32_t)(q * kSlot), ws, lane, z24);
-}
+// A wave's streams of consecutive images as ONE stream (batch launches).  A stream on its own ends with kAhead trailing copies
+// nobody reads and a drain (its last strip's stores and those copies: a memory round trip with nothing in flight), and the next
+// one starts with another (its first items).  Chained, the trailing items' places are taken by the NEXT image's first items,
+// the ring position and the count of items issued ahead of the last stores carry over, and nothing is waited for between two
+// images: the wave goes from one image's last strip to the next one's first like from strip to strip.
+//   head[0 .. kAhead-1], head[kAhead], se0   THIS stream's first items, the one behind them and its first strip entry (asked for
+//                                            one image ahead: no scalar round trip at the start)
+//   next_on, next_head, next_ws, next_z24    the stream that follows, if this wave has one (else: trailing copies + drain)
+//   cs, behind                               in: where this stream's first item sits (its first kAhead items are in flight);
+//                                            out: the same for the next stream -- 0, 0 after a drain
+struct NoChain { static constexpr bool kOn = false; };
+struct StreamChain {
+    static constexpr bool kOn = true;
+    ItemRegs head[kAhead + 1], se0;
+    bool next_on;
+    ItemRegs next_head[kAhead];
+    const uint8_t *next_ws;
+    bool next_z24;
+    uint32_t cs, behind;
+};
 
-template <int kFmt, int kStores, bool kMoments, bool kPrimed = false, class OnJ, class OnChunk, class OnTail, class OnEnd>
+template <int kFmt, int kStores, bool kMoments, bool kPrimed = false, class Chain = NoChain, class OnJ, class OnChunk, class OnTail, class OnEnd>
 __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
                                               uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, bool z24, OnJ on_J,
-                                              OnChunk on_chunk, OnTail on_tail, OnEnd on_end) {
+                                              OnChunk on_chunk, OnTail on_tail, OnEnd on_end, Chain *chain = nullptr) {
     if (K == 0) return;
+    constexpr bool kChain = Chain::kOn;
+    static_assert(!kChain || kPrimed, "a chained stream's first items are in flight when it starts");
     const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
     const uint8_t *ringp = &lds.ring[wave][0][0];
     const ConstItems items = const_items(plan);
     const ConstItems strips = const_items(strip_list);
-    auto issue = [&](const ItemRegs it, uint32_t slot_off) { issue_item<kFmt>(it, ring0, slot_off, ws, lane, z24); };
+    uint32_t trail = 0u;               // (chained) how many of the next stream's first items have been issued
+    auto issue = [&](const ItemRegs it, uint32_t slot_off) {
+        if constexpr (kChain) {
+            if (chain->next_on && (it.y & kShapeTrail)) {   // wave-uniform
+                ItemRegs f = chain->next_head[0];
+#pragma unroll
+                for (int q = 1; q < kAhead; ++q) f = trail == (uint32_t)q ? chain->next_head[q] : f;
+                ++trail;
+                issue_item<kFmt>(f, ring0, slot_off, chain->next_ws, lane, chain->next_z24);
+                return;
+            }
+        }
+        issue_item<kFmt>(it, ring0, slot_off, ws, lane, z24);
+    };
     // the first kAhead items (a wave with a strip has at least 1 + kAhead + 1 entries: its items, the trailing ones, the spare)
     if (!kPrimed) {
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) issue(items[q], (uint32_t)(q * kSlot));
     }
-    ItemRegs nxt = items[kAhead];      // item i + kAhead, issued at the top of step i
+    ItemRegs nxt;                      // item i + kAhead, issued at the top of step i
+    if constexpr (kChain) nxt = chain->head[kAhead]; else nxt = items[kAhead];
     uint32_t i = 0;                    // the item being consumed
     uint32_t cs = 0u;                  // byte offset of its slot in the wave's ring; item i + kAhead goes to the slot before it
     uint32_t behind = 0u;              // how many of the next items were issued before the previous strip's stores
+    if constexpr (kChain) { cs = chain->cs; behind = chain->behind; }
     const uint32_t gen = blockIdx.x >> 8;   // (experiment) which of a CU's resident workgroups this one is, oldest first
+    constexpr int kPrio = kChain ? 0 : kExpPrio;   // (the priority experiments were on one image's launch; a batch kernel has no register to spare)
     auto set_prio = [&](uint32_t p) {
         switch (p & 3u) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -565,13 +594,14 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         const uint8_t *sp = ringp + cs;
         cs = cs == (uint32_t)((kRing - 1) * kSlot) ? 0u : cs + (uint32_t)kSlot;
         ++i;
-        if (kExpPrio == 3) set_prio(gen + i);
+        if (kPrio == 3) set_prio(gen + i);
         return sp;
     };
-    ItemRegs se = strips[0];
-    if (kExpPrio == 2) set_prio(gen >= 3u ? 3u : gen);
+    ItemRegs se;
+    if constexpr (kChain) se = chain->se0; else se = strips[0];
+    if (kPrio == 2) set_prio(gen >= 3u ? 3u : gen);
     for (uint32_t k = 0; k < K; ++k) {
-        if (kExpPrio == 1) set_prio(gen + k);
+        if (kPrio == 1) set_prio(gen + k);
         const uint32_t strip = se.x, counts = se.y;
         if (k + 1u < K) se = strips[k + 1u];
         const uint32_t nu = counts_unmasked(counts), nm = counts_masked(counts), r = counts_tail(counts);
@@ -582,6 +612,15 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
         if (kMoments) on_end(strip, step());
         else on_end(strip, (const uint8_t *)nullptr);
         behind = (uint32_t)kAhead;
+    }
+    if constexpr (kChain) {
+        if (chain->next_on) {   // the next stream's first items are in flight in the slots behind this one's last
+            chain->cs = cs;
+            chain->behind = (uint32_t)kAhead;
+            return;
+        }
+        chain->cs = 0u;
+        chain->behind = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of ours is in flight past this point (the trailing items included)
 }
@@ -726,12 +765,13 @@ __device__ __forceinline__ void finish_from_wave_sums(FitLds &lds, float *partia
 
 // One wave's share of a J-parameter iteration on one image (sucre.py:142-148 with J among the parameters): streams
 // the wave's items, steps J of every strip, and keeps adding the lane's shares of the global sums to acc / sBeta.
-template <int kFmt, bool kPrimed = false>
+template <int kFmt, bool kPrimed = false, class Chain = NoChain>
 __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                           const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
-                                          const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3], const RangeCodes &rc) {
+                                          const Water &w, float gscale, const AdamCoef &co, Acc &acc, float (&sBeta)[3], const RangeCodes &rc,
+                                          Chain *chain = nullptr) {
     float J[3] = {0.f, 0.f, 0.f};
-    stream_strips<kFmt, 9, true, kPrimed>(
+    stream_strips<kFmt, 9, true, kPrimed, Chain>(
         lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
@@ -762,11 +802,19 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
                 sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
                 adam_update_J(Jc, m, v, gscale * acc.pa[c], co);
+                if (kExpNoStore && gscale != -1234.5f) continue;   // ablation build only: the step is computed, nothing is written
+                if (kStoreNt == 1 || (kStoreNt == 2 && Chain::kOn)) {
+                    __builtin_nontemporal_store(Jc, &st[c * kStripPx + lane]);
+                    __builtin_nontemporal_store(m, &st[(3 + c) * kStripPx + lane]);
+                    __builtin_nontemporal_store(v, &st[(6 + c) * kStripPx + lane]);
+                    continue;
+                }
                 st[c * kStripPx + lane] = Jc;
                 st[(3 + c) * kStripPx + lane] = m;
                 st[(6 + c) * kStripPx + lane] = v;
             }
-        });
+        },
+        chain);
 }
 
 __device__ __forceinline__ void zero_acc(Acc &acc) {
@@ -827,13 +875,13 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
 // SUCRe.update_J alone (sucre.py:66-77, 156): J = sum (I - b) a / sum a^2 from the current parameters, nothing else.
 struct ClosedSums { float sB[3], sGZ[3], sBeta[3], cost; };
 
-template <int kFmt, bool kJOnly, bool kPrimed = false>
+template <int kFmt, bool kJOnly, bool kPrimed = false, class Chain = NoChain>
 __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strips, uint32_t n_strips_wave,
                                             const uint8_t *__restrict__ ws, float *__restrict__ state, int wave, int lane,
-                                            const Water &w, bool fmt_ok, ClosedSums &cs, const RangeCodes &rc) {
+                                            const Water &w, bool fmt_ok, ClosedSums &cs, const RangeCodes &rc, Chain *chain = nullptr) {
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
-    stream_strips<kFmt, 3, false, kPrimed>(
+    stream_strips<kFmt, 3, false, kPrimed, Chain>(
         lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
@@ -870,7 +918,8 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
                 const float N = acc.q[0][c], D = acc.q[1][c];
                 const float dJ = N / D;                          // 0/0 = NaN where nothing was observed (sucre.py:77)
                 const float Jc = fmt_ok ? Jp[c] + dJ : __builtin_nanf("");   // = sum y a / sum a^2
-                st[c * kStripPx + lane] = Jc;
+                if (kStoreNt == 1 || (kStoreNt == 2 && Chain::kOn)) __builtin_nontemporal_store(Jc, &st[c * kStripPx + lane]);
+                else st[c * kStripPx + lane] = Jc;
                 if (!kJOnly && D != 0.0f) {
                     cs.sB[c] += __builtin_fmaf(-dJ, acc.q[3][c], acc.q[2][c]);
                     cs.sBeta[c] += Jc * __builtin_fmaf(-dJ, acc.q[5][c], acc.q[4][c]);
@@ -887,7 +936,8 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
                     cs.cost += __builtin_inff();
                 }
             }
-        });
+        },
+        chain);
 }
 
 template <bool kFused, int kFmt, bool kJOnly>
@@ -1170,6 +1220,7 @@ struct BatchView {
     bool fmt_ok;
     Water w;
     float gscale;
+    ItemRegs head[kAhead + 1], se0;   // the wave's first plan items and strip entry (StreamChain)
 };
 
 template <int kFmt>
@@ -1197,6 +1248,10 @@ __device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ i
         v.w.ng[c] = -cload<float>(v.ws + o_params + 4 * (6 + c)) * kLog2e;
     }
     v.gscale = -2.0f * ((1.0f / 3.0f) / (float)cload<uint64_t>(v.ws + o_n));
+    const ConstItems items = const_items(v.plan);   // (in bounds also for a wave without strips: every wave has its stride)
+#pragma unroll
+    for (int q = 0; q < kAhead + 1; ++q) v.head[q] = items[q];
+    v.se0 = const_items(v.strips)[0];
     return v;
 }
 
@@ -1212,31 +1267,54 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     // Every wave walks the images by itself -- no barrier between them: its ten sums of an image go to LDS and the next
     // image's first items are already in flight.
+    // The wave's streams of consecutive images are chained (StreamChain): image i + 1's first items take the places of image i's
+    // trailing ones.  Only a wave without a strip in one of two neighbours drains its ring between them and starts over.
+    auto prime = [&](const BatchView &x) {   // the ring is idle
+        if (x.n_mine == 0u) return;
+        const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) issue_item<kFmt>(x.head[q], ring0, (uint32_t)(q * kSlot), x.ws, lane, x.rc.z24);
+    };
+    StreamChain ch;
+    ch.cs = 0u;
+    ch.behind = 0u;
     BatchView v = batch_view<kFmt>(images, 0, wid);
-    prime_stream<kFmt>(lds, v.plan, v.n_mine, v.ws, wave, lane, v.rc.z24);
+    prime(v);
     for (int i = 0; i < n_images; ++i) {
         BatchView vn = v;
         if (i + 1 < n_images) vn = batch_view<kFmt>(images, i + 1, wid);   // on its way while this image is walked
+        // Chained: this wave has strips in both images, and this image's stream is long enough to issue ALL of the next one's
+        // first kAhead items in place of its trailing ones (a closed-form stream can be ONE item long: a strip of pixels nobody
+        // observes -- its second item is already a trailing one).
+        const bool chained = kExpBatchChain && i + 1 < n_images && v.n_mine != 0u && vn.n_mine != 0u && !(v.head[kAhead - 1].y & kShapeTrail);
+#pragma unroll
+        for (int q = 0; q < kAhead + 1; ++q) ch.head[q] = v.head[q];
+        ch.se0 = v.se0;
+        ch.next_on = chained;
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) ch.next_head[q] = vn.head[q];
+        ch.next_ws = vn.ws;
+        ch.next_z24 = vn.rc.z24;
         float s[kNumSums];
         if (kMode == 0) {
             Acc acc;
             zero_acc(acc);
             if (!v.fmt_ok) acc.cost = __builtin_nanf("");
             float sBeta[3] = {0.f, 0.f, 0.f};
-            grad_pass<kFmt, true>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.gscale, co, acc, sBeta, v.rc);
+            grad_pass<kFmt, true, StreamChain>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.gscale, co, acc, sBeta, v.rc, &ch);
             const float q[kNumSums] = {acc.sB[0], acc.sB[1], acc.sB[2], acc.sGZ[0], acc.sGZ[1], acc.sGZ[2], sBeta[0], sBeta[1], sBeta[2], acc.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
         } else {
             ClosedSums cs = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, v.fmt_ok ? 0.f : __builtin_nanf("")};
-            closed_pass<kFmt, false, true>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.fmt_ok, cs, v.rc);
+            closed_pass<kFmt, false, true, StreamChain>(lds, v.plan, v.strips, v.n_mine, v.ws, v.state, wave, lane, v.w, v.fmt_ok, cs, v.rc, &ch);
             const float q[kNumSums] = {cs.sB[0], cs.sB[1], cs.sB[2], cs.sGZ[0], cs.sGZ[1], cs.sGZ[2], cs.sBeta[0], cs.sBeta[1], cs.sBeta[2], cs.cost};
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
         }
-        if (i + 1 < n_images) {   // the wave's ring is idle: the pass has consumed its last item and drained its trailing ones
+        if (i + 1 < n_images && !chained) {   // the wave's ring is idle: the pass has consumed its last item and drained its trailing ones
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            prime_stream<kFmt>(lds, vn.plan, vn.n_mine, vn.ws, wave, lane, vn.rc.z24);
+            prime(vn);
         }
         wave_sums(s);
         if (lane == 0) {

@@ -625,7 +625,8 @@ def test_experiment_variants_compile(tmp_path):
         'tlight1': '-DSUCRE_EXP_LIGHT_WATER_PASS1 -DSUCRE_EXP_NOCOMPUTE',
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
-        'tbatch': '-DSUCRE_EXP_BATCH=2',
+        'tstorent': '-DSUCRE_STORE_NT=1',
+        'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0',
         'thalf': '-DSUCRE_EXP_HALF_EXPS -DSUCRE_CLOSED_WAVES=5 -DSUCRE_EXP_NO_BATCH_CLOSED -DSUCRE_DEAL_CLOSED=64,48,32,20,10',
     }
     objects = {'texactdiv': 'match', 'tlight1': 'light', 'tlight2': 'light', 'tscatter': 'compact'}   # the source a knob lives in (default: fit)
