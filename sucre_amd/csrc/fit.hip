@@ -1338,56 +1338,48 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
 // threads to an image, sixteen images to a round -- adds its group's partials; the workgroup that arrives last takes every
 // image's total, its step on B, beta, gamma and its log row.  (As the tail of the launch above these trees wanted more
 // registers than its waves have: the kernel spilled.)
-__global__ __launch_bounds__(256) void batch_tail_kernel(const BatchEntry *__restrict__ images, int n_images, int n_blocks, const AdamCoef co, int row) {
-    __shared__ double stot[16][kNumSums];
+constexpr int kTailThreads = 16 * kBatchMax;   // sixteen threads to an image: all images of a launch in ONE round
+__global__ __launch_bounds__(kTailThreads) void batch_tail_kernel(const BatchEntry *__restrict__ images, int n_images, int n_blocks, const AdamCoef co, int row) {
+    __shared__ double stot[kBatchMax][kNumSums];
     __shared__ int is_last;
     const int t = threadIdx.x, g = blockIdx.x, n_groups = gridDim.x;
-    for (int i0 = 0; i0 < n_images; i0 += 16) {
-        const int i = i0 + (t >> 4), q = t & 15;
-        if (i < n_images && q < kNumSums)
-            reduce_group_thread(reinterpret_cast<const float *>(images[i].ws + images[i].o.partials), n_blocks, g, q,
-                                reinterpret_cast<double *>(images[i].ws + images[i].o.gpart), n_groups);
-    }
+    const int i = t >> 4, q = t & 15;
+    const bool mine = i < n_images && q < kNumSums;
+    uint8_t *ws = mine ? images[i].ws : nullptr;
+    if (mine)
+        reduce_group_thread(reinterpret_cast<const float *>(ws + images[i].o.partials), n_blocks, g, q, reinterpret_cast<double *>(ws + images[i].o.gpart), n_groups);
     if (kExpBatch == 1) return;   // (timing experiment, experiment.h)
+    // what the step needs besides the totals is asked for before the arrival (every workgroup: one of them will use it)
+    float p = 0.f, m = 0.f, v = 0.f, Bc = 0.f, scale = 0.f;
+    float *pstate = nullptr;
+    if (mine && q < 9) {
+        pstate = reinterpret_cast<float *>(ws + images[i].o.params);
+        scale = (1.0f / 3.0f) / (float)(*reinterpret_cast<const uint64_t *>(ws + images[i].o.n_obs_total));
+        p = pstate[q]; m = pstate[9 + q]; v = pstate[18 + q];
+        Bc = pstate[q % 3];   // B before its step
+    }
     unsigned *ticket = reinterpret_cast<unsigned *>(images[0].ws + images[0].o.ticket);   // the batch's arrival counter: the first image's
     if (!arrive_last(ticket, (unsigned)n_groups, &is_last)) return;
-    for (int i0 = 0; i0 < n_images; i0 += 16) {
-        const int i = i0 + (t >> 4), q = t & 15, ii = t >> 4;
-        const bool mine = i < n_images && q < kNumSums;
-        uint8_t *ws = mine ? images[i].ws : nullptr;
-        if (mine) {
-            const BatchOffsets &o = images[i].o;
-            const double y = reduce_total_thread(reinterpret_cast<const double *>(ws + o.gpart), n_groups, q);
-            __hip_atomic_store(reinterpret_cast<double *>(ws + o.sums) + q, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            stot[ii][q] = y;
-        }
-        __syncthreads();
-        // water_step (sucre.py:148-152), thread q of an image in the role of lane q
-        float p = 0.f, m = 0.f, v = 0.f;
-        double grad = 0.0;
-        float *pstate = nullptr;
-        if (mine && q < 9) {
-            const BatchOffsets &o = images[i].o;
-            pstate = reinterpret_cast<float *>(ws + o.params);
-            const float scale = (1.0f / 3.0f) / (float)(*reinterpret_cast<const uint64_t *>(ws + o.n_obs_total));
-            const int c = q % 3;
-            if (q < 3) grad = -2.0 * (double)scale * stot[ii][c];
-            else if (q < 6) grad = 2.0 * (double)scale * stot[ii][6 + c];
-            else grad = -2.0 * (double)scale * (double)pstate[c] * stot[ii][3 + c];   // B before its step
-            p = pstate[q]; m = pstate[9 + q]; v = pstate[18 + q];
-        }
-        __syncthreads();   // every B of the round is read before any is overwritten
-        if (mine) {
-            double *trace = images[i].trace;
-            if (q < 9) {
-                adam_update(p, m, v, (float)grad, co);
-                pstate[q] = p; pstate[9 + q] = m; pstate[18 + q] = v;
-                if (trace) trace[(size_t)row * 10 + 1 + q] = (double)p;
-            } else if (trace) {
-                trace[(size_t)row * 10] = stot[ii][9];
-            }
-        }
-        __syncthreads();   // the round's totals are spent before the next round's arrive
+    if (mine) {
+        const double y = reduce_total_thread(reinterpret_cast<const double *>(ws + images[i].o.gpart), n_groups, q);
+        __hip_atomic_store(reinterpret_cast<double *>(ws + images[i].o.sums) + q, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stot[i][q] = y;
+    }
+    __syncthreads();
+    if (!mine) return;
+    // water_step (sucre.py:148-152), thread q of an image in the role of lane q
+    double *trace = images[i].trace;
+    if (q < 9) {
+        const int c = q % 3;
+        double grad;
+        if (q < 3) grad = -2.0 * (double)scale * stot[i][c];
+        else if (q < 6) grad = 2.0 * (double)scale * stot[i][6 + c];
+        else grad = -2.0 * (double)scale * (double)Bc * stot[i][3 + c];
+        adam_update(p, m, v, (float)grad, co);
+        pstate[q] = p; pstate[9 + q] = m; pstate[18 + q] = v;
+        if (trace) trace[(size_t)row * 10 + 1 + q] = (double)p;
+    } else if (trace) {
+        trace[(size_t)row * 10] = stot[i][9];
     }
 }
 
@@ -1600,7 +1592,7 @@ hipError_t launch_batch_iter(const Layout &L, void *batch, int n_images, const A
             if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n, co, row);
             else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n, co, row);
         }
-        hipLaunchKernelGGL(batch_tail_kernel, dim3(L.fit_groups[mode]), block, 0, s, b, n, L.fit_blocks[mode], co, row);
+        hipLaunchKernelGGL(batch_tail_kernel, dim3(L.fit_groups[mode]), dim3(kTailThreads), 0, s, b, n, L.fit_blocks[mode], co, row);
     }
     return hipGetLastError();
 }
