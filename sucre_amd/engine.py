@@ -683,6 +683,22 @@ def current_slot() -> int:
     return getattr(_TLS, 'slot', 0)
 
 
+def current_lane() -> int:
+    return getattr(_TLS, 'lane', 0)
+
+
+@contextlib.contextmanager
+def slot_lane(index: int):
+    """The ``index``-th of several images that share ONE in-flight slot (a survey of small images whose fits advance in one
+    launch per iteration, ``fit_batch``): inside the block ``acquire_restoration`` hands out that image's own workspace; the
+    stream stays the slot's."""
+    prev, _TLS.lane = current_lane(), int(index)
+    try:
+        yield
+    finally:
+        _TLS.lane = prev
+
+
 def acquire_restoration(height: int, width: int, n_views: int, device='cuda', light: bool = False,
                         obs_format: str | None = None, float_colour: bool = False, tag: str = '') -> Restoration:
     """Workspace pool: one Restoration per (geometry, device, in-flight slot, tag), reused image after image (the
@@ -697,7 +713,7 @@ def acquire_restoration(height: int, width: int, n_views: int, device='cuda', li
     # capacities come in steps, so targets whose surviving view counts differ a little share one workspace
     n = int(n_views)
     cap = (n + 7) // 8 * 8 if n <= 256 else (n + 31) // 32 * 32   # (65 views -> 72, not 96: +11 % HBM per slot, not +48 %)
-    key = (int(height), int(width), str(dev), bool(light), current_slot(), obs_format, bool(float_colour), tag)
+    key = (int(height), int(width), str(dev), bool(light), (current_slot(), current_lane()), obs_format, bool(float_colour), tag)
     have = _POOL.get(key)
     if have is None or have.capacity < n:
         _POOL.pop(key, None)   # release the smaller workspace before allocating the larger one

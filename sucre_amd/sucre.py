@@ -391,6 +391,46 @@ def _restore_enqueue_fit(job: _Job) -> None:
     job.trace = resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
 
 
+def _restore_enqueue_fits(jobs: list) -> None:
+    """The fits of several images submitted together.  Images of one size without the extension planes (light model,
+    float32 colours) advance in ONE launch per iteration (``engine.fit_batch``: what a small image pays for most is its own
+    launches -- 640x480 x 5 views: 16.7 us per image and iteration alone, 7.3 in a launch of 32); every image's results are
+    the bits of ``_restore_enqueue_fit``.  Whatever does not fit a batch is fitted by itself."""
+    from . import engine
+    groups: dict = {}
+    singles = []
+    for job in jobs:
+        resto = _adam_begin(job.sucre, job.matches_data, params0=job.params0)
+        job.resto = resto
+        if resto.light or resto.float_colour:
+            singles.append(job)
+        else:
+            groups.setdefault((resto.H, resto.W, resto.obs_format, job.num_iter, job.lr, job.sucre.use_closed_form), []).append(job)
+    for key, members in groups.items():
+        if len(members) == 1:
+            singles.extend(members)
+            continue
+        print(f'Solve least squares with Adam optimizer ({key[3]} iterations), {len(members)} images per launch.')
+        traces = engine.fit_batch([j.resto for j in members], key[3], lr=key[4], use_closed_form=key[5])
+        for j, t in zip(members, traces):
+            j.trace = t
+    for job in singles:
+        print(f'Solve least squares with Adam optimizer ({job.num_iter} iterations).')
+        job.trace = job.resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
+
+
+def fit_batch_size(images: list, light_model: bool = False) -> int:
+    """Images per fit launch in a survey (engine knob ``SUCRE_FIT_BATCH``; not a reference flag).  ``auto``: 8 for images of
+    less than a megapixel (BASELINE config 1's 640x480: 144 -> 215 Mpix/s; 32 per launch: 219), 1 otherwise -- at 1080p a
+    launch of two images is no faster than two launches in flight -- and 1 with the light model."""
+    env = os.environ.get('SUCRE_FIT_BATCH', 'auto').strip().lower()
+    if env != 'auto':
+        return max(1, int(env))
+    if light_model or not images:
+        return 1
+    return 8 if max(int(im.camera.width) * int(im.camera.height) for im in images) < 1_000_000 else 1
+
+
 def _restore_finish(job: _Job, keep_matches: bool, writers: ThreadPoolExecutor | None = None):
     """Results back from the device (the only wait of the image), then the output files (sucre.py:211-219).  With a
     ``writers`` pool the files are written in the background -- percentile stretch, PNG encoding and the .pt take
@@ -441,39 +481,49 @@ def restore_image(image: sfm.Image, colmap_model: sfm.COLMAPModel, output_dir: P
 
 
 def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, output_dir: Path, in_flight: int = 2,
-                   keep_matches: bool = False, device: str = 'cuda', **kw) -> None:
+                   keep_matches: bool = False, device: str = 'cuda', fit_batch: int | None = None, **kw) -> None:
     """A survey: the same per-image pipeline with ``in_flight`` images on the GPU at once (engine.in_flight_slot)
     and the output files written by background threads (SUCRE_WRITER_THREADS).  While image i iterates,
     image i+1 is matched and submitted and the plots of images < i are encoded, so neither the tails of the fit
     launches nor the PNG encoding leave the GPU idle.  Per-image results are the same bits as ``restore_image``
-    (each image has its own workspace and stream; nothing is shared)."""
-    from . import engine
-    pending: list[tuple[int, _Job]] = []
+    (each image has its own workspace and stream; nothing is shared).  ``fit_batch`` consecutive images share a slot and
+    their fits one launch per iteration (``fit_batch_size``; same bits again)."""
+    pending: list[tuple[int, list]] = []
     written = []
-    _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw)
+    if fit_batch is None:
+        fit_batch = fit_batch_size(images, bool(kw.get('light_model', False)))
+    _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw, max(1, int(fit_batch)))
 
 
-def _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw) -> None:
+def _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw, fit_batch: int = 1) -> None:
     from . import engine
     # writer threads: the CPUs this process may use minus two (this thread and the HIP runtime's), at most 32
     with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get('SUCRE_WRITER_THREADS', min(32, loader.effective_cpus() - 2)))),
                             thread_name_prefix='sucre-write') as writers:
-        def finish(slot, job):
+        def finish(slot, jobs):
             with engine.in_flight_slot(slot, device, wait_for_caller=False):
-                written.append(_restore_finish(job, keep_matches, writers))
+                for job in jobs:
+                    written.append(_restore_finish(job, keep_matches, writers))
             while len(written) > 64:                  # bound the host memory held by queued outputs (~50 MB each)
                 written.pop(0).result()
 
-        for i, image in enumerate(images):
-            slot = i % in_flight
+        chunks = [images[i:i + fit_batch] for i in range(0, len(images), fit_batch)]
+        for c, chunk in enumerate(chunks):
+            slot = c % in_flight
             while pending and (len(pending) >= in_flight or pending[0][0] == slot):
                 finish(*pending.pop(0))
             with engine.in_flight_slot(slot, device, wait_for_caller=False):   # inputs: Image.device_view, complete
-                job = _restore_submit(image, colmap_model, output_dir, device=device, defer_checks=True, **kw)
-                _restore_enqueue_fit(job)
-            pending.append((slot, job))
-        for slot, job in pending:
-            finish(slot, job)
+                jobs = []
+                for k, image in enumerate(chunk):
+                    with engine.slot_lane(k):   # every image of the chunk in its own workspace
+                        jobs.append(_restore_submit(image, colmap_model, output_dir, device=device, defer_checks=True, **kw))
+                if len(jobs) == 1:
+                    _restore_enqueue_fit(jobs[0])
+                else:
+                    _restore_enqueue_fits(jobs)
+            pending.append((slot, jobs))
+        for slot, jobs in pending:
+            finish(slot, jobs)
         for f in written:
             f.result()   # re-raises anything a writer thread hit
 

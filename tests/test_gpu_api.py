@@ -366,6 +366,31 @@ def test_cli_images_in_flight_equal_one_by_one(disk_scene, tmp_path, monkeypatch
     assert np.array_equal(np.isnan(J), np.isnan(Jo)) and helpers.rms_per_channel(J, Jo).max() < 1e-5
 
 
+@pytest.mark.parametrize('closed', [False, True], ids=['J-parameter', 'closed-form'])
+def test_cli_fit_batch_equals_one_by_one(disk_scene, tmp_path, monkeypatch, closed, capsys):
+    """A survey of small images through the CLI with several images per fit launch (SUCRE_FIT_BATCH; engine.fit_batch, every
+    image of a chunk in its own workspace on the slot's stream) must write the same bits as one launch per image; ``auto``
+    batches images of this size."""
+    from sucre_amd import sucre
+    root, scene, model, loaded = disk_scene
+    base = ['--image-dir', str(root / 'images'), '--depth-dir', str(root / 'depth'), '--model-dir', str(root / 'model'),
+            '--image-ids', '1', '6', '--num-iter', '20'] + (['--use-closed-form'] if closed else [])
+    outs = {}
+    for mode in ('1', '3', 'auto'):
+        monkeypatch.setenv('SUCRE_FIT_BATCH', mode)
+        out = tmp_path / f'batch{mode}'
+        capsys.readouterr()
+        sucre.main(base + ['--output-dir', str(out)])
+        said = capsys.readouterr().out
+        assert ('images per launch' in said) == (mode != '1'), mode   # the batch path is the one that ran
+        outs[mode] = {p.name: torch.load(p) for p in sorted(out.glob('*.pt'))}
+        assert len(outs[mode]) == 5 and len(list(out.glob('*_rgb.png'))) == 5
+    for mode in ('3', 'auto'):
+        for name, state in outs['1'].items():
+            for k, v in state.items():
+                assert torch.equal(torch.nan_to_num(v, nan=-7.0), torch.nan_to_num(outs[mode][name][k], nan=-7.0)), (mode, name, k)
+
+
 def test_plot_J_on_the_device_equals_the_host_path():
     """SUCRe.plot_J with J on the GPU (order statistics by radix select, one stretch kernel: sucre_select_ranks,
     sucre_plot_stretch) must give the same image as the host path, which tests/test_host_logic.py pins to
