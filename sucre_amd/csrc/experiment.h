@@ -156,3 +156,11 @@ constexpr bool kExpMatchCountOnly = false;
 #define SUCRE_EXP_BATCH_CHAIN 1
 #endif
 constexpr bool kExpBatchChain = SUCRE_EXP_BATCH_CHAIN != 0;
+
+// J-parameter kernels, timing only: the stepped state of every strip written to ONE place per wave (wrong results): what of
+// the stores' cost is their issue and acknowledgement, and what the write stream to HBM.
+#ifdef SUCRE_EXP_STORE_LOCAL
+constexpr bool kExpStoreLocal = true;
+#else
+constexpr bool kExpStoreLocal = false;
+#endif

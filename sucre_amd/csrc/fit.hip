@@ -795,14 +795,19 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
         },
         [&](uint32_t strip, const uint8_t *sp) {  // moments landed: torch.optim.Adam on this pixel's J
             const float *f = reinterpret_cast<const float *>(sp);
-            float *st = state + (size_t)strip * kStateFloats;
+            // (kExpStoreLocal, timing only: every wave writes ONE strip's place over and over -- the stores are issued and
+            // acknowledged like the product's, but the lines stay in L2)
+            float *st = state + (size_t)(kExpStoreLocal ? blockIdx.x * 4u + (uint32_t)wave : strip) * kStateFloats;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float Jc = J[c], m = f[c * kStripPx + lane], v = f[(3 + c) * kStripPx + lane];
                 // unobserved pixels: zero sum, and J (possibly NaN) must not leak into the beta gradient
                 sBeta[c] += (acc.pb[c] == 0.0f) ? 0.0f : Jc * acc.pb[c];
                 adam_update_J(Jc, m, v, gscale * acc.pa[c], co);
-                if (kExpNoStore && gscale != -1234.5f) continue;   // ablation build only: the step is computed, nothing is written
+                if (kExpNoStore) {   // ablation build only: the step is computed (the asm keeps it alive), nothing is written
+                    asm volatile("" ::"v"(Jc), "v"(m), "v"(v));
+                    continue;
+                }
                 if (kStoreNt == 1 || (kStoreNt == 2 && Chain::kOn)) {
                     __builtin_nontemporal_store(Jc, &st[c * kStripPx + lane]);
                     __builtin_nontemporal_store(m, &st[(3 + c) * kStripPx + lane]);
