@@ -2,7 +2,7 @@
 """Self-consistency sweep of the command line on the GPU box: random synthetic surveys on disk (sizes, grids), random
 reference flags (--use-closed-form, --light-model, --image-scale, --num-iter, --min-cover, --save-interval,
 --keep-matches), each restored twice -- once with the engine's default knobs and once with a random other setting of the
-knobs that must NOT change a single output byte (images in flight, packed views, overlap cull, decode / PNG threads and
+knobs that must NOT change a single output byte (images in flight, images per fit launch, packed views, overlap cull, decode / PNG threads and
 processes, one rank vs two ranks).  Every file of the two output directories must be identical; with --keep-matches a third
 run over the kept matches files (the import path instead of matching) must reproduce the outputs too.
     python3 tools/cli_sweep.py [n_cases] [seed0]"""
@@ -74,6 +74,8 @@ def main():
             if rng.random() < 0.3:
                 knobs['SUCRE_DECODE_IN_WORKERS'] = '0'
             two_ranks = rng.random() < 0.3
+            if rng.random() < 0.6:   # (round 5) the default is auto: images of these sizes fit 8 per launch
+                knobs['SUCRE_FIT_BATCH'] = str(int(rng.choice([1, 2, 5])))
             run([sys.executable, '-m', 'sucre_amd.sucre', '--output-dir', str(tmp / 'a')] + common, base_env)
             env_b = dict(base_env, **knobs)
             if two_ranks:
