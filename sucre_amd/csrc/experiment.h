@@ -164,3 +164,10 @@ constexpr bool kExpStoreLocal = true;
 #else
 constexpr bool kExpStoreLocal = false;
 #endif
+
+// wave_sums through __shfl_down (ds_bpermute) as until round 5, for the same-box A/B of the register-to-register form.
+#ifdef SUCRE_EXP_SHFL_SUMS
+constexpr bool kExpShflSums = true;
+#else
+constexpr bool kExpShflSums = false;
+#endif

@@ -625,7 +625,7 @@ def test_experiment_variants_compile(tmp_path):
         'tlight1': '-DSUCRE_EXP_LIGHT_WATER_PASS1 -DSUCRE_EXP_NOCOMPUTE',
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
-        'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL',
+        'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL -DSUCRE_EXP_SHFL_SUMS',
         'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0',
         'thalf': '-DSUCRE_EXP_HALF_EXPS -DSUCRE_CLOSED_WAVES=5 -DSUCRE_EXP_NO_BATCH_CLOSED -DSUCRE_DEAL_CLOSED=64,48,32,20,10',
     }
