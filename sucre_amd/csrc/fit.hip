@@ -696,16 +696,6 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
     }
 }
 
-// lane l <- x of lane l + kOff, for the lanes whose partner sits in the same half (32), quarter (16) or row of the wave: what
-// lane 0's tree needs at every level.  Register-to-register (v_permlane32_swap / v_permlane16_swap of gfx950, DPP row shifts);
-// __shfl_down goes through the LDS crossbar (ds_bpermute: sixty of them and as many waits per image in a batch launch).
-template <int kOff>
-__device__ __forceinline__ float lane_down(float x) {
-    if constexpr (kOff == 32) return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-    else if constexpr (kOff == 16) return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + kOff, 0xf, 0xf, true));   // row_shl:kOff
-}
-
 // The lanes' ten sums -> lane 0 holds the wave's: x_l + x_(l+32), then + (l+16), ... + (l+1) -- the additions of the
 // __shfl_down tree that lane 0 depends on, in its association (the other lanes end with values nobody reads).
 __device__ __forceinline__ void wave_sums(float (&s)[kNumSums]) {
@@ -715,12 +705,7 @@ __device__ __forceinline__ void wave_sums(float (&s)[kNumSums]) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
         } else {
-            s[q] += lane_down<32>(s[q]);
-            s[q] += lane_down<16>(s[q]);
-            s[q] += lane_down<8>(s[q]);
-            s[q] += lane_down<4>(s[q]);
-            s[q] += lane_down<2>(s[q]);
-            s[q] += lane_down<1>(s[q]);
+            s[q] = wave_sum_lane0(s[q]);
         }
     }
 }

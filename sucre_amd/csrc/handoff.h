@@ -1,4 +1,4 @@
-// In-launch hand-off between workgroups (fit.hip, light.hip): the last workgroup to arrive on a counter continues with
+// In-launch hand-off between workgroups (fit.hip): the last workgroup to arrive on a counter continues with
 // everybody's results, so a reduction + parameter step needs no second launch.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,6 +27,28 @@ __device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned expected
     }
     __syncthreads();
     return *flag != 0;
+}
+
+// lane l <- x of lane l + kOff, for the lanes whose partner sits in the same half (32), quarter (16) or row of the wave: what
+// lane 0's tree needs at every level.  Register-to-register (v_permlane32_swap / v_permlane16_swap of gfx950, DPP row shifts);
+// __shfl_down goes through the LDS crossbar (ds_bpermute: sixty of them and as many waits per image in a batch launch).
+template <int kOff>
+__device__ __forceinline__ float lane_down(float x) {
+    if constexpr (kOff == 32) return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+    else if constexpr (kOff == 16) return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
+    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + kOff, 0xf, 0xf, true));   // row_shl:kOff
+}
+
+// lane 0 <- the wave's sum in the association of  for (off = 32; off; off >>= 1) x += __shfl_down(x, off)  (the other lanes end
+// with values nobody reads).
+__device__ __forceinline__ float wave_sum_lane0(float x) {
+    x += lane_down<32>(x);
+    x += lane_down<16>(x);
+    x += lane_down<8>(x);
+    x += lane_down<4>(x);
+    x += lane_down<2>(x);
+    x += lane_down<1>(x);
+    return x;
 }
 
 }  // namespace sucre

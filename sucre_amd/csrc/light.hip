@@ -17,6 +17,7 @@
 #include <type_traits>
 #include <mutex>
 #include "fit_math.h"
+#include "handoff.h"
 
 namespace sucre {
 
@@ -575,9 +576,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
     // workgroup sums: shuffle tree, then the four waves in fixed order
 #pragma unroll
     for (int q = 0; q < kLightSums; ++q) {
-        float x = acc.s[q];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        const float x = wave_sum_lane0(acc.s[q]);   // (handoff.h: the __shfl_down tree's additions, register to register)
         if (lane == 0) wsum[wave][q] = x;
     }
     __syncthreads();
