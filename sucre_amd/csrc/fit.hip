@@ -630,10 +630,13 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
 //   sums[q]     = sum over the groups                  (4 loads per lane + the same tree)
 // The same two functions run in the fused tail (group-last / global-last workgroup) and in the split-path
 // kernel, so both paths produce the same bits.  All hand-off data move with agent-scope (sc1) accesses.
-__device__ __forceinline__ double wave_sum_fixed(double x) {  // fixed-shape tree: same bits on every run
+__device__ __forceinline__ double wave_sum_fixed(double x) {  // fixed-shape tree: same bits on every run (lane 0 holds the sum)
+    if (kExpShflSums) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        return x;
+    }
+    return wave_sum_lane0(x);   // the same additions, register to register (handoff.h)
 }
 
 // 256 threads: wave w reduces quantities q = w, w+4, w+8; lane l holds workgroup 32 g + l (lanes >= 32 hold 0).

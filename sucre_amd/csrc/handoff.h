@@ -33,15 +33,24 @@ __device__ __forceinline__ bool arrive_last(unsigned *counter, unsigned expected
 // lane 0's tree needs at every level.  Register-to-register (v_permlane32_swap / v_permlane16_swap of gfx950, DPP row shifts);
 // __shfl_down goes through the LDS crossbar (ds_bpermute: sixty of them and as many waits per image in a batch launch).
 template <int kOff>
-__device__ __forceinline__ float lane_down(float x) {
-    if constexpr (kOff == 32) return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-    else if constexpr (kOff == 16) return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]);
-    else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + kOff, 0xf, 0xf, true));   // row_shl:kOff
+__device__ __forceinline__ uint32_t lane_down_bits(uint32_t x) {
+    if constexpr (kOff == 32) return __builtin_amdgcn_permlane32_swap(x, x, false, false)[1];
+    else if constexpr (kOff == 16) return __builtin_amdgcn_permlane16_swap(x, x, false, false)[1];
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x100 + kOff, 0xf, 0xf, true);   // row_shl:kOff
+}
+template <int kOff>
+__device__ __forceinline__ float lane_down(float x) { return __uint_as_float(lane_down_bits<kOff>(__float_as_uint(x))); }
+template <int kOff>
+__device__ __forceinline__ double lane_down(double x) {
+    const uint64_t u = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = lane_down_bits<kOff>((uint32_t)u), hi = lane_down_bits<kOff>((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
 // lane 0 <- the wave's sum in the association of  for (off = 32; off; off >>= 1) x += __shfl_down(x, off)  (the other lanes end
 // with values nobody reads).
-__device__ __forceinline__ float wave_sum_lane0(float x) {
+template <class T>
+__device__ __forceinline__ T wave_sum_lane0(T x) {
     x += lane_down<32>(x);
     x += lane_down<16>(x);
     x += lane_down<8>(x);

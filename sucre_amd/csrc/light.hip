@@ -278,9 +278,7 @@ __device__ __forceinline__ void light_reduce(const float *partials, int n_blocks
     }
 #pragma unroll
     for (int q = 0; q < kLightSums; ++q) {
-        double y = x[q];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) y += __shfl_down(y, off, 64);
+        const double y = wave_sum_lane0(x[q]);
         if (lane == 0) w4[q][wave] = y;
     }
     __syncthreads();
