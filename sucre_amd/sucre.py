@@ -567,10 +567,20 @@ def parse_args(args: argparse.Namespace):
         n_io = int(os.environ.get('SUCRE_IO_PROCESSES', max(1, cpus - 2)))
         if n_io > 0:
             _pixelio.start_pool(n_io)
+    # The host's torch work is all tiny (3x3 inverses and products per view, nine-number parameter vectors): with its default of
+    # one intra-op thread per core every such call wakes the whole OpenMP team -- 2 ms instead of 0.1 ms per camera on a 16-core
+    # box with the decode and writer threads next to it (tools/cli_survey_bench.py: 20 -> 16.5 ms per 640x480 image, 49 -> 41 per
+    # 1080p image).  SUCRE_HOST_TORCH_THREADS (1; 0 = leave torch alone); restored on the way out.
+    host_threads = int(os.environ.get('SUCRE_HOST_TORCH_THREADS', '1'))
+    threads_before = torch.get_num_threads()
+    if host_threads > 0:
+        torch.set_num_threads(host_threads)
     try:
         _run_request(args, images, image_list, colmap_model, device, survey, in_flight)
     finally:
         _pixelio.stop_pool()
+        if host_threads > 0:
+            torch.set_num_threads(threads_before)
 
 
 def _run_request(args, images, image_list, colmap_model, device, survey: bool, in_flight: int) -> None:

@@ -74,6 +74,8 @@ def main():
             if rng.random() < 0.3:
                 knobs['SUCRE_DECODE_IN_WORKERS'] = '0'
             two_ranks = rng.random() < 0.3
+            if rng.random() < 0.3:
+                knobs['SUCRE_HOST_TORCH_THREADS'] = '0'
             if rng.random() < 0.6:   # (round 5) the default is auto: images of these sizes fit 8 per launch
                 knobs['SUCRE_FIT_BATCH'] = str(int(rng.choice([1, 2, 5])))
             run([sys.executable, '-m', 'sucre_amd.sucre', '--output-dir', str(tmp / 'a')] + common, base_env)
