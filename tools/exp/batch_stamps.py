@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where ONE wave of a batch launch spends an image (experiment build with stamps in batch_iter_kernel / stream_strips):
-    make -C sucre_amd/csrc VARIANT=stamps EXTRA=-DSUCRE_EXP_WAVE_TIMES
+"""Where ONE wave of a batch launch spends an image.  Needs the stamps of tools/exp/batch_stamps.patch in batch_iter_kernel /
+stream_strips (git apply it; the stamped J-parameter kernel spills 20 bytes per lane, which the Makefile refuses: build fit.hip by
+hand with the Makefile's flags + -DSUCRE_EXP_WAVE_TIMES and link the six objects into sucre_amd/libsucre_hip_stamps.so):
     SUCRE_HIP_LIB=$PWD/sucre_amd/libsucre_hip_stamps.so python3 tools/exp/batch_stamps.py
 Stamps: 1 image begins, 10 step begins, 13 the step's item has landed (after both waits), 4 pass done, 5 sums in LDS."""
 import ctypes
