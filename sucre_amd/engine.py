@@ -84,6 +84,21 @@ class DeviceView:
             self.__dict__['_packed'] = [key, out, done, True]   # one entry: records, their event and "not known complete yet"
             return out
 
+    def repack(self) -> None:
+        """Builds the records again, in place, on the CURRENT stream (same bytes; allocation-free): what a caller pays who
+        meets this view for the first time -- bench.py charges it to every timed image (VERDICT round 5, weak point 5)."""
+        records = self.packed_records()
+        self.wait_packed()
+        H, W = self.depth.shape
+        with torch.cuda.device(self.depth.device):
+            _lib.check(_lib.load().sucre_pack_view(C.c_void_p(self.depth.data_ptr()), C.c_void_p(self.rgb.data_ptr()), H, W,
+                                                   C.c_void_p(records.data_ptr()), _stream_ptr()))
+
+    def twin(self) -> 'DeviceView':
+        """The same pixels and matrices as a view of its own: own packed records, own struct caches (bench.py gives every
+        in-flight slot its own, so that one slot's ``repack`` never rewrites records another slot's match kernel is reading)."""
+        return DeviceView(depth=self.depth, rgb=self.rgb, K=self.K, R=self.R, t=self.t, name=self.name, Kinv=self.Kinv, tinv=self.tinv)
+
     def wait_packed(self) -> None:
         """Makes the current stream wait for this view's records (nothing once they are known to be complete)."""
         entry = self.__dict__.get('_packed')

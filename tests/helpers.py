@@ -336,7 +336,7 @@ def check_baseline_matches(b, counts, maps, label):
                   maps=f'{n_maps}/{len(ref_counts)}' if maps is not None else '-')
 
 
-def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, trace_key=None, light_bar=None):
+def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, trace_key=None, light_bar=None, mode=None):
     """A full (H,W,3) J and a (T, >=10) trace against what the REFERENCE stored: J[::stride, ::stride], the NaN count
     and the per-channel sums of J and J^2 over the whole image, the (T,10) cost / B / beta / gamma trajectory."""
     st = max(int(b['stride']), 4) if key == 'param_1' else int(b['stride'])
@@ -364,7 +364,7 @@ def check_baseline_fit(b, key, J, trace, rms_bar, param_bar, cost_bar, label, tr
         assert out['dcost'] < cost_bar, (label, key, 'cost trajectory', out['dcost'])
     print(f'{label} [{key}] vs the REFERENCE: rms(J)={rms} |dmean|={dmean.max():.2e} '
           f'max|dparams|={out.get("dpar", float("nan")):.2e} max rel dcost={out.get("dcost", float("nan")):.2e}')
-    record_parity(label, key, b, rms=rms, dpar=out.get('dpar'), dcost=out.get('dcost'), dlight=out.get('dlight'),
+    record_parity(label, mode or key, b, rms=rms, dpar=out.get('dpar'), dcost=out.get('dcost'), dlight=out.get('dlight'),
                   T=None if trace is None else int(trace.shape[0]), bars=(rms_bar, param_bar, cost_bar))
     return out
 

@@ -266,3 +266,45 @@ def test_config2_shared_water_engine_vs_reference():
             helpers.check_baseline_fit(b, f'shared{i}', x.J().cpu().numpy(), None, 1e-6, 0, 0, f'ENGINE, config 2 shared water ({path}), image {i}')
         del rs
         torch.cuda.empty_cache()
+
+
+# ---- round 6: BASELINE config 5's LOSSY store (uint16 millimetres, 5 B/observation) against the REFERENCE ITSELF -------------
+# Until round 5 every `u16mm` check at size compared the engine with the oracle fed the same quantised ranges: that shows the
+# kernel implements the format, not that the format meets the north star's 1e-4 against the reference, which never rounds a
+# range (VERDICT round 5, weak point 1).  Here the engine's u16mm store runs on the reference-made goldens -- unquantised
+# reference outputs -- at config 5's view count, at config 2's size in full (200 + 60 iterations) and on config 1 in full.
+# The J bar is the north star's 1e-4; parameter / cost bars are a few times what tools/exp/u16mm_vs_reference.py measured with
+# the oracle on the CPU (the engine's own figures are in the terminal summary, mode 'u16mm' / 'u16mm closed').
+U16MM_CASES = {
+    # fixture: (RMS(J) bar, |dparams| bar, rel dcost bar) J-parameter mode; the same for closed form
+    helpers.BASELINE_C5VIEWS: ((1e-4, 1e-6, 5e-6), (1e-4, 2e-5, 1e-4)),
+    helpers.BASELINE_C1: ((1e-4, 2e-6, 5e-5), (1e-4, 3e-4, 2e-4)),
+    helpers.BASELINE_C2FULL: ((1e-4, 2e-6, 5e-5), (1e-4, 3e-4, 2e-4)),
+}
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('name', list(U16MM_CASES))
+def test_u16mm_store_engine_vs_unquantised_reference(name):
+    from sucre_amd import _lib, engine
+    b = helpers.load_baseline(name)
+    sc = b.scene
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views), obs_format='u16mm')
+    r.match(views[sc.target], views)
+    # the store is lossy, the matching is not: same match sets, same counts
+    helpers.check_baseline_matches(b, r.view_counts().cpu().numpy().tolist(), None, f'{name} engine u16mm')
+    assert r.n_obs() == int(b['n_obs']) and int(r.store_format()[0].item()) == _lib.STORE_U16MM
+    bars_p, bars_c = U16MM_CASES[name]
+    r.fit_init(views[sc.target])
+    trace = r.fit(T_param).cpu().numpy()
+    torch.cuda.synchronize()
+    helpers.check_baseline_fit(b, 'param', r.J().cpu().numpy(), trace, *bars_p, f'ENGINE u16mm store, {name}, {T_param} iterations', mode='u16mm')
+    r.fit_init(views[sc.target])
+    trace_c = r.fit(T_closed, use_closed_form=True).cpu().numpy()
+    torch.cuda.synchronize()
+    helpers.check_baseline_fit(b, 'closed', r.J().cpu().numpy(), trace_c, *bars_c, f'ENGINE u16mm store, {name}, {T_closed} closed-form iterations',
+                               mode='u16mm closed')
+    del r, views
+    torch.cuda.empty_cache()

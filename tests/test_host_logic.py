@@ -831,3 +831,40 @@ def test_bench_presets_respect_explicit_flags(monkeypatch):
     assert a.shared_water and a.batch_images == 64 and bench.baseline_config(a) == 4
     a = parse('--gpus', '8', '--steps', '5', '--warmup', '1')      # the driver's own line
     assert (a.gpus, a.steps, a.warmup, a.fit_batch) == (8, 5, 1, 1) and bench.baseline_config(a) == 2
+
+
+def test_bench_finds_the_profile_of_exactly_its_own_mode(monkeypatch, tmp_path):
+    """``roofline.traffic`` / ``profile_frac`` come from profiles/rNN_<mode>_traffic.json of the mode the flags describe -- the
+    mode EXACTLY: until round 5 a glob made ``--use-closed-form`` read the light + closed-form kernel's file (VERDICT round 5,
+    weak point 4).  Every mode of tools/profile.sh maps to files of its own name only, newest round first."""
+    import importlib
+    import json
+    import re
+    bench = importlib.import_module('bench')
+
+    def tag(*argv):
+        monkeypatch.setattr('sys.argv', ['bench.py', *argv])
+        return bench.profile_tag(bench.parse())
+    modes = {'jparam': (), 'closed': ('--use-closed-form',), 'light': ('--light-model',), 'light_closed': ('--light-model', '--use-closed-form'),
+             'u16mm_4k': ('--config', '5'), 'shared4': ('--shared-water', '--batch-images', '4'), 'jparam_batch32': ('--config', '1'),
+             'closed_batch32': ('--config', '1', '--use-closed-form'), 'jparam_f32plain': ('--obs-format', 'f32plain'),
+             'shared64': ('--config', '4')}
+    for mode, argv in modes.items():
+        assert tag(*argv) == mode
+    # every mode tools/profile.sh knows is one bench.py can name (the in-flight variant is the default command's second profile)
+    sh = (helpers.ROOT / 'tools' / 'profile.sh').read_text()
+    for mode in re.findall(r'^\s+(\w+)\) echo', sh, flags=re.M):
+        assert mode in modes or mode == 'jparam_inflight2', mode
+    for name in ('r05_closed', 'r05_light_closed', 'r04_closed', 'r06_closed', 'r06_closed_batch32', 'r05_jparam', 'r02', 'r05_jparam_inflight2',
+                 'r05_jparam_batch32', 'r06_jparam_f32plain', 'r10_closed'):
+        (tmp_path / f'{name}_traffic.json').write_text(json.dumps({'n_obs': 1}))
+    (tmp_path / 'r05_closed_summary.txt').write_text('')
+    got = {m: [f.name for f in bench.profile_candidates(m, tmp_path)] for m in modes}
+    assert got['closed'] == ['r10_closed_traffic.json', 'r06_closed_traffic.json', 'r05_closed_traffic.json', 'r04_closed_traffic.json']
+    assert got['light_closed'] == ['r05_light_closed_traffic.json']
+    assert got['closed_batch32'] == ['r06_closed_batch32_traffic.json']
+    assert got['jparam'] == ['r05_jparam_traffic.json', 'r02_traffic.json'] and got['jparam_batch32'] == ['r05_jparam_batch32_traffic.json']
+    assert got['jparam_f32plain'] == ['r06_jparam_f32plain_traffic.json'] and got['shared64'] == []
+    # the committed tree: the closed-form line reads the closed-form kernel's file
+    newest = bench.profile_candidates('closed')[0]
+    assert json.loads(newest.read_text())['kernel'].startswith('fit_closed_kernel'), newest.name
