@@ -58,8 +58,10 @@ extern "C" {
  * colours = 7 B/observation, lossless for the reference's data (default).  How the library keeps those float32 ranges is
  * its own business as long as every bit comes back: when all ranges of an image lie within 2^24 - 2 float32 bit patterns
  * of the smallest one (a span of about a factor of four) and nothing rides along in extension planes, the finalize step
- * stores them as 24-bit offsets from it (6 B/observation, decided on the device, no host synchronisation); results are
- * bit-identical either way.  SUCRE_OBS_F32_PLAIN asks for the float32 words themselves (A/B measurements, tests).
+ * stores them as 24-bit offsets from it (6 B/observation, decided on the device, no host synchronisation); an image whose
+ * ranges span more than that but lie within 2^26 - 2 bit patterns (a factor of up to 256 between the nearest and the
+ * farthest range) is stored as 26-bit offsets, 6.25 B/observation; wider still, as the float32 words.  Results are
+ * bit-identical whichever it is.  SUCRE_OBS_F32_PLAIN asks for the float32 words themselves (A/B measurements, tests).
  * SUCRE_OBS_U16MM: the range as uint16 millimetres, rint(1000 z) clamped to [1, 65535] = 5 B/observation (BASELINE
  * config 5) -- lossy by at most 0.5 mm of range; every sum is still accumulated in float32/float64 exactly as with
  * SUCRE_OBS_F32.  A store finalised with SUCRE_OBS_F32 or SUCRE_OBS_F32_PLAIN is fitted WITHOUT SUCRE_FIT_OBS_U16MM.
@@ -67,6 +69,7 @@ extern "C" {
 #define SUCRE_OBS_F32 0
 #define SUCRE_OBS_U16MM 1
 #define SUCRE_OBS_F32_PLAIN 2
+#define SUCRE_OBS_F32_Z26 3   /* SUCRE_OBS_F32 that may only choose the 26-bit offsets (below) or the words: tests, A/B */
 
 /*
  * What the three float32 extension planes of the second workspace (`lws`, see the *_light entry points) carry per
@@ -110,8 +113,9 @@ enum {
     SUCRE_WS_SUMS = 4,       /* float64[12]      reduced gradient sums of the last sucre_fit_grad (multi-GPU) */
     SUCRE_WS_N_OBS_TOTAL = 5,/* uint64[1]        n_obs used for the 1/(3 n_obs) scale (shared-water: summed over ranks) */
     SUCRE_WS_STORE_FORMAT = 6/* uint32[4]        how sucre_finalize_matches* laid the observations out: 0 = float32 ranges,
-                                                 1 = uint16 millimetres, 2 = 24-bit offsets of the float32 bit patterns; the
-                                                 offset; the smallest and the largest float32 bit pattern among the ranges */
+                                                 1 = uint16 millimetres, 2 = 24-bit, 3 = 26-bit offsets of the float32 bit
+                                                 patterns; the offset; the smallest and the largest float32 bit pattern among
+                                                 the ranges */
 };
 
 int sucre_version(void);

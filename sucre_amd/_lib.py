@@ -18,11 +18,11 @@ FIT_OBS_U16MM = 2
 FIT_EXT_COLOUR = 4
 FIT_EXT_BOTH = 16
 FIT_KEEP_J = 8
-OBS_F32, OBS_U16MM, OBS_F32_PLAIN = 0, 1, 2
+OBS_F32, OBS_U16MM, OBS_F32_PLAIN, OBS_F32_Z26 = 0, 1, 2, 3
 EXT_POINTS, EXT_COLOUR, EXT_POINTS_COLOUR = 1, 2, 3
-OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM, 'f32plain': OBS_F32_PLAIN}
+OBS_FORMATS = {'f32': OBS_F32, 'u16mm': OBS_U16MM, 'f32plain': OBS_F32_PLAIN, 'f32z26': OBS_F32_Z26}
 WS_VIEW_COUNT, WS_VIEW_KEEP, WS_N_OBS, WS_PARAMS, WS_SUMS, WS_N_OBS_TOTAL, WS_STORE_FORMAT = range(7)
-STORE_F32, STORE_U16MM, STORE_Z24 = 0, 1, 2   # what the compaction chose (SUCRE_WS_STORE_FORMAT)
+STORE_F32, STORE_U16MM, STORE_Z24, STORE_Z26 = 0, 1, 2, 3   # what the compaction chose (SUCRE_WS_STORE_FORMAT)
 
 
 class SucreView(C.Structure):

@@ -156,7 +156,7 @@ int sucre_finalize_matches_fmt(void *ws, int H, int W, int n_views, double min_c
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
     if (std::isnan(min_cover)) return fail(SUCRE_ERR_ARG, "min_cover is NaN");
-    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN)
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN && obs_format != SUCRE_OBS_F32_Z26)
         return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
     return check_hip(launch_finalize(L, static_cast<uint8_t *>(ws), min_cover, static_cast<hipStream_t>(stream),
                                      nullptr, nullptr, obs_format), "sucre_finalize_matches_fmt");
@@ -236,7 +236,7 @@ int sucre_update_J(void *ws, int H, int W, int n_views, void *stream) {
 int sucre_update_J_fmt(void *ws, int H, int W, int n_views, int obs_format, void *stream) {
     Layout L;
     if (int rc = check_ws(ws, H, W, n_views, &L)) return rc;
-    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN)
+    if (obs_format != SUCRE_OBS_F32 && obs_format != SUCRE_OBS_U16MM && obs_format != SUCRE_OBS_F32_PLAIN && obs_format != SUCRE_OBS_F32_Z26)
         return fail(SUCRE_ERR_ARG, "unknown observation format %d", obs_format);
     return check_hip(launch_update_J(L, static_cast<uint8_t *>(ws), obs_format == SUCRE_OBS_U16MM ? SUCRE_OBS_U16MM : SUCRE_OBS_F32,
                                      static_cast<hipStream_t>(stream)),

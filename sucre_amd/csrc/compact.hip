@@ -199,10 +199,17 @@ __global__ __launch_bounds__(256) void permute_kernel(const uint16_t *__restrict
 // 3a. levels of every strip (64 consecutive sorted pixels) = the largest pixel count in it; the chunks wholly below
 //     the smallest count hold real observations only, which lets the fit skip the validity select there.
 //     One workgroup per sorted tile = four strips, one per wave; also the tile's total, for the offsets below.
+__device__ __forceinline__ uint32_t choose_store_format(uint32_t lo, uint32_t hi, int fmt_req, int allow);
+
 __global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__restrict__ pcount,
                                                            const uint32_t *__restrict__ perm,
-                                                           StripMeta *__restrict__ meta, uint32_t *__restrict__ tile_levels) {
+                                                           StripMeta *__restrict__ meta, uint32_t *__restrict__ tile_levels,
+                                                           const uint64_t *__restrict__ total_levels, int fmt_req, int allow) {
     __shared__ uint32_t lv[kStripsPerTile];
+    // (the store's format is a function of the ranges' span, which view_total_kernel has left behind: every workgroup works it
+    // out for itself; tile_offset_kernel records it)
+    const uint32_t *fw = reinterpret_cast<const uint32_t *>(total_levels + 1);
+    const int fmt = (int)choose_store_format(fw[2], fw[3], fmt_req, allow);
     const int t = threadIdx.x;
     uint32_t mx = pcount[perm[(size_t)blockIdx.x * kTilePx + t]], mn = mx;
 #pragma unroll
@@ -217,18 +224,27 @@ __global__ __launch_bounds__(256) void strip_levels_kernel(const uint16_t *__res
         lv[t >> 6] = mx;
     }
     __syncthreads();
-    if (t == 0) tile_levels[blockIdx.x] = lv[0] + lv[1] + lv[2] + lv[3];
+    if (t == 0) tile_levels[blockIdx.x] = padded_levels(fmt, lv[0]) + padded_levels(fmt, lv[1]) + padded_levels(fmt, lv[2]) + padded_levels(fmt, lv[3]);
 }
 
-// What the store will be: the format the caller asked for, except that float32 ranges become 24-bit codes (kStoreZ24, layout.h)
-// when the caller allows it and every range of the image lies within 2^24 - 2 bit patterns of the smallest one (view_total_kernel
-// left both ends behind the format word).  One thread; the scatter, the plan and the fit kernels read the two words.
-__device__ __forceinline__ void decide_store_format(uint64_t *total_levels, int fmt_req, int allow_z24) {
+// What the store will be: the format the caller asked for, except that float32 ranges become range CODES (layout.h) when the
+// caller allows it: 24-bit ones (kStoreZ24) when every range of the image lies within 2^24 - 2 bit patterns of the smallest
+// one, 26-bit ones (kStoreZ26) within 2^26 - 2 (view_total_kernel left both ends behind the format word).  allow: bit 0 = 24-bit
+// codes, bit 1 = 26-bit codes may be chosen.
+__device__ __forceinline__ uint32_t choose_store_format(uint32_t lo, uint32_t hi, int fmt_req, int allow) {
+    if (fmt_req != kStoreF32 || !(hi >= lo && lo >= 2u)) return (uint32_t)fmt_req;
+    const uint32_t span = hi - lo;
+    if ((allow & 1) && span <= 0xfffffdu) return (uint32_t)kStoreZ24;
+    if ((allow & 2) && span <= 0x3fffffdu) return (uint32_t)kStoreZ26;
+    return (uint32_t)kStoreF32;
+}
+
+// One thread records it; the scatter, the plan and the fit kernels read the two words.
+__device__ __forceinline__ void decide_store_format(uint64_t *total_levels, int fmt_req, int allow) {
     uint32_t *w = reinterpret_cast<uint32_t *>(total_levels + 1);   // [0] format, [1] code offset, [2] smallest, [3] largest range bits
-    const uint32_t lo = w[2], hi = w[3];
-    const bool z24 = fmt_req == kStoreF32 && allow_z24 && hi >= lo && lo >= 2u && hi - lo <= 0xfffffdu;
-    w[0] = z24 ? (uint32_t)kStoreZ24 : (uint32_t)fmt_req;
-    w[1] = z24 ? lo - 1u : 0u;
+    const uint32_t f = choose_store_format(w[2], w[3], fmt_req, allow);
+    w[0] = f;
+    w[1] = (f == (uint32_t)kStoreZ24 || f == (uint32_t)kStoreZ26) ? w[2] - 1u : 0u;
 }
 
 // 3b. where every strip's chunks start, in levels: exclusive scan of the sorted tiles' totals by one workgroup of 1024
@@ -236,7 +252,7 @@ __device__ __forceinline__ void decide_store_format(uint64_t *total_levels, int 
 //     strips.  (Scanning the 16-byte StripMeta records themselves in one workgroup took 62 us per image.)
 __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__restrict__ tile_levels, int n_tiles,
                                                            uint64_t *__restrict__ tile_off, uint64_t *__restrict__ total_levels,
-                                                           int fmt, int allow_z24) {
+                                                           int fmt, int allow) {
     __shared__ unsigned long long wave_base[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (n_tiles + 1023) / 1024;
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__res
     }
     if (t == 0) {
         *total_levels = total;
-        decide_store_format(total_levels, fmt, allow_z24);  // what the scatter, the plan and the fit kernels must be told
+        decide_store_format(total_levels, fmt, allow);  // what the scatter, the plan and the fit kernels must be told
     }
     for (int i0 = lo; i0 < hi; i0 += 8) {
         uint32_t v[8];
@@ -275,15 +291,16 @@ __global__ __launch_bounds__(1024) void tile_offset_kernel(const uint32_t *__res
 }
 
 __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict__ meta, const uint64_t *__restrict__ tile_off,
-                                                           int n_tiles) {
+                                                           int n_tiles, const uint32_t *__restrict__ store_fmt) {
     const int tile = blockIdx.x * 256 + threadIdx.x;
     if (tile >= n_tiles) return;
+    const int fmt = (int)store_fmt[0];   // (tile_offset_kernel has recorded it)
     uint64_t run = tile_off[tile];
 #pragma unroll
     for (int i = 0; i < kStripsPerTile; ++i) {
         StripMeta *m = meta + (size_t)tile * kStripsPerTile + i;
         m->lvoff = run;
-        run += m->levels;
+        run += padded_levels(fmt, m->levels);
     }
 }
 
@@ -296,8 +313,11 @@ __global__ __launch_bounds__(256) void strip_offset_kernel(StripMeta *__restrict
 //     the counts and the three kernels above do the work.
 __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__restrict__ totals, int n_views, int n_strips,
                                                           StripMeta *__restrict__ meta, uint64_t *__restrict__ total_levels,
-                                                          int fmt, int allow_z24) {
+                                                          int fmt_req, int allow) {
     __shared__ uint32_t start[kMaxBins];              // entry i: the bin of count bins-1-i (heaviest first)
+    // the store's format follows from the span of the ranges (in place since view_total_kernel): every workgroup works it out
+    // for itself, workgroup 0 records it.  It decides how the strips are laid out: a kStoreZ26 strip starts on a whole chunk.
+    const int fmt = (int)choose_store_format(reinterpret_cast<const uint32_t *>(total_levels + 1)[2], reinterpret_cast<const uint32_t *>(total_levels + 1)[3], fmt_req, allow);
     __shared__ uint32_t first[kMaxBins];              // first strip that starts inside the bin
     __shared__ unsigned long long before[kMaxBins];   // levels of all strips starting in heavier bins
     __shared__ uint32_t wsum[4];
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__rest
         uint32_t st = incl - v;
         for (int w = 0; w < wave; ++w) st += wsum[w];
         const uint32_t fs = (st + kStripPx - 1) / kStripPx, fe = (st + v + kStripPx - 1) / kStripPx;
-        const unsigned long long lv = t < bins ? (unsigned long long)(fe - fs) * (unsigned)(bins - 1 - t) : 0ull;
+        const unsigned long long lv = t < bins ? (unsigned long long)(fe - fs) * padded_levels(fmt, (uint32_t)(bins - 1 - t)) : 0ull;
         const unsigned long long incl64 = wave_inclusive_scan(lv);
         if (lane == 63) wsum64[wave] = incl64;
         __syncthreads();
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__rest
         before[t] = bf;
         if (blockIdx.x == 0 && t == 0) {
             *total_levels = total;
-            decide_store_format(total_levels, fmt, allow_z24);  // what the scatter, the plan and the fit kernels must be told
+            decide_store_format(total_levels, fmt_req, allow);  // what the scatter, the plan and the fit kernels must be told
         }
         __syncthreads();
     }
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(256) void strip_table_kernel(const uint32_t *__rest
     const int i = bin_at(p), j = bin_at(p + kStripPx - 1);
     const uint32_t levels = (uint32_t)(bins - 1 - i);
     StripMeta m;
-    m.lvoff = before[i] + (unsigned long long)((uint32_t)s - first[i]) * levels;
+    m.lvoff = before[i] + (unsigned long long)((uint32_t)s - first[i]) * padded_levels(fmt, levels);
     m.levels = levels;
     m.full = (uint32_t)(bins - 1 - j);
     meta[s] = m;
@@ -385,21 +405,24 @@ __device__ __forceinline__ uint32_t range_mm(float z) {
     return z > 0.0f ? (uint32_t)mm : 0u;
 }
 
-// Writes chunk g (r of its four levels exist in the strip) of pixel `lane`.
-// 24-bit code of a range (layout.h, kStoreZ24): bits - offset, 0 for an empty slot.
+// Code of a range (layout.h, kStoreZ24 / kStoreZ26): bits - offset, 0 for an empty slot.
 __device__ __forceinline__ uint32_t range_code(float z, uint32_t zoff) { return z > 0.0f ? __float_as_uint(z) - zoff : 0u; }
 
-// The same for a store of 24-bit codes (the device's choice for a float32 store without extension planes).
-__device__ __forceinline__ void store_group_z24(uint8_t *strip, uint32_t g, uint32_t r, uint32_t lane, const float (&z)[kGroupLv],
-                                                const uint32_t (&c)[3], uint32_t zoff) {
-    uint8_t *ch = strip + (size_t)g * kChunk24;
+// Writes chunk g (r of its four levels exist in the strip) of pixel `lane` of a store of range codes (the device's choice for
+// a float32 store without extension planes): kZ = 24 or 26 bits.
+template <int kZ>
+__device__ __forceinline__ void store_group_codes(uint8_t *strip, uint32_t g, uint32_t r, uint32_t lane, const float (&z)[kGroupLv],
+                                                  const uint32_t (&c)[3], uint32_t zoff) {
+    uint8_t *ch = strip + (size_t)g * (kZ == 26 ? kChunk26 : kChunk24);
     if (r == kGroupLv) {
-        // the lane's 24 bytes: four dwords {code of level j | red of level j << 24} (the reader takes the code with one
-        // v_mad_u32_u24 and the red byte with v_cvt_f32_ubyte3), then the G and B words
+        // the lane's 24 bytes: four dwords {low 24 bits of the code of level j | red of level j << 24} (the reader takes them with
+        // one v_mad_u32_u24 and the red byte with v_cvt_f32_ubyte3), then the G and B words
+        const uint32_t k0 = range_code(z[0], zoff), k1 = range_code(z[1], zoff), k2 = range_code(z[2], zoff), k3 = range_code(z[3], zoff);
         uint32_t *p = reinterpret_cast<uint32_t *>(ch + lane * 24);
-        *reinterpret_cast<uint4 *>(p) = make_uint4(range_code(z[0], zoff) | (c[0] << 24), range_code(z[1], zoff) | ((c[0] >> 8) << 24),
-                                                   range_code(z[2], zoff) | ((c[0] >> 16) << 24), range_code(z[3], zoff) | ((c[0] >> 24) << 24));
+        *reinterpret_cast<uint4 *>(p) = make_uint4((k0 & 0xffffffu) | (c[0] << 24), (k1 & 0xffffffu) | ((c[0] >> 8) << 24),
+                                                   (k2 & 0xffffffu) | ((c[0] >> 16) << 24), (k3 & 0xffffffu) | ((c[0] >> 24) << 24));
         *reinterpret_cast<uint2 *>(p + 4) = make_uint2(c[1], c[2]);
+        if (kZ == 26) ch[kChunk24 + lane] = (uint8_t)((k0 >> 24) | ((k1 >> 24) << 2) | ((k2 >> 24) << 4) | ((k3 >> 24) << 6));   // bits 24-25 of the four codes
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < (uint32_t)kGroupLv - 1u; ++j) {
@@ -410,8 +433,28 @@ __device__ __forceinline__ void store_group_z24(uint8_t *strip, uint32_t g, uint
             uint8_t *cb = ch + 3u * kStripPx * r;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) cb[pl * kStripPx * r + lane * r + j] = (uint8_t)(c[pl] >> (8 * j));
+            if (kZ == 26 && (code >> 24)) {
+                // bits 24-25: two-bit field lane r + j, sixteen fields to a dword shared by several pixels (of this and of other
+                // workgroups): OR-ed into words tail_bits_clear_kernel has zeroed
+                const uint32_t f = lane * r + j;
+                atomicOr(reinterpret_cast<uint32_t *>(ch + 6u * kStripPx * r) + (f >> 4), (code >> 24) << (2u * (f & 15u)));
+            }
         }
     }
+}
+
+// kStoreZ26: the two-bit fields of every strip's short last chunk start out as zeros (the scatter ORs into them).  One thread
+// per strip; returns at once for any other store.
+__global__ __launch_bounds__(256) void tail_bits_clear_kernel(const StripMeta *__restrict__ meta, int n_strips, uint8_t *__restrict__ comp,
+                                                              const uint32_t *__restrict__ store_fmt) {
+    if (store_fmt[0] != (uint32_t)kStoreZ26) return;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_strips) return;
+    const StripMeta m = meta[s];
+    const uint32_t r = m.levels & 3u;
+    if (r == 0u) return;
+    uint32_t *w = reinterpret_cast<uint32_t *>(comp + (m.lvoff + (m.levels & ~3u)) * (uint64_t)level_bytes(kStoreZ26) + 6u * kStripPx * r);
+    for (uint32_t i = 0; i < 4u * r; ++i) w[i] = 0u;   // 64 r fields of two bits = 16 r bytes
 }
 
 template <int kFmt, int kExt>
@@ -482,10 +525,10 @@ __device__ __forceinline__ int nth_set_bit(uint32_t p, int n) {
 
 __device__ unsigned long long g_exp_scatter_clock[2];   // (experiment build) shader cycles / 100 MHz ticks, summed over the workgroups
 
-// kZ24: the instantiation that writes 24-bit range codes.  Which of the two forms a float32 store takes is decided on the
-// device (decide_store_format), so both instantiations are launched and the one whose form it is not returns at once (a few
-// microseconds per image; one kernel with both store paths in it held 100 registers instead of 92 and lost a wave per SIMD).
-template <int kFmt, int kExt, bool kZ24 = false>
+// kZ = 24 / 26: the instantiations that write range codes.  Which of the three forms a float32 store takes is decided on the
+// device (decide_store_format), so all allowed instantiations are launched and the ones whose form it is not return at once (a
+// few microseconds per image; one kernel with two store paths in it held 100 registers instead of 92 and lost a wave per SIMD).
+template <int kFmt, int kExt, int kZ = 0>
 __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict__ obs, size_t tile_stride,
                                                       size_t view_stride, const uint32_t *__restrict__ invperm,
                                                       const uint64_t *__restrict__ pmask, int mask_words,
@@ -495,8 +538,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
                                                       uint8_t *__restrict__ ext_comp,
                                                       const uint8_t *__restrict__ ext2_dense,
                                                       uint8_t *__restrict__ ext2_comp, const uint32_t *__restrict__ store_fmt) {
-    static_assert(!kZ24 || (kFmt == 0 && kExt == 0), "24-bit range codes: float32 store without extension planes");
-    if ((store_fmt[0] == (uint32_t)kStoreZ24) != kZ24) return;   // the other instantiation's store (kernel-uniform)
+    static_assert(kZ == 0 || ((kZ == 24 || kZ == 26) && kFmt == 0 && kExt == 0), "range codes: float32 store without extension planes");
+    // the other instantiations' store (kernel-uniform): kZ = 0 writes whatever is no store of codes
+    if (kZ ? store_fmt[0] != (uint32_t)(kZ == 24 ? kStoreZ24 : kStoreZ26) : (store_fmt[0] == (uint32_t)kStoreZ24 || store_fmt[0] == (uint32_t)kStoreZ26)) return;
     const unsigned long long exp_c0 = kExpWaveTimes ? clock64() : 0ull, exp_t0 = kExpWaveTimes ? wall_clock64() : 0ull;
     constexpr int kStageViews = StageCfg<kExt>::kViews, kStageBytes = StageCfg<kExt>::kBytes;
     constexpr uint32_t kStageMask = (1u << kStageViews) - 1u;
@@ -511,9 +555,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     const StripMeta sm = meta[dst / kStripPx];
     const uint32_t nl = sm.levels;
     // a float32 store without extension planes may have been made a store of 24-bit codes (decide_store_format)
-    constexpr bool z24 = kZ24;
+    constexpr bool z24 = kZ != 0;   // (a store of range codes, 24 or 26 bits)
     const uint32_t zoff = store_fmt[1];
-    uint8_t *out = comp + sm.lvoff * (uint64_t)(z24 ? level_bytes(kStoreZ24) : level_bytes(kFmt));
+    uint8_t *out = comp + sm.lvoff * (uint64_t)(kZ == 24 ? level_bytes(kStoreZ24) : kZ == 26 ? level_bytes(kStoreZ26) : level_bytes(kFmt));
     float *const eout[2] = {kExt >= 1 ? reinterpret_cast<float *>(ext_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr,
                             kExt >= 2 ? reinterpret_cast<float *>(ext2_comp + sm.lvoff * (uint64_t)kExtLevelBytes) : nullptr};
     const uint64_t *mask = pmask + ((size_t)tile * kTilePx + t) * mask_words;
@@ -603,7 +647,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
             q.c[0] |= cr << (8 * j); q.c[1] |= cg << (8 * j); q.c[2] |= cb << (8 * j);
             ++lv;
             if ((lv & 3u) == 0u) {   // four levels collected: this pixel's share of chunk lv/4 - 1 (a full one)
-                if (z24) store_group_z24(out, (lv >> 2) - 1u, kGroupLv, dlane, q.z, q.c, zoff);
+                if (z24) store_group_codes<kZ ? kZ : 24>(out, (lv >> 2) - 1u, kGroupLv, dlane, q.z, q.c, zoff);
                 else store_group<kFmt, kExt>(out, eout, (lv >> 2) - 1u, kGroupLv, dlane, q);
                 clear_group(q);
             }
@@ -614,7 +658,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const uint8_t *__restrict_
     // level count: the strip has as many levels as its richest pixel
     for (uint32_t g = lv >> 2; g * kGroupLv < nl; ++g) {
         const uint32_t r = min((uint32_t)kGroupLv, nl - g * kGroupLv);
-        if (z24) store_group_z24(out, g, r, dlane, q.z, q.c, zoff);
+        if (z24) store_group_codes<kZ ? kZ : 24>(out, g, r, dlane, q.z, q.c, zoff);
         else store_group<kFmt, kExt>(out, eout, g, r, dlane, q);
         clear_group(q);
     }
@@ -647,7 +691,8 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     // fmt: what the caller asked for (include/sucre_hip.h): SUCRE_OBS_F32 = float32 ranges, kept as 24-bit codes when the image
     // allows it and nothing rides along in extension planes; SUCRE_OBS_U16MM; SUCRE_OBS_F32_PLAIN = float32 ranges as they are
     const int store_req = fmt == SUCRE_OBS_U16MM ? kStoreU16 : kStoreF32;
-    const int allow_z24 = (fmt == SUCRE_OBS_F32 && !ext_dense) ? 1 : 0;
+    // range codes the device may choose: bit 0 = 24-bit, bit 1 = 26-bit (SUCRE_OBS_F32_Z26: the 26-bit ones or none -- tests, A/B)
+    const int allow = ext_dense ? 0 : fmt == SUCRE_OBS_F32 ? 3 : fmt == SUCRE_OBS_F32_Z26 ? 2 : 0;
     const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2;
     hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(ws + L.off_vbits),
                        pmask, L.mask_words, keep, L.n_views, L.n_tiles, pcount, blockhist);
@@ -656,15 +701,16 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
                        L.n_tiles, perm, invperm);
     if (L.n_views < kMaxBins - 1) {
         hipLaunchKernelGGL(strip_table_kernel, dim3((L.n_strips + 255) / 256), dim3(256), 0, s, totals, L.n_views, L.n_strips,
-                           meta, reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow_z24);
+                           meta, reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow);
     } else {
         // the counting sort is done with its histograms: their space holds the sorted tiles' totals and offsets
         auto *tile_levels = blockhist;
         auto *tile_off = reinterpret_cast<uint64_t *>(blockhist + align_up((size_t)L.n_tiles, 2));
-        hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels);
+        hipLaunchKernelGGL(strip_levels_kernel, dim3(L.n_tiles), dim3(256), 0, s, pcount, perm, meta, tile_levels,
+                           reinterpret_cast<const uint64_t *>(ws + L.off_total_chunks), store_req, allow);
         hipLaunchKernelGGL(tile_offset_kernel, dim3(1), dim3(1024), 0, s, tile_levels, L.n_tiles, tile_off,
-                           reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow_z24);
-        hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles);
+                           reinterpret_cast<uint64_t *>(ws + L.off_total_chunks), store_req, allow);
+        hipLaunchKernelGGL(strip_offset_kernel, dim3((L.n_tiles + 255) / 256), dim3(256), 0, s, meta, tile_off, L.n_tiles, store_fmt);
     }
     const dim3 grid(L.n_tiles), block(256);
     const uint8_t *obs = ws + L.off_obs;
@@ -679,11 +725,16 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
         hipLaunchKernelGGL((scatter_kernel<1, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
                            pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
     else {
-        hipLaunchKernelGGL((scatter_kernel<0, 0, false>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+        hipLaunchKernelGGL((scatter_kernel<0, 0, 0>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
                            pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
-        if (allow_z24)
-            hipLaunchKernelGGL((scatter_kernel<0, 0, true>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+        if (allow & 1)
+            hipLaunchKernelGGL((scatter_kernel<0, 0, 24>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
                                pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
+        if (allow & 2) {
+            hipLaunchKernelGGL(tail_bits_clear_kernel, dim3((L.n_strips + 255) / 256), dim3(256), 0, s, meta, L.n_strips, comp, store_fmt);
+            hipLaunchKernelGGL((scatter_kernel<0, 0, 26>), grid, block, 0, s, obs, L.obs_tile_stride, L.obs_view_stride, invperm,
+                               pmask, L.mask_words, meta, comp, L.n_views, ext_dense, ext_comp, ext2_dense, ext2_comp, store_fmt);
+        }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     return launch_plan(L, ws, s);   // the fit waves' item streams over the store just written (fit.hip); it reads the store's format

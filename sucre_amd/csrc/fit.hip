@@ -292,8 +292,9 @@ __host__ __device__ __forceinline__ uint32_t item_shape(uint32_t bytes, bool ful
     const uint32_t nA = pieces < 64u ? pieces : 64u, nB = pieces - nA;
     return (nA - 1u) | ((nB ? nB - 1u : 0u) << 8) | ((nB ? nA : nA - 1u) << 16) | (full_chunk ? kShapeFull : 0u);
 }
-static_assert(level_bytes(0) % 16 == 0 && level_bytes(1) % 16 == 0 && level_bytes(2) % 16 == 0 && kChunk % 16 == 0 && kChunk16 % 16 == 0 && kChunk24 % 16 == 0, "items are copied in 16-byte pieces");
-static_assert(kChunk <= 2048 && kChunk >= 1024 && kChunk16 >= 1024 && kChunk24 >= 1024, "a full chunk is one whole DMA + a partial one");
+static_assert(level_bytes(0) % 16 == 0 && level_bytes(1) % 16 == 0 && level_bytes(2) % 16 == 0 && level_bytes(3) % 16 == 0 && kChunk % 16 == 0 && kChunk16 % 16 == 0 && kChunk24 % 16 == 0 && kChunk26 % 16 == 0, "items are copied in 16-byte pieces");
+static_assert(kChunk <= 2048 && kChunk >= 1024 && kChunk16 >= 1024 && kChunk24 >= 1024 && kChunk26 >= 1024 && kChunk26 <= kChunk, "a full chunk is one whole DMA + a partial one");
+static_assert(level_bytes(0) % 64 == 0 && level_bytes(1) % 64 == 0 && level_bytes(2) % 64 == 0 && (kGroupLv * level_bytes(3)) % 64 == 0, "items start on 64-byte units (PlanItem.src64; a kStoreZ26 strip starts on a whole chunk)");
 
 // src (wave-uniform global address) -> LDS bytes [slotA, ...) and [slotB, ...) (wave-uniform LDS byte addresses) through the
 // per-lane byte offsets voffA / voffB.  EXEC is all ones (whole waves run this code) and stays so; M0 is written in the
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const StripMeta *__restrict__
                                                    uint32_t *__restrict__ count0, uint32_t *__restrict__ count1, uint64_t comp_off,
                                                    uint64_t state_off) {
     const int mode = blockIdx.y;   // both plans in one launch
-    const int fmt = (int)store_fmt[0];   // kStoreF32 / kStoreU16 / kStoreZ24: what the compaction has just written (decide_store_format)
+    const int fmt = (int)store_fmt[0];   // kStoreF32 / kStoreU16 / kStoreZ24 / kStoreZ26: what the compaction has just written (decide_store_format)
     const uint32_t W = mode ? W1 : W0, stride = mode ? stride1 : stride0, kmax = mode ? kmax1 : kmax0;
     PlanItem *plan = mode ? plan1 : plan0;
     StripEntry *strips = mode ? strips1 : strips0;
@@ -419,27 +420,55 @@ __device__ __forceinline__ ConstItems const_items(const T *p) {
     return (ConstItems)(reinterpret_cast<uintptr_t>(uniform_ptr(p)));
 }
 
-// What a kernel instantiated for float32 ranges finds in the store: the float32 words, or their 24-bit codes
-// (layout.h, kStoreZ24; chosen on the device by the compaction): bits(z) = code + zoff, code 0 = empty slot.
-struct RangeCodes { bool z24; uint32_t zoff; };
+// What a kernel instantiated for float32 ranges finds in the store: the float32 words, or their 24- or 26-bit codes
+// (layout.h, kStoreZ24 / kStoreZ26; chosen on the device by the compaction): bits(z) = code + zoff, code 0 = empty slot.
+// fullB: lanes of the second DMA of a full chunk of the store as it is (full_chunk_b).
+struct RangeCodes { bool z24, z26; uint32_t zoff, fullB; };
 
-__device__ __forceinline__ RangeCodes range_codes(const uint32_t *__restrict__ store_fmt) {
+template <int kFmt>
+__device__ __forceinline__ RangeCodes range_codes_of(uint32_t f0, uint32_t f1) {   // f0, f1: the store's format word and code offset, wave-uniform
     RangeCodes rc;
-    rc.z24 = __builtin_amdgcn_readfirstlane(store_fmt[0]) == (uint32_t)kStoreZ24;
-    rc.zoff = __builtin_amdgcn_readfirstlane(store_fmt[1]);
+    rc.z24 = kFmt == 0 && f0 == (uint32_t)kStoreZ24;
+    rc.z26 = kFmt == 0 && f0 == (uint32_t)kStoreZ26;
+    rc.zoff = f1;
+    rc.fullB = rc.z24 ? full_chunk_b(kStoreZ24) : rc.z26 ? full_chunk_b(kStoreZ26) : full_chunk_b(kFmt);
     return rc;
 }
 
-// Is the store one the instantiation can read?  (kFmt 0: float32 ranges, as words or as 24-bit codes; 1: uint16 millimetres.)
+template <int kFmt>
+__device__ __forceinline__ RangeCodes range_codes(const uint32_t *__restrict__ store_fmt) {
+    return range_codes_of<kFmt>(__builtin_amdgcn_readfirstlane(store_fmt[0]), __builtin_amdgcn_readfirstlane(store_fmt[1]));
+}
+
+// Is the store one the instantiation can read?  (kFmt 0: float32 ranges, as words or as range codes; 1: uint16 millimetres.)
+__host__ __device__ constexpr bool format_readable(int kFmt, uint32_t f) {
+    return kFmt == kStoreU16 ? f == (uint32_t)kStoreU16 : (f == (uint32_t)kStoreF32 || f == (uint32_t)kStoreZ24 || f == (uint32_t)kStoreZ26);
+}
 template <int kFmt>
 __device__ __forceinline__ bool store_matches(const uint32_t *__restrict__ store_fmt) {
-    const uint32_t f = __builtin_amdgcn_readfirstlane(store_fmt[0]);
-    return kFmt == kStoreU16 ? f == (uint32_t)kStoreU16 : (f == (uint32_t)kStoreF32 || f == (uint32_t)kStoreZ24);
+    return format_readable(kFmt, __builtin_amdgcn_readfirstlane(store_fmt[0]));
 }
 
 // A full chunk in a ring slot -> this lane's four ranges and three colour dwords.  masked: the chunk may hold empty slots.
 template <int kFmt>
 __device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&zz)[kGroupLv], uint32_t (&cc)[3], const RangeCodes &rc, bool masked) {
+    if (kFmt == 0 && rc.z26) {   // wave-uniform: a kStoreZ24 chunk + one byte per lane with bits 24-25 of its four codes
+        const uint2 a = *reinterpret_cast<const uint2 *>(sp + lane * 24), b = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 8),
+                    c = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 16);
+        const uint32_t h = sp[kChunk24 + lane];
+        const uint32_t w[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+        for (int j = 0; j < kGroupLv; ++j) {
+            uint32_t bits;
+            asm("v_mad_u32_u24 %0, %1, 1, %2" : "=v"(bits) : "v"(w[j]), "s"(rc.zoff));   // low 24 bits of the code + offset
+            bits += ((h >> (2 * j)) & 3u) << 24;                                            // v_bfe_u32 + v_lshl_add_u32
+            zz[j] = __uint_as_float(bits);
+            if (masked) zz[j] = bits != rc.zoff ? zz[j] : 0.0f;   // code 0: an empty slot reads as range 0, like in the float32 store
+        }
+        cc[0] = __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0703u) | __builtin_amdgcn_perm(b.y, b.x, 0x07030c0cu);
+        cc[1] = c.x; cc[2] = c.y;
+        return;
+    }
     if (kFmt == 0 && rc.z24) {   // wave-uniform: the lane's 24 bytes side by side -- {code | red << 24} x 4, G word, B word
         const uint2 a = *reinterpret_cast<const uint2 *>(sp + lane * 24), b = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 8),
                     c = *reinterpret_cast<const uint2 *>(sp + lane * 24 + 16);
@@ -472,10 +501,14 @@ __device__ __forceinline__ void read_chunk(const uint8_t *sp, int lane, float (&
 // Level j of a short chunk (r < 4 levels, rows of r) in a ring slot.
 template <int kFmt>
 __device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t r, uint32_t j, float &z, uint32_t (&k)[3], const RangeCodes &rc) {
-    const bool z24 = kFmt == 0 && rc.z24;
+    const bool z24 = kFmt == 0 && (rc.z24 || rc.z26);   // (range codes: three bytes per level, then the colours)
     if (z24) {
         const uint8_t *zp = sp + (lane * r + j) * 3u;
-        const uint32_t code = (uint32_t)zp[0] | ((uint32_t)zp[1] << 8) | ((uint32_t)zp[2] << 16);
+        uint32_t code = (uint32_t)zp[0] | ((uint32_t)zp[1] << 8) | ((uint32_t)zp[2] << 16);
+        if (rc.z26) {   // bits 24-25: two-bit field lane r + j behind the colour planes
+            const uint32_t f = (uint32_t)lane * r + j;
+            code |= ((reinterpret_cast<const uint32_t *>(sp + 6u * kStripPx * r)[f >> 4] >> (2u * (f & 15u))) & 3u) << 24;
+        }
         z = code ? __uint_as_float(code + rc.zoff) : 0.0f;
     } else if (kFmt == 0) z = reinterpret_cast<const float *>(sp)[lane * r + j];
     else z = (float)reinterpret_cast<const uint16_t *>(sp)[lane * r + j] * kMPerMm;
@@ -495,10 +528,10 @@ __device__ __forceinline__ void read_level(const uint8_t *sp, int lane, uint32_t
 // immediate: vmcnt(2 kAhead), or vmcnt(2 kAhead + kStores) for the first kAhead items behind a strip's stores.
 // One item -> ring slot at byte offset slot_off of the wave's ring.
 template <int kFmt>
-__device__ __forceinline__ void issue_item(const ItemRegs it, uint32_t ring0, uint32_t slot_off, const uint8_t *__restrict__ ws, int lane, bool z24) {
-    // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch)
+__device__ __forceinline__ void issue_item(const ItemRegs it, uint32_t ring0, uint32_t slot_off, const uint8_t *__restrict__ ws, int lane, uint32_t fullB) {
+    // per-lane byte offsets of the two DMAs of a full chunk (constants of the launch; fullB = RangeCodes.fullB)
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    const uint32_t voffB_full = (64u + min((uint32_t)lane, (z24 ? full_chunk_b(kStoreZ24) : full_chunk_b(kFmt)) - 1u)) * 16u;
+    const uint32_t voffB_full = (64u + min((uint32_t)lane, fullB - 1u)) * 16u;
     const uint8_t *src = ws + ((uint64_t)it.x << 6);
     const uint32_t slot = ring0 + slot_off;
     if (it.y & kShapeFull) {
@@ -516,7 +549,7 @@ __device__ __forceinline__ void issue_item(const ItemRegs it, uint32_t ring0, ui
 // images: the wave goes from one image's last strip to the next one's first like from strip to strip.
 //   head[0 .. kAhead-1], head[kAhead], se0   THIS stream's first items, the one behind them and its first strip entry (asked for
 //                                            one image ahead: no scalar round trip at the start)
-//   next_on, next_head, next_ws, next_z24    the stream that follows, if this wave has one (else: trailing copies + drain)
+//   next_on, next_head, next_ws, next_fullB  the stream that follows, if this wave has one (else: trailing copies + drain)
 //   cs, behind                               in: where this stream's first item sits (its first kAhead items are in flight);
 //                                            out: the same for the next stream -- 0, 0 after a drain
 struct NoChain { static constexpr bool kOn = false; };
@@ -526,13 +559,13 @@ struct StreamChain {
     bool next_on;
     ItemRegs next_head[kAhead];
     const uint8_t *next_ws;
-    bool next_z24;
+    uint32_t next_fullB;
     uint32_t cs, behind;
 };
 
 template <int kFmt, int kStores, bool kMoments, bool kPrimed = false, class Chain = NoChain, class OnJ, class OnChunk, class OnTail, class OnEnd>
 __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__restrict__ plan, const StripEntry *__restrict__ strip_list,
-                                              uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, bool z24, OnJ on_J,
+                                              uint32_t K, const uint8_t *__restrict__ ws, int wave, int lane, uint32_t fullB, OnJ on_J,
                                               OnChunk on_chunk, OnTail on_tail, OnEnd on_end, Chain *chain = nullptr) {
     if (K == 0) return;
     constexpr bool kChain = Chain::kOn;
@@ -549,11 +582,11 @@ __device__ __forceinline__ void stream_strips(FitLds &lds, const PlanItem *__res
 #pragma unroll
                 for (int q = 1; q < kAhead; ++q) f = trail == (uint32_t)q ? chain->next_head[q] : f;
                 ++trail;
-                issue_item<kFmt>(f, ring0, slot_off, chain->next_ws, lane, chain->next_z24);
+                issue_item<kFmt>(f, ring0, slot_off, chain->next_ws, lane, chain->next_fullB);
                 return;
             }
         }
-        issue_item<kFmt>(it, ring0, slot_off, ws, lane, z24);
+        issue_item<kFmt>(it, ring0, slot_off, ws, lane, fullB);
     };
     // the first kAhead items (a wave with a strip has at least 1 + kAhead + 1 entries: its items, the trailing ones, the spare)
     if (!kPrimed) {
@@ -780,7 +813,7 @@ __device__ __forceinline__ void grad_pass(FitLds &lds, const PlanItem *__restric
                                           Chain *chain = nullptr) {
     float J[3] = {0.f, 0.f, 0.f};
     stream_strips<kFmt, 9, true, kPrimed, Chain>(
-        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
+        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.fullB,
         [&](const uint8_t *sp) {  // J plane
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -863,7 +896,7 @@ __global__ __launch_bounds__(256, kFitWaves) void fit_grad_kernel(const uint8_t 
     const Water w = load_water(pstate);
     const float gscale = -2.0f * ((1.0f / 3.0f) / (float)(*n_obs_total));  // (loss / n_obs / 3).backward(), sucre.py:145
     // a store compacted in the other format is not read at all; the logged cost turns NaN instead
-    const RangeCodes rc = range_codes(obs_format);
+    const RangeCodes rc = range_codes<kFmt>(obs_format);
     const bool fmt_ok = store_matches<kFmt>(obs_format);
     const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
     const uint32_t n_mine = fmt_ok ? plan_count[wid] : 0u;   // strips of this wave
@@ -895,7 +928,7 @@ __device__ __forceinline__ void closed_pass(FitLds &lds, const PlanItem *__restr
     AccOne acc;
     float Jp[3] = {0.f, 0.f, 0.f};
     stream_strips<kFmt, 3, false, kPrimed, Chain>(
-        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.z24,
+        lds, plan, strips, n_strips_wave, ws, wave, lane, rc.fullB,
         [&](const uint8_t *sp) {  // previous J of this pixel
             const float *f = reinterpret_cast<const float *>(sp);
 #pragma unroll
@@ -966,7 +999,7 @@ __global__ __launch_bounds__(256, kClosedWaves) void fit_closed_kernel(const uin
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const Water w = load_water_uniform(pstate);   // scalar registers: the 27 accumulators need the vector ones
-    const RangeCodes rc = range_codes(obs_format);
+    const RangeCodes rc = range_codes<kFmt>(obs_format);
     const bool fmt_ok = store_matches<kFmt>(obs_format);
     // update_J on a store of the other format poisons J instead of misreading it: every strip is still visited (the
     // plan was written for the store's format, so the items themselves are sound)
@@ -1086,7 +1119,7 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void gr
         const GroupImage im = images[i];
         uint8_t *ws = uniform_ptr(im.ws);   // between images nothing is in flight: ordinary loads are harmless here
         const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + im.off_format);
-        const RangeCodes rc = range_codes(store_fmt);
+        const RangeCodes rc = range_codes<kFmt>(store_fmt);
         if (!store_matches<kFmt>(store_fmt)) { poisoned = true; continue; }
         if (wid >= im.n_waves[kMode]) continue;
         const uint32_t n_mine = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(ws + im.off_count[kMode])[wid]);
@@ -1246,9 +1279,8 @@ __device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ i
                    o_state = cload<uint64_t>(&e->o.state);
     const uint32_t stride = cload<uint32_t>(&e->o.stride), kmax = cload<uint32_t>(&e->o.kmax);
     const uint32_t f0 = cload<uint32_t>(v.ws + o_format), f1 = cload<uint32_t>(v.ws + o_format + 4);
-    v.rc.z24 = f0 == (uint32_t)kStoreZ24;
-    v.rc.zoff = f1;
-    v.fmt_ok = kFmt == kStoreU16 ? f0 == (uint32_t)kStoreU16 : (f0 == (uint32_t)kStoreF32 || f0 == (uint32_t)kStoreZ24);
+    v.rc = range_codes_of<kFmt>(f0, f1);
+    v.fmt_ok = format_readable(kFmt, f0);
     v.n_mine = v.fmt_ok ? cload<uint32_t>(v.ws + o_count + 4ull * wid) : 0u;
     if (kExpBatch == 2) v.n_mine = 0u;
     v.plan = reinterpret_cast<const PlanItem *>(v.ws + o_plan) + (size_t)wid * stride;
@@ -1286,7 +1318,7 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
         if (x.n_mine == 0u) return;
         const uint32_t ring0 = lds_addr(&lds.ring[wave][0][0]);
 #pragma unroll
-        for (int q = 0; q < kAhead; ++q) issue_item<kFmt>(x.head[q], ring0, (uint32_t)(q * kSlot), x.ws, lane, x.rc.z24);
+        for (int q = 0; q < kAhead; ++q) issue_item<kFmt>(x.head[q], ring0, (uint32_t)(q * kSlot), x.ws, lane, x.rc.fullB);
     };
     StreamChain ch;
     ch.cs = 0u;
@@ -1307,7 +1339,7 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) ch.next_head[q] = vn.head[q];
         ch.next_ws = vn.ws;
-        ch.next_z24 = vn.rc.z24;
+        ch.next_fullB = vn.rc.fullB;
         float s[kNumSums];
         if (kMode == 0) {
             Acc acc;

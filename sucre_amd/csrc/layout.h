@@ -22,9 +22,20 @@ constexpr float kMmPerM = 1000.0f, kMPerMm = 0.001f;
 // factor of four -- are kept as 24-bit codes, code = bits(z) - bits(z_min) + 1 (0 = empty slot): bits(z) = code + offset
 // gives every range back exactly, 6 instead of 7 bytes per observation.  A full chunk: 64 x {4 codes (12 B), R word, G word,
 // B word} = 1536 B, a lane's 24 bytes side by side (four dwords code | red << 24, then the G and B words); the short last chunk: [code: 64 x r x 3 B][R: 64 x r][G][B].
-constexpr int kStoreF32 = 0, kStoreU16 = 1, kStoreZ24 = 2;
+// Store format 3 (kStoreZ26, round 6; also the device's choice): an image whose ranges span MORE than 2^24 - 2 bit patterns but
+// no more than 2^26 - 2 (a factor of up to 256 between the nearest and the farthest range: any real scene) keeps 26-bit codes,
+// 6.25 bytes per observation.  A full chunk is a kStoreZ24 chunk -- the low 24 bits of the four codes, the colours -- followed
+// by ONE byte per lane holding bits 24-25 of the lane's four codes (level j in bits 2j, 2j+1): 1536 + 64 = 1600 B.  The short
+// last chunk (r levels): [low 24 bits: 64 x r x 3 B][R: 64 x r][G][B][bits 24-25: 64 r two-bit fields, field lane r + j, sixteen
+// to a dword].  A level is 400 bytes, no multiple of 64, and items are addressed in units of 64 bytes (PlanItem.src64): a
+// kStoreZ26 strip therefore STARTS on a multiple of four levels (StripMeta.lvoff counts padded levels) -- its chunks then sit
+// at multiples of 1600 = 25 x 64 bytes -- and the padding is never copied (store space, not traffic).
+constexpr int kStoreF32 = 0, kStoreU16 = 1, kStoreZ24 = 2, kStoreZ26 = 3;
 constexpr int kChunk24 = 6 * 256;    // 1536 bytes
-__host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt == kStoreU16 ? kChunk16 : fmt == kStoreZ24 ? kChunk24 : kChunk; }
+constexpr int kChunk26 = kChunk24 + 64;   // 1600 bytes
+__host__ __device__ constexpr int chunk_bytes(int fmt) { return fmt == kStoreU16 ? kChunk16 : fmt == kStoreZ24 ? kChunk24 : fmt == kStoreZ26 ? kChunk26 : kChunk; }
+// strip offsets of a store: kStoreZ26 counts every strip's levels rounded up to a multiple of four
+__host__ __device__ constexpr uint32_t padded_levels(int fmt, uint32_t levels) { return fmt == kStoreZ26 ? (levels + 3u) & ~3u : levels; }
 constexpr int kExtChunk = 3 * kChunkZ;  // light model: cP.x, cP.y, cP.z planes of a chunk (extension workspace)
 // Compact store (what the fit streams): the count-sorted pixels are cut into STRIPS of 64 consecutive pixels -- one
 // pixel per lane of the wave that owns the strip.  A strip with n levels is stored as ceil(n/4) chunks of 64 pixels x
@@ -35,12 +46,13 @@ constexpr int kStripPx = 64;
 constexpr int kStripsPerTile = kTilePx / kStripPx;
 constexpr int kGroupLv = 4;                       // levels per full chunk
 constexpr int kStateFloats = 9 * kStripPx;        // J[3], exp_avg[3], exp_avg_sq[3] planes of a strip (2304 B)
-__host__ __device__ constexpr int range_bytes(int fmt) { return fmt == kStoreU16 ? 2 : fmt == kStoreZ24 ? 3 : 4; }
-__host__ __device__ constexpr int level_bytes(int fmt) { return (range_bytes(fmt) + 3) * kStripPx; }  // 448 / 320 / 384
+__host__ __device__ constexpr int range_bytes(int fmt) { return fmt == kStoreU16 ? 2 : (fmt == kStoreZ24 || fmt == kStoreZ26) ? 3 : 4; }   // (kStoreZ26: + 2 bits)
+__host__ __device__ constexpr int level_bytes(int fmt) { return (range_bytes(fmt) + 3) * kStripPx + (fmt == kStoreZ26 ? kStripPx / 4 : 0); }  // 448 / 320 / 384 / 400
+static_assert(kGroupLv * level_bytes(kStoreZ26) == kChunk26 && kChunk26 % 64 == 0, "a 26-bit chunk is four levels and a whole number of 64-byte units");
 constexpr int kExtLevelBytes = 3 * 4 * kStripPx;  // extension planes of one level of a strip: 3 floats x 64 pixels
 
 struct StripMeta {
-    uint64_t lvoff;   // levels of all earlier strips: the strip's chunks start at comp + lvoff * level_bytes(fmt)
+    uint64_t lvoff;   // levels of all earlier strips (kStoreZ26: each rounded up to a multiple of four): the strip's chunks start at comp + lvoff * level_bytes(fmt)
     uint32_t levels;  // largest pixel count in the strip
     uint32_t full;    // smallest pixel count: chunks wholly below it hold 64 x 4 real observations (no select needed)
 };
@@ -181,8 +193,8 @@ struct Layout {
     size_t off_invperm;     // uint32 [n_tiles*256]        dense slot  -> sorted slot
     int n_strips;           // n_tiles * 4 strips of 64 sorted pixels
     size_t off_strip_meta;  // StripMeta [n_strips]
-    size_t off_total_chunks;// uint64 [1] total levels over all strips, then uint32 [5]: format of the compact store (kStore*), the
-                            // offset of its 24-bit range codes (kStoreZ24), smallest / largest range bits of the dense store
+    size_t off_total_chunks;// uint64 [1] total (padded) levels over all strips, then uint32 [5]: format of the compact store (kStore*), the
+                            // offset of its range codes (kStoreZ24 / kStoreZ26), smallest / largest range bits of the dense store
     size_t off_zrange;      // uint2  [n_tiles][n_views]   smallest / largest float32 bit pattern of ranges of the tile (0xffffffff / 0: none); an imported
                             // view's entry holds its own, a matched view's the ranges of ALL the views its wave walked (or none)
     size_t off_zpart;       // uint2  [ceil(n_tiles / 32)] the same over 32 tiles and all views
@@ -221,7 +233,9 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_obs = take(nt * nv * kChunk);
     L->obs_tile_stride = nv * kChunk; L->obs_view_stride = kChunk;      // [tile][view]
     L->off_cnt = take(nt * nv * sizeof(uint16_t));
-    L->off_comp = take(nt * nv * kChunk);
+    // (the 26-bit store rounds every strip up to whole chunks: at most n_strips * (n_views + 3) levels of 400 bytes)
+    const size_t comp_f32 = nt * nv * kChunk, comp_z26 = nt * (nv + 3) * kChunk26;
+    L->off_comp = take(comp_f32 > comp_z26 ? comp_f32 : comp_z26);
     L->off_pcount = take(nt * kTilePx * sizeof(uint16_t));
     L->mask_words = (n_views + 63) / 64;
     L->off_pmask = take(nt * kTilePx * (size_t)L->mask_words * sizeof(uint64_t));

@@ -226,6 +226,7 @@ class Restoration:
         self._views_buf = torch.empty(self.capacity * C.sizeof(_lib.SucreView), dtype=torch.uint8, device=self.device)
         self._views_copied = None
         self._keepalive = []
+        self._batch_table = None
         self.trace = None
         self.steps_done = 0
 
@@ -487,14 +488,19 @@ def fit_batch(restorations: list, num_iter: int = 200, lr: float = 0.05, use_clo
     size, sit on one device, stand at the same step and use the same observation format; their view counts may differ.
     Returns the list of (num_iter, 10) device traces (or of None)."""
     rs = list(restorations)
-    assert rs, 'no image'
+    if not rs:
+        raise ValueError('fit_batch: no image')
     r0 = rs[0]
     for r in rs:
         if r.light or r.float_colour:
             raise NotImplementedError('fit_batch: the extension-plane modes (light model, float32 colours) are fitted one by one')
-        assert (r.H, r.W, str(r.device), r.obs_format, r.steps_done) == (r0.H, r0.W, str(r0.device), r0.obs_format, r0.steps_done), \
-            'one image size, device, observation format and step per batch'
-    assert len({r.ws.data_ptr() for r in rs}) == len(rs), 'every image needs its own workspace'
+        # (not asserts: under python -O images at different Adam steps would be stepped with one bias correction, silently --
+        # ADVICE round 5.  The float32 forms of the store -- words, 24- or 26-bit codes -- may mix: each workspace says its own.)
+        if (r.H, r.W, str(r.device), r._fmt_flag, r.steps_done) != (r0.H, r0.W, str(r0.device), r0._fmt_flag, r0.steps_done):
+            raise ValueError('fit_batch: one image size, device, observation format and Adam step per batch -- got '
+                             f'{(r.H, r.W, str(r.device), r.obs_format, r.steps_done)} next to {(r0.H, r0.W, str(r0.device), r0.obs_format, r0.steps_done)}')
+    if len({r.ws.data_ptr() for r in rs}) != len(rs):
+        raise ValueError('fit_batch: every image needs its own workspace')
     n = len(rs)
     traces = [torch.zeros((num_iter, 10), dtype=torch.float64, device=r0.device) if record_trace else None for _ in rs]
     flags = (_lib.FIT_CLOSED_FORM if use_closed_form else 0) | r0._fmt_flag
@@ -514,7 +520,8 @@ def fit_batch(restorations: list, num_iter: int = 200, lr: float = 0.05, use_clo
     for r, t in zip(rs, traces):
         r.steps_done += int(num_iter)
         r.trace = t
-        r._keepalive.append(table)   # the launches read the table: it lives as long as the workspaces' current image
+        r._batch_table = table   # the launches read the table: it lives until the workspace's next batch (replaced, not appended:
+                                 # a fit driven one iteration per call would otherwise keep one table per call -- ADVICE round 5)
     return traces
 
 

@@ -106,8 +106,9 @@ def _albedo(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 
 def render_view(K: torch.Tensor, R: np.ndarray, t: np.ndarray, width: int, height: int, view_id: int,
-                seed: int, relief: float, invalid_frac: float, device: str | torch.device = 'cpu'):
-    """Ray-cast one camera against the seabed -> (depth mm as int32, rgb uint8)."""
+                seed: int, relief: float, invalid_frac: float, device: str | torch.device = 'cpu', iters: int = 8):
+    """Ray-cast one camera against the seabed -> (depth mm as int32, rgb uint8).  ``iters``: fixed-point steps on the ray
+    parameter (8 for the downward-looking surveys -- every committed fixture was rendered with 8; oblique cameras take more)."""
     dev = torch.device(device)
     f64 = torch.float64
     fx, fy, cx, cy = (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
@@ -121,7 +122,7 @@ def render_view(K: torch.Tensor, R: np.ndarray, t: np.ndarray, width: int, heigh
     wz = Rt[2, 0] * dx + Rt[2, 1] * dy + Rt[2, 2]
     ox, oy, oz = float(t[0]), float(t[1]), float(t[2])
     s = (3.0 - oz) / wz
-    for _ in range(8):  # fixed point on the ray parameter; |grad h| <= 0.2 so it contracts fast
+    for _ in range(iters):  # fixed point on the ray parameter; |grad h| <= 0.2 so it contracts fast
         s = (_seabed(ox + s * wx, oy + s * wy, relief) - oz) / wz
     X, Y = ox + s * wx, oy + s * wy
     depth_mm = torch.round(s * 1000.0)
@@ -180,6 +181,53 @@ def make_scene(width: int, height: int, n_neighbours: int, seed: int = 0, relief
         t32 = torch.tensor(t, dtype=torch.float32).view(3, 1)
         depth_mm, rgb = render_view(K, R32.double().numpy(), t32.double().numpy().ravel(), width, height,
                                     view_id=q, seed=seed, relief=relief, invalid_frac=invalid_frac, device=device)
+        views.append(SynthView(name=f'img_{rank:04d}.png', R=R32, t=t32, depth_u16=depth_mm, rgb_u8=rgb))
+        if (i, j) == (0, 0):
+            target = rank
+    return SynthScene(width=width, height=height, K=K, views=views, target=target, seed=seed)
+
+
+# Altitudes (camera z; the seabed lies at z = 3 +- relief) and tilts about the camera's x axis of the DEEP scene's views, by
+# view index (0 = the target): cameras from 0.75 m to 4 m above the seabed, looking straight down or up to 45 degrees ahead.
+DEEP_ALT = (0.0, 2.25, 2.0, 1.2, 0.0, -1.0, 0.5, 1.8, 0.0, 2.1, 1.0, -0.5)
+DEEP_TILT_DEG = (25.0, 0.0, 20.0, -30.0, 40.0, 45.0, -45.0, 10.0, 0.0, -15.0, 35.0, -40.0, 5.0)
+
+
+def make_deep_scene(width: int, height: int, n_neighbours: int, seed: int = 0, relief: float = 0.15, spacing: float = 0.1,
+                    invalid_frac: float = 0.01, rot_sigma: float = 0.03, pos_sigma: float = 0.1,
+                    device: str | torch.device = 'cpu') -> SynthScene:
+    """A scene whose RANGES span more than a factor of ten (task 3): the same seabed and grid as ``make_scene``,
+    but the cameras fly at altitudes from 0.75 m to 4 m above it and a good half of them look obliquely ahead (tilts up to 45
+    degrees, aimed back at the target's footprint), so one target's observations hold ranges from about 0.7 m to more than 8 m --
+    more than the 2^24 bit patterns the 24-bit range codes of the compact store cover (csrc/layout.h)."""
+    fxy = 0.78 * width
+    K = torch.tensor([[fxy, 0.0, width / 2.0], [0.0, fxy, height / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    foot_w = 3.0 * width / fxy
+    foot_h = 3.0 * height / fxy
+    r = int(math.ceil(math.sqrt(n_neighbours + 1))) + 2
+    offs = [(i, j) for j in range(-r, r + 1) for i in range(-r, r + 1)]
+    offs.sort(key=lambda ij: (ij[0] * ij[0] + ij[1] * ij[1], ij[1], ij[0]))
+    offs = offs[:n_neighbours + 1]
+    n = len(offs)
+    nw = _normal_host(3 * n, 1, seed).reshape(n, 3) * rot_sigma
+    npos = _normal_host(3 * n, 2, seed).reshape(n, 3) * pos_sigma
+    order = sorted(range(n), key=lambda q: (offs[q][1], offs[q][0] if offs[q][1] % 2 == 0 else -offs[q][0]))
+    views: list[SynthView] = []
+    target = -1
+    for rank, q in enumerate(order):
+        i, j = offs[q]
+        alt = DEEP_ALT[q % len(DEEP_ALT)]
+        tilt = math.radians(DEEP_TILT_DEG[q % len(DEEP_TILT_DEG)])
+        Rx = np.array([[1.0, 0.0, 0.0], [0.0, math.cos(tilt), -math.sin(tilt)], [0.0, math.sin(tilt), math.cos(tilt)]])
+        R = Rx @ _rodrigues(nw[q])
+        scale = (3.0 - alt) / 3.0    # a low camera sees a small footprint: it stays nearer to the target's centre
+        t = np.array([(i + npos[q, 0]) * spacing * foot_w * scale,
+                      (j + npos[q, 1]) * spacing * foot_h * scale + (3.0 - alt) * math.tan(tilt),   # the axis meets the bed near the grid point
+                      alt + npos[q, 2] * 0.2])
+        R32 = torch.tensor(R, dtype=torch.float32)
+        t32 = torch.tensor(t, dtype=torch.float32).view(3, 1)
+        depth_mm, rgb = render_view(K, R32.double().numpy(), t32.double().numpy().ravel(), width, height,
+                                    view_id=q, seed=seed, relief=relief, invalid_frac=invalid_frac, device=device, iters=40)
         views.append(SynthView(name=f'img_{rank:04d}.png', R=R32, t=t32, depth_u16=depth_mm, rgb_u8=rgb))
         if (i, j) == (0, 0):
             target = rank

@@ -49,7 +49,16 @@ CONFIGS = {
     'baseline_c5views_480x360_n256': (480, 360, 256, 0, 8, 4, 2),
     # an image whose sides are no multiples of the engine's 16 x 16 tiles (ragged last tile column and row), in full
     'baseline_odd_333x207_n8': (333, 207, 8, 3, 60, 30, 1),
+    # round 6: a scene whose ranges span a factor of eleven (0.72 .. 8.03 m: cameras 0.75 .. 4 m above the seabed, half of them
+    # oblique; synth.make_deep_scene) -- more than the 2^24 bit patterns of the compact store's 24-bit range codes -- in full
+    'baseline_deep_640x480_n8': (640, 480, 8, 0, 200, 200, 1, 'deep'),
 }
+
+
+def make_scene(spec):
+    W, H, nn, seed = spec[:4]
+    kind = spec[7] if len(spec) > 7 else 'plain'
+    return (synth.make_deep_scene if kind == 'deep' else synth.make_scene)(W, H, nn, seed=seed), kind
 
 
 def input_digests(scene):
@@ -79,7 +88,7 @@ def add_derived(name, spec):
     W, H, nn, seed = spec[:4]
     path = HERE / f'{name}.npz'
     z = dict(np.load(path))
-    scene = synth.make_scene(W, H, nn, seed=seed)
+    scene, _ = make_scene(spec)
     assert input_digests(scene)[1] == str(z['input_digest']), 'this host regenerates another scene'
     z.update(derived_matrices(scene))
     np.savez_compressed(path, **z)
@@ -104,11 +113,11 @@ def quiet(fn, *a, **k):
 
 
 def generate(name, spec):
-    W, H, nn, seed, T_param, T_closed, stride = spec
+    W, H, nn, seed, T_param, T_closed, stride = spec[:7]
     t0 = time.perf_counter()
-    scene = synth.make_scene(W, H, nn, seed=seed)
+    scene, kind = make_scene(spec)
     per_view_digest, scene_digest = input_digests(scene)
-    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names),
+    out = dict(width=W, height=H, seed=seed, n_neighbours=nn, target=scene.target, names=np.array(scene.names), scene_kind=np.array(kind),
                input_digest_per_view=np.array(per_view_digest), input_digest=np.array(scene_digest),
                T_param=T_param, T_closed=T_closed, stride=stride,
                torch_version=np.array(torch.__version__), threads=torch.get_num_threads())

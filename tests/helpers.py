@@ -143,6 +143,7 @@ BASELINE_C2 = 'baseline_c2_1920x1080_n64'
 BASELINE_C2FULL = 'baseline_c2full_1920x1080_n64'
 BASELINE_C5VIEWS = 'baseline_c5views_480x360_n256'
 BASELINE_ODD = 'baseline_odd_333x207_n8'
+BASELINE_DEEP = 'baseline_deep_640x480_n8'   # ranges 0.72 .. 8.03 m (synth.make_deep_scene)
 
 
 def scene_digests(scene):
@@ -176,14 +177,14 @@ class SceneMismatch(AssertionError):
     """The regenerated synthetic scene is not the one the reference ran on."""
 
 
-def _make_scene(width, height, n_neighbours, seed):
+def _make_scene(width, height, n_neighbours, seed, kind='plain'):
     """The seeded scene of a baseline fixture.  ``SUCRE_TEST_PERTURB_SCENE=<view index>`` flips ONE colour byte of ONE view
     after rendering -- the smallest way a host could render another scene: every reference-pinned test must then be RED
     (``SUCRE_TEST_PERTURB_SCENE=0 pytest -m gpu`` shows it; tests/test_host_logic.py asserts it on the CPU tier)."""
     import os
 
     from sucre_amd import synth
-    scene = synth.make_scene(width, height, n_neighbours, seed=seed)
+    scene = (synth.make_deep_scene if kind == 'deep' else synth.make_scene)(width, height, n_neighbours, seed=seed)
     k = os.environ.get('SUCRE_TEST_PERTURB_SCENE')
     if k not in (None, ''):
         scene.views[int(k) % len(scene.views)].rgb_u8[height // 2, width // 2, 1] ^= 1
@@ -201,7 +202,7 @@ class Baseline:
         self.name = name
         self.z = np.load(GOLDEN_DIR / f'{name}.npz')
         z = self.z
-        skey = (int(z['width']), int(z['height']), int(z['n_neighbours']), int(z['seed']))
+        skey = (int(z['width']), int(z['height']), int(z['n_neighbours']), int(z['seed']), str(z['scene_kind']) if 'scene_kind' in z else 'plain')
         if skey not in _SCENES:   # several fixtures hold results on the same scene (config 2: short, in full, light model)
             _SCENES.clear()       # ... one at a time: a config-2 scene is 0.7 GB
             _SCENES[skey] = _make_scene(*skey)

@@ -101,6 +101,28 @@ def test_odd_image_size_engine_vs_reference():
 
 
 @pytest.mark.timeout(900)
+def test_deep_scene_engine_vs_reference():
+    """A scene whose ranges span a factor of eleven (0.72 .. 8.03 m; tests/golden/baseline_deep_640x480_n8.npz) against the reference
+    itself, in full: match maps of all nine views bit for bit, 200 J-parameter and 200 closed-form iterations -- on the store the
+    device chooses for such an image: 26-bit range codes (6.25 B/observation; until round 5: the 7-byte float32 words)."""
+    from sucre_amd import _lib, engine
+    b = helpers.load_baseline(helpers.BASELINE_DEEP)
+    T_param, T_closed = int(b['T_param']), int(b['T_closed'])
+    assert (T_param, T_closed) == (200, 200)
+    sc = b.scene
+    views = engine.device_views_from_scene(sc, 'cuda')
+    r = engine.Restoration(sc.height, sc.width, len(views))
+    r.match(views[sc.target], views)
+    word = r.store_format().cpu().numpy().astype(np.uint32)
+    assert int(word[0]) == _lib.STORE_Z26 and int(word[3]) - int(word[2]) > 0xfffffd, word
+    del r
+    e = engine_run(b, T_param, T_closed)
+    helpers.check_baseline_fit(b, 'param_1', e['J1'], None, 1e-7, 0, 0, 'ENGINE, deep scene, 1 iteration')
+    helpers.check_baseline_fit(b, 'param', e['J'], e['trace'], 1e-6, 2e-6, 2e-5, f'ENGINE, deep scene, {T_param} iterations')
+    helpers.check_baseline_fit(b, 'closed', e['Jc'], e['trace_c'], 2e-5, 2e-5, 2e-5, f'ENGINE, deep scene, {T_closed} iterations')
+
+
+@pytest.mark.timeout(900)
 def test_config5_view_count_engine_vs_reference():
     """BASELINE config 5's view count (256 neighbours + self: five mask words per pixel, strips of up to 257 levels = 65 chunks)
     on a 480x360 image against the reference itself: all 257 match maps bit for bit, 8 J-parameter and 4 closed-form iterations."""

@@ -957,9 +957,10 @@ def test_float32_store_as_24_bit_offsets_changes_no_bit():
 
 
 def test_24_bit_offsets_exactly_when_the_ranges_fit():
-    """The decision at its boundary, through the import path (explicit ranges): views whose ranges are the bit patterns
-    lo .. lo + span.  span = 2^24 - 3: the largest that fits (code 0 is the empty slot); one more: the float32 words are
-    kept.  Either way the fit equals the one on the float32 words bit for bit."""
+    """The decision at its boundaries, through the import path (explicit ranges): views whose ranges are the bit patterns
+    lo .. lo + span.  span = 2^24 - 3: the largest that fits 24-bit codes (code 0 is the empty slot); one more: 26-bit codes
+    (round 6), up to 2^26 - 3; one more: the float32 words are kept.  Whichever it is, the fit equals the one on the float32
+    words bit for bit."""
     from sucre_amd import _lib, engine
     H, W = 32, 48
     g = torch.Generator().manual_seed(5)
@@ -970,7 +971,8 @@ def test_24_bit_offsets_exactly_when_the_ranges_fit():
     rgb_t = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g)
     depth_t = torch.full((H, W), 2.0)
     target = engine.DeviceView(depth=depth_t.cuda(), rgb=rgb_t.cuda(), K=torch.eye(3), R=torch.eye(3), t=torch.zeros(3, 1))
-    for span, want in ((0xfffffd, _lib.STORE_Z24), (0xfffffe, _lib.STORE_F32), (5, _lib.STORE_Z24)):
+    for span, want in ((0xfffffd, _lib.STORE_Z24), (0xfffffe, _lib.STORE_Z26), (5, _lib.STORE_Z24), (0x3fffffd, _lib.STORE_Z26),
+                       (0x3fffffe, _lib.STORE_F32)):
         lists = []
         for k in range(3):
             bits = lo + torch.randint(0, span + 1, (n,), generator=g, dtype=torch.int64)
@@ -990,3 +992,59 @@ def test_24_bit_offsets_exactly_when_the_ranges_fit():
             assert int(word[0]) == (want if fmt == 'f32' else _lib.STORE_F32), (span, fmt, word)
             got[fmt] = _fit_digest(r, target, T=6)
         assert got['f32'] == got['f32plain'], hex(span)
+
+
+# ---- round 6: float32 ranges kept as 26-bit offsets when they span more than 2^24 bit patterns (layout.h kStoreZ26) ------------
+
+@pytest.mark.timeout(600)
+def test_deep_scene_keeps_26_bit_codes_and_changes_no_bit():
+    """A scene whose ranges span a factor of eleven (synth.make_deep_scene: 0.7 .. 8 m, more than 2^24 float32 bit patterns) --
+    until round 5 such an image fell back to the 7-byte float32 words; now the device keeps 26-bit codes (6.25 B/observation).
+    Same trace, J and parameters bit for bit as 'f32plain' in both J modes; also with 257 views (the strip_levels /
+    tile_offset / strip_offset path of the compaction, whose strip offsets are padded to whole chunks for this format)."""
+    from sucre_amd import _lib, engine, synth
+    for (W, H, nn) in ((333, 207, 8), (640, 480, 8), (96, 64, 256)):
+        scene = synth.make_deep_scene(W, H, nn, seed=0, device='cuda')
+        views = engine.device_views_from_scene(scene, 'cuda')
+        got = {}
+        for fmt in ('f32', 'f32plain'):
+            r = engine.Restoration(H, W, len(views), obs_format=fmt)
+            r.match(views[scene.target], views)
+            word = r.store_format().cpu().numpy().astype(np.uint32)
+            lo, hi = int(word[2]), int(word[3])
+            assert 0xfffffd < hi - lo <= 0x3fffffd, 'the deep scene spans more than 2^24 and less than 2^26 range bit patterns'
+            assert int(word[0]) == (_lib.STORE_Z26 if fmt == 'f32' else _lib.STORE_F32) and int(word[1]) == (lo - 1 if fmt == 'f32' else 0)
+            got[fmt] = _fit_digest(r, views[scene.target]) + [int(r.n_obs())]
+            r.fit_init(views[scene.target])
+            r.update_J()
+            got[fmt].append(r.J().cpu().numpy().tobytes())
+            del r
+        assert got['f32'] == got['f32plain'], (W, H, nn)
+
+
+@pytest.mark.timeout(600)
+def test_forced_26_bit_codes_change_no_bit():
+    """'f32z26' (SUCRE_OBS_F32_Z26: the 26-bit codes or the words, never the 24-bit ones) on scenes that would fit 24 bits: the
+    third form of the same store -- bit for bit the fits on the 24-bit codes and on the float32 words, alone and through the
+    batch launch, below and above 255 views."""
+    from sucre_amd import _lib, engine, synth
+    for (W, H, nn, seed, far) in ((333, 207, 13, 7, 0), (160, 120, 6, 3, 1), (96, 64, 2, 11, 0), (96, 64, 258, 1, 0)):
+        scene = synth.make_scene(W, H, nn, seed=seed, device='cuda', far_views=far, relief=0.4)
+        views = engine.device_views_from_scene(scene, 'cuda')
+        got, keep = {}, {}
+        for fmt, want in (('f32', _lib.STORE_Z24), ('f32z26', _lib.STORE_Z26), ('f32plain', _lib.STORE_F32)):
+            r = engine.Restoration(H, W, len(views), obs_format=fmt)
+            r.match(views[scene.target], views)
+            assert int(r.store_format()[0].item()) == want, fmt
+            got[fmt] = _fit_digest(r, views[scene.target])
+            keep[fmt] = r
+        assert got['f32'] == got['f32z26'] == got['f32plain'], (W, H, nn)
+        # two images in one batch launch, one per format of the float32 store (the formats are per image: read from each workspace)
+        rs = [keep['f32z26'], keep['f32']]
+        for closed in (False, True):
+            for r in rs:
+                r.fit_init(views[scene.target])
+            traces = engine.fit_batch(rs, 7, use_closed_form=closed)
+            torch.cuda.synchronize()
+            assert np.array_equal(traces[0].cpu().numpy(), traces[1].cpu().numpy())
+            assert rs[0].J().cpu().numpy().tobytes() == rs[1].J().cpu().numpy().tobytes()

@@ -848,7 +848,7 @@ def test_bench_finds_the_profile_of_exactly_its_own_mode(monkeypatch, tmp_path):
     modes = {'jparam': (), 'closed': ('--use-closed-form',), 'light': ('--light-model',), 'light_closed': ('--light-model', '--use-closed-form'),
              'u16mm_4k': ('--config', '5'), 'shared4': ('--shared-water', '--batch-images', '4'), 'jparam_batch32': ('--config', '1'),
              'closed_batch32': ('--config', '1', '--use-closed-form'), 'jparam_f32plain': ('--obs-format', 'f32plain'),
-             'shared64': ('--config', '4')}
+             'shared64': ('--config', '4'), 'jparam_f32z26': ('--obs-format', 'f32z26'), 'jparam_deep': ('--scene', 'deep')}
     for mode, argv in modes.items():
         assert tag(*argv) == mode
     # every mode tools/profile.sh knows is one bench.py can name (the in-flight variant is the default command's second profile)

@@ -278,6 +278,21 @@ def test_baseline_config1_in_full_oracle_vs_reference():
     helpers.check_baseline_fit(b, 'closed', Jc, trc, 1e-5, 2e-5, 1e-5, f'oracle, config 1, {T_closed} iterations')
 
 
+def test_baseline_deep_scene_oracle_vs_reference():
+    """A scene whose ranges span a factor of eleven (0.72 .. 8.03 m: synth.make_deep_scene, cameras 0.75 .. 4 m above the seabed,
+    half of them oblique; tests/golden/baseline_deep_640x480_n8.npz, round 6) in full: the reference's match sets of all nine
+    views bit for bit, its 200 J-parameter and 200 closed-form iterations."""
+    b = helpers.load_baseline(helpers.BASELINE_DEEP)
+    sc = b.scene
+    samples, J0, T_param, T_closed = oracle_baseline_run(b)
+    z = np.concatenate([np.sqrt((cP.astype(np.float64) ** 2).sum(axis=0)) for _, _, cP, _ in samples])
+    assert z.min() < 0.75 and z.max() > 8.0, 'the deep scene spans more than a factor of ten in range'
+    J, params, trace = oracle.fit(sc.height, sc.width, samples, J0, num_iter=T_param)
+    helpers.check_baseline_fit(b, 'param', J, trace, 1e-6, 2e-6, 2e-5, f'oracle, deep scene, {T_param} iterations')
+    Jc, pc, trc = oracle.fit(sc.height, sc.width, samples, None, num_iter=T_closed, use_closed_form=True)
+    helpers.check_baseline_fit(b, 'closed', Jc, trc, 2e-5, 2e-5, 2e-5, f'oracle, deep scene, {T_closed} iterations')
+
+
 def test_baseline_odd_image_size_oracle_vs_reference():
     """An image whose sides are no multiples of 16 (333x207, 8 neighbours + self; tests/golden/baseline_odd_333x207_n8.npz):
     the reference's match sets bit for bit, its 60 J-parameter and 30 closed-form iterations, the whole J."""

@@ -6,7 +6,7 @@
 # the SQ counters.  tools/summarize_prof.py condenses them into profiles/<tag>_<mode>_{kernel_stats.csv,traffic.json,
 # summary.txt}; raw per-dispatch dumps stay on the box.
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 MODES=${*:-"jparam jparam_inflight2 closed light light_closed u16mm_4k shared4 jparam_batch32"}
 export TMPDIR=/tmp
 mode_args() {
@@ -19,6 +19,10 @@ mode_args() {
     u16mm_4k) echo "--width 3840 --height 2160 --neighbours 256 --obs-format u16mm" ;;
     shared4) echo "--shared-water --batch-images 4" ;;
     jparam_batch32) echo "--config 1" ;;   # BASELINE config 1 (640x480, 4 neighbours), 32 consecutive images per fit launch
+    closed_batch32) echo "--config 1 --use-closed-form" ;;
+    jparam_f32plain) echo "--obs-format f32plain" ;;   # the float32 words themselves (7 B/obs): what an image outside every code window pays
+    jparam_f32z26) echo "--obs-format f32z26" ;;       # the 26-bit range codes forced on the default scene (A/B against the 24-bit ones)
+    jparam_deep) echo "--scene deep" ;;                # ranges 0.7-8 m: the device keeps 26-bit range codes (6.25 B/obs)
     *) echo "unknown mode $1" >&2; exit 2 ;;
   esac
 }
@@ -38,13 +42,13 @@ for MODE in $MODES; do
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
   else
     STEPS="--steps 2 --warmup 1"; [ $MODE = u16mm_4k ] && STEPS="--steps 1 --warmup 1 --solo-images 1"
-    [ $MODE = jparam_batch32 ] && STEPS="--steps 64 --warmup 32"
+    case $MODE in *_batch32) STEPS="--steps 64 --warmup 32" ;; esac
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $STEPS --no-cpu-baseline --images-in-flight 1 $M > $OUT/bench_trace.log 2>&1
     PMC="--steps 1 --warmup 0 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M"
     # (shared4: with --warmup 0 bench.py's set-up pass fits ONE image through the group kernel; --warmup 1 skips it, so that
     # every group_iter_kernel dispatch in the averages walks all four images)
     [ $MODE = shared4 ] && PMC="--steps 1 --warmup 1 --no-cpu-baseline --images-in-flight 1 --num-iter 10 $M"
-    [ $MODE = jparam_batch32 ] && PMC="--steps 32 --warmup 32 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M"
+    case $MODE in *_batch32) PMC="--steps 32 --warmup 32 --no-cpu-baseline --images-in-flight 1 --num-iter 10 --solo-images 1 $M" ;; esac
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $PMC > $OUT/bench_pmc_fetch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 bench.py $PMC > $OUT/bench_pmc_write.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 bench.py $PMC > $OUT/bench_pmc_sq.log 2>&1
