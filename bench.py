@@ -59,7 +59,7 @@ def parse():
                         "words themselves (A/B); u16mm = 5 B/obs (config 5)")
     p.add_argument('--scene', choices=['survey', 'deep'], default='survey',
                    help="survey = SURVEY 8(d)'s seabed seen from 3 m (ranges within a factor of 1.3: the store keeps 24-bit range codes); deep = "
-                        "synth.make_deep_scene: cameras 0.75-4 m above it, half of them oblique, ranges 0.7-8 m and more (26-bit codes, 6.25 B/obs)")
+                        "synth.make_deep_scene: cameras 0.75-4 m above it, half of them oblique, ranges 0.7-8 m and more (the float32 words, 7 B/obs)")
     p.add_argument('--solo-images', type=int, default=3,
                    help='images restored one at a time after the timed region for the roofline block')
     p.add_argument('--timeout-s', type=float, default=1500.0,
@@ -116,12 +116,12 @@ def profile_tag(args, B=None):
     tag = ('light_closed' if args.use_closed_form else 'light') if args.light_model else ('closed' if args.use_closed_form else 'jparam')
     if B > 1:
         tag += f'_batch{B}'
+    if getattr(args, 'scene', 'survey') != 'survey':
+        tag += '_' + args.scene
     if args.obs_format == 'u16mm':
         tag = 'u16mm_4k' if (tag, args.width, args.height) == ('jparam', 3840, 2160) else tag + '_u16mm'
     elif args.obs_format != 'f32':
         tag += '_' + args.obs_format
-    if getattr(args, 'scene', 'survey') != 'survey':
-        tag += '_' + args.scene
     return tag
 
 

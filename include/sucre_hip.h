@@ -59,9 +59,10 @@ extern "C" {
  * its own business as long as every bit comes back: when all ranges of an image lie within 2^24 - 2 float32 bit patterns
  * of the smallest one (a span of about a factor of four) and nothing rides along in extension planes, the finalize step
  * stores them as 24-bit offsets from it (6 B/observation, decided on the device, no host synchronisation); an image whose
- * ranges span more than that but lie within 2^26 - 2 bit patterns (a factor of up to 256 between the nearest and the
- * farthest range) is stored as 26-bit offsets, 6.25 B/observation; wider still, as the float32 words.  Results are
- * bit-identical whichever it is.  SUCRE_OBS_F32_PLAIN asks for the float32 words themselves (A/B measurements, tests).
+ * ranges span more keeps the float32 words.  SUCRE_OBS_F32_Z26 asks for 26-bit offsets instead (6.25 B/observation) whenever
+ * the ranges lie within 2^26 - 2 bit patterns (a factor of up to 256 between the nearest and the farthest range) -- an
+ * opt-in: measured, the fit reads the words faster than it decodes these.  Results are bit-identical
+ * whichever form the store takes.  SUCRE_OBS_F32_PLAIN asks for the float32 words themselves (A/B measurements, tests).
  * SUCRE_OBS_U16MM: the range as uint16 millimetres, rint(1000 z) clamped to [1, 65535] = 5 B/observation (BASELINE
  * config 5) -- lossy by at most 0.5 mm of range; every sum is still accumulated in float32/float64 exactly as with
  * SUCRE_OBS_F32.  A store finalised with SUCRE_OBS_F32 or SUCRE_OBS_F32_PLAIN is fitted WITHOUT SUCRE_FIT_OBS_U16MM.
@@ -69,7 +70,7 @@ extern "C" {
 #define SUCRE_OBS_F32 0
 #define SUCRE_OBS_U16MM 1
 #define SUCRE_OBS_F32_PLAIN 2
-#define SUCRE_OBS_F32_Z26 3   /* SUCRE_OBS_F32 that may only choose the 26-bit offsets (below) or the words: tests, A/B */
+#define SUCRE_OBS_F32_Z26 3   /* float32 ranges as 26-bit offsets when they fit, else as words (never the 24-bit form) */
 
 /*
  * What the three float32 extension planes of the second workspace (`lws`, see the *_light entry points) carry per

@@ -691,8 +691,11 @@ hipError_t launch_compact(const Layout &L, uint8_t *ws, hipStream_t s, const uin
     // fmt: what the caller asked for (include/sucre_hip.h): SUCRE_OBS_F32 = float32 ranges, kept as 24-bit codes when the image
     // allows it and nothing rides along in extension planes; SUCRE_OBS_U16MM; SUCRE_OBS_F32_PLAIN = float32 ranges as they are
     const int store_req = fmt == SUCRE_OBS_U16MM ? kStoreU16 : kStoreF32;
-    // range codes the device may choose: bit 0 = 24-bit, bit 1 = 26-bit (SUCRE_OBS_F32_Z26: the 26-bit ones or none -- tests, A/B)
-    const int allow = ext_dense ? 0 : fmt == SUCRE_OBS_F32 ? 3 : fmt == SUCRE_OBS_F32_Z26 ? 2 : 0;
+    // range codes the device may choose: bit 0 = 24-bit, bit 1 = 26-bit.  The default store takes the 24-bit codes or the words:
+    // the 26-bit codes (SUCRE_OBS_F32_Z26: those or the words) are built, bit-exact and measured SLOWER than the words they would
+    // replace -- 139.3 against 135.9 us per launch at 1080p x 65 views, 90.0 against 86.3 us on a scene whose ranges span 0.7-8 m
+    // (profiles/r06_jparam_f32z26_*, r06_jparam_deep_*): eight more vector instructions per chunk cost more than 192 fewer bytes return
+    const int allow = ext_dense ? 0 : fmt == SUCRE_OBS_F32 ? 1 : fmt == SUCRE_OBS_F32_Z26 ? 2 : 0;
     const uint32_t *store_fmt = reinterpret_cast<const uint32_t *>(ws + L.off_total_chunks) + 2;
     hipLaunchKernelGGL(pixel_count_kernel, dim3(L.n_tiles), dim3(256), 0, s, reinterpret_cast<const uint64_t *>(ws + L.off_vbits),
                        pmask, L.mask_words, keep, L.n_views, L.n_tiles, pcount, blockhist);

@@ -21,14 +21,18 @@
 
 namespace sucre {
 
-constexpr int kLightSums = 26;   // sB[3] sGZ[3] sBeta[3] cost | dR[9] dt[3] dM[4]
+// sB[3] sGZ[3] sBeta[3] cost | torque[3] = sum lP x dlP, force[3] = sum dlP | dM00, dM01, dM11.  (Until round 5: 26 sums, the
+// 3x3 sum dlP cP^T and sum dlP in their place.  With T = exp(hat xi) and D exp(hat xi)[G_i] = hat(v_i) T, v_i = (omega_i, u_i):
+// <sum dlP cP^T, D_R> + <sum dlP, D_t> = sum dlP . (omega_i x lP + u_i) = omega_i . torque + u_i . force -- six sums and six FMAs
+// per observation instead of twelve and twelve; light_geometry leaves the six twists v_i behind instead of the derivatives.)
+constexpr int kLightSums = 19;
 constexpr int kLightParams = 19;
 
 struct LightLayout {
     size_t off_ext_dense, off_ext_comp;   // dense: float [chunk][3][256]; compact: kExtLevelBytes per level of a strip
     size_t off_params;                    // float [19] params, [19] exp_avg, [19] exp_avg_sq
     size_t off_geom;                      // float [16]: R[9], t[3], M[4] = Sigma^-1 (row-major)
-    size_t off_dexp;                      // double [6][12]: d exp(hat xi)[G_i], rows 0..2 of the 4x4 derivative (with the geometry)
+    size_t off_dexp;                      // double [6][12]: entries 0..5 of row i = the twist v_i = (omega_i, u_i) with D exp(hat xi)[G_i] = hat(v_i) exp(hat xi) (with the geometry)
     size_t off_partials;                  // float [26][n_blocks]
     size_t off_sums;                      // double [26]
     size_t off_deal;                      // uint32 [8192] strips per wave, then [8 n_strips] the waves' strip lists (light_deal_kernel)
@@ -126,9 +130,25 @@ __device__ __forceinline__ void light_geometry(const float *params, float *geom,
         if (c < 3) geom[r * 3 + c] = (float)E[0][r * 8 + c];
         else geom[9 + r] = (float)E[0][r * 8 + 3];
     }
-    for (int k = tid; k < 72; k += blockDim.x) {   // any workgroup size writes all 72 derivatives
-        const int i = k / 12, e = k % 12, r = e / 4, c = e % 4;
-        dexp[i * 12 + e] = E[i][r * 8 + 4 + c];
+    if (tid < 6) {   // v_i from D_i = D exp(hat xi)[G_i] (upper-right block of exponential i) and T = exp(hat xi) (its diagonal block):
+        // hat(v_i) = D_i T^-1, T^-1 = [R^T, -R^T t]: Omega = D_R R^T (antisymmetric up to rounding), u = D_t - Omega t
+        const double *Ei = E[tid];
+        double Om[9], u[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double x = 0.0;
+                for (int k = 0; k < 3; ++k) x += Ei[r * 8 + 4 + k] * Ei[c * 8 + k];   // D_R[r][k] R[c][k]
+                Om[r * 3 + c] = x;
+            }
+        for (int r = 0; r < 3; ++r) {
+            double x = Ei[r * 8 + 7];
+            for (int k = 0; k < 3; ++k) x -= Om[r * 3 + k] * Ei[k * 8 + 3];
+            u[r] = x;
+        }
+        double *v = dexp + tid * 12;
+        v[0] = 0.5 * (Om[7] - Om[5]); v[1] = 0.5 * (Om[2] - Om[6]); v[2] = 0.5 * (Om[3] - Om[1]);
+        v[3] = u[0]; v[4] = u[1]; v[5] = u[2];
+        for (int k = 6; k < 12; ++k) v[k] = 0.0;
     }
     if (tid == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
         const float *sg = params + 15;
@@ -159,7 +179,7 @@ struct LightAcc {
 };
 
 // l, total range z and the light-frame quantities of one observation (sucre.py:55-63)
-struct LightObs { float l, z, nl, inl, iz, lp0, lp1, w0, w1, lP[3]; };
+struct LightObs { float l, z, nl, inl, iz, lp0, lp1, w0, w1, q, lP[3]; };   // q = lp^T M lp = lp . (w0, w1)
 
 template <bool kGradual = false>
 __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const float (&R)[9], const float (&tl)[3],
@@ -175,8 +195,8 @@ __device__ __forceinline__ LightObs light_obs(const float cP[3], float zc, const
     o.lp1 = o.lP[1] * o.iz;
     o.w0 = __builtin_fmaf(M[0], o.lp0, M[1] * o.lp1);   // M = (sigma^T sigma)^-1 is symmetric: M[1] == M[2]
     o.w1 = __builtin_fmaf(M[2], o.lp0, M[3] * o.lp1);
-    const float q = __builtin_fmaf(o.lp0, o.w0, o.lp1 * o.w1);
-    o.l = exp2_as<kGradual>(q * (-0.5f * kLog2e));
+    o.q = __builtin_fmaf(o.lp0, o.w0, o.lp1 * o.w1);
+    o.l = exp2_as<kGradual>(o.q * (-0.5f * kLog2e));
     const float n2 = __builtin_fmaf(o.lP[2], o.lP[2], __builtin_fmaf(o.lP[1], o.lP[1], o.lP[0] * o.lP[0]));
     o.inl = __builtin_amdgcn_rsqf(n2);
     o.nl = n2 * o.inl;
@@ -302,12 +322,9 @@ __device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *
     double *grad = lds.grad;
     const int tid = threadIdx.x;
     const double f = -2.0 * (double)((1.0f / 3.0f) / (float)(*n_obs_total));   // dL/dIhat = f * r
-    if (tid < 6) {  // cam2light: <[dR dt; 0 0], D exp(hat xi)[G_i]>, the derivative left behind with the geometry
+    if (tid < 6) {  // cam2light: omega_i . torque + u_i . force, the twist left behind with the geometry
         double s = 0.0;
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) s += sums[10 + r * 3 + c] * dexp[tid * 12 + r * 4 + c];
-            s += sums[19 + r] * dexp[tid * 12 + r * 4 + 3];
-        }
+        for (int r = 0; r < 3; ++r) s += sums[10 + r] * dexp[tid * 12 + r] + sums[13 + r] * dexp[tid * 12 + 3 + r];
         grad[9 + tid] = f * s;
     }
     if (tid == 6) {  // water parameters (same combinations as water_step of the default path)
@@ -319,7 +336,7 @@ __device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *
     }
     if (tid == 7) {  // sigma: M = Sigma^-1, Sigma = sigma^T sigma;  dSigma = -M^T dM M^T;  dsigma = sigma (dSigma + dSigma^T)
         const double M[4] = {geom[12], geom[13], geom[14], geom[15]};
-        const double dM[4] = {f * sums[22], f * sums[23], f * sums[23], f * sums[25]};  // lane 24 is not accumulated (symmetry)
+        const double dM[4] = {f * sums[16], f * sums[17], f * sums[17], f * sums[18]};  // (lp lp^T is symmetric)
         const double Mt[4] = {M[0], M[2], M[1], M[3]};
         double T1[4], dS[4];
         T1[0] = Mt[0] * dM[0] + Mt[1] * dM[2]; T1[1] = Mt[0] * dM[1] + Mt[1] * dM[3];
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                                                          const AdamCoef co, const uint32_t *__restrict__ deal_count,
                                                          const uint32_t *__restrict__ deal_strips, uint32_t deal_kmax) {
     __shared__ float wsum[4][kLightSums];
+    constexpr bool kPingPong = !kColour && !kBoth;   // two named register sets for the chunk prefetch (the light model on uint8 colours)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n_blocks = gridDim.x;
@@ -397,33 +415,30 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             if (strip >= (uint32_t)n_strips) continue;
         }
         const StripMeta sm = meta[strip];
-        const uint32_t n = sm.levels, nch = (n + 3u) >> 2;
-        const uint8_t *sobs = comp + sm.lvoff * (uint64_t)level_bytes(0);
-        const uint8_t *sext = ext + sm.lvoff * (uint64_t)kExtLevelBytes;
-        const uint8_t *sext2 = kBoth ? ext2 + sm.lvoff * (uint64_t)kExtLevelBytes : nullptr;
+        const uint32_t n = __builtin_amdgcn_readfirstlane(sm.levels), nch = (n + 3u) >> 2;
+        // wave-uniform bases, held in scalar registers: the loads below are base + 32-bit lane offset (with per-lane 64-bit
+        // pointers the address arithmetic was 7 vector instructions per observation)
+        const uint64_t lvoff = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sm.lvoff >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)sm.lvoff);
+        const uint8_t *sobs = comp + lvoff * (uint64_t)level_bytes(0);
+        const uint8_t *sext = ext + lvoff * (uint64_t)kExtLevelBytes;
+        const uint8_t *sext2 = kBoth ? ext2 + lvoff * (uint64_t)kExtLevelBytes : nullptr;
         float *st = state + (size_t)strip * kStateFloats + lane;
         float J[3];
         if (kClosed) {
             // closed-form J of this pixel: numerator / denominator per channel over all levels
             float num[3], den[3];
-            float wq[7][3];   // (kExpWaterPass1 only)
-            if (kExpWaterPass1) {
-#pragma unroll
-                for (int q = 0; q < 7; ++q) wq[q][0] = wq[q][1] = wq[q][2] = 0.f;
-            }
             auto solve = [&](auto gradual) {
                 constexpr bool kGradual = decltype(gradual)::value;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) num[c] = den[c] = 0.f;
-                for (uint32_t g = 0; g < nch; ++g) {
-                    const uint32_t rr = min((uint32_t)kGroupLv, n - g * kGroupLv);
-                    const LightChunk kk = load_light_chunk<kJOnly>(sobs, sext, g, rr, lane);
+                auto load1 = [&](uint32_t g) { return load_light_chunk<kJOnly>(sobs, sext, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane); };
+                auto solve_chunk = [&](const LightChunk &kk, uint32_t g) {
                     ColourChunk fc;
-                    if (kBoth) fc = load_colour_chunk(sext2, g, rr, lane);
+                    if (kBoth) fc = load_colour_chunk(sext2, g, min((uint32_t)kGroupLv, n - g * kGroupLv), lane);
                     if (kExpNoCompute) {  // ablation build only: touch the data, skip the model
                         num[0] += chunk_checksum(kk);
                         den[0] = den[1] = den[2] = 1.0f;
-                        continue;
+                        return;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -439,16 +454,23 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                             const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
                             num[c] = __builtin_fmaf(I - b, a, num[c]);
                             den[c] = __builtin_fmaf(a, a, den[c]);
-                            if (kExpWaterPass1) {   // timing experiment only (experiment.h): what the one-pass water sums of
-                                // fit.hip's closed_terms would add to this pass -- omg, z a, z g and seven more sums per channel
-                                const float g2 = 1.0f - b, za = o.z * a, zg = o.z * g2, p = I - b;
-                                wq[0][c] = __builtin_fmaf(p, g2, wq[0][c]); wq[1][c] = __builtin_fmaf(a, g2, wq[1][c]);
-                                wq[2][c] = __builtin_fmaf(p, za, wq[2][c]); wq[3][c] = __builtin_fmaf(a, za, wq[3][c]);
-                                wq[4][c] = __builtin_fmaf(p, zg, wq[4][c]); wq[5][c] = __builtin_fmaf(a, zg, wq[5][c]);
-                                wq[6][c] = __builtin_fmaf(p, p, wq[6][c]);
-                            }
                         }
                     }
+                };
+                // the next chunk's loads before this chunk's arithmetic, two named register sets (as in the gradient pass below;
+                // until round 6 this pass loaded, waited, computed)
+                if constexpr (kPingPong) {
+                    LightChunk ka = nch ? load1(0) : LightChunk{}, kb2 = LightChunk{};
+                    for (uint32_t g = 0; g < nch; g += 2u) {
+                        if (g + 1u < nch) kb2 = load1(g + 1u);
+                        solve_chunk(ka, g);
+                        if (g + 1u < nch) {
+                            if (g + 2u < nch) ka = load1(g + 2u);
+                            solve_chunk(kb2, g + 1u);
+                        }
+                    }
+                } else {
+                    for (uint32_t g = 0; g < nch; ++g) solve_chunk(load1(g), g);
                 }
             };
             solve(std::false_type{});
@@ -463,13 +485,6 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             for (int c = 0; c < 3; ++c) {
                 J[c] = num[c] / den[c];  // 0/0 = NaN where nothing was observed
                 st[c * kStripPx] = J[c];
-                if (kExpWaterPass1) {   // the pixel's share of the water sums, formed from the pass-one sums (values meaningless here)
-                    const float dJ = J[c];
-                    acc.s[c] += __builtin_fmaf(-dJ, wq[1][c], wq[0][c]);
-                    acc.s[6 + c] += __builtin_fmaf(-dJ, wq[3][c], wq[2][c]);
-                    acc.s[3 + c] += __builtin_fmaf(-dJ, wq[5][c], wq[4][c]);
-                    acc.s[9] += __builtin_fmaf(-dJ, num[c], wq[6][c]);
-                }
             }
             if (kJOnly) continue;
         } else {
@@ -486,20 +501,14 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         // the caches would find none of it).
         auto chunk_at = [&](uint32_t i) { return kClosed ? nch - 1u - i : i; };
         auto levels_of = [&](uint32_t g) { return min((uint32_t)kGroupLv, n - g * kGroupLv); };
-        LightChunk kn = nch ? load_light_chunk(sobs, sext, chunk_at(0), levels_of(chunk_at(0)), lane) : LightChunk{};
-        for (uint32_t gi = 0; gi < nch; ++gi) {
-            const uint32_t g = chunk_at(gi);
-            const uint32_t rr = levels_of(g);
-            const LightChunk kk = kn;
-            if (!kBoth && gi + 1u < nch) kn = load_light_chunk(sobs, sext, chunk_at(gi + 1u), levels_of(chunk_at(gi + 1u)), lane);
+        auto load_at = [&](uint32_t i) { return load_light_chunk(sobs, sext, chunk_at(i), levels_of(chunk_at(i)), lane); };
+        // one chunk: four levels of this lane's pixel
+        auto grad_chunk = [&](const LightChunk &kk, uint32_t gi) {
             ColourChunk fc;
-            if (kBoth) {
-                fc = load_colour_chunk(sext2, g, rr, lane);
-                if (gi + 1u < nch) kn = load_light_chunk(sobs, sext, chunk_at(gi + 1u), levels_of(chunk_at(gi + 1u)), lane);
-            }
+            if (kBoth) fc = load_colour_chunk(sext2, chunk_at(gi), levels_of(chunk_at(gi)), lane);
             if (kExpNoCompute) {
                 acc.s[9] += chunk_checksum(kk);
-                continue;
+                return;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -509,52 +518,75 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                 if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
                 else o = light_obs(cP, kk.zz[j], R, tl, M);
                 const float l = o.l, z = o.z;
-                float dl = 0.f, dz = 0.f;
+                float dl = 0.f, dz = 0.f;   // dl = l dL/dl (the factor l rides in the modelled colour l E), dz = dL/dz
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float a = fast_exp2(z * nb[c]), g2 = fast_exp2(z * ng[c]);
                     const float omg = 1.0f - g2;
-                    const float E = __builtin_fmaf(J[c], a, B[c] * omg);
+                    const float lE = l * __builtin_fmaf(J[c], a, B[c] * omg);
                     // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
                     // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
                     const uint32_t kb = (kk.cc[c] >> (8 * j)) & 255u;
-                    const float r = kBoth ? fc.c[c][j] - l * E
-                                  : kColour ? cP[c] - l * E
-                                  : kClosed ? unit_from_u8(kb) - l * E : __builtin_fmaf((float)kb, kInv255L, -(l * E));
+                    const float r = kBoth ? fc.c[c][j] - lE
+                                  : kColour ? cP[c] - lE
+                                  : kClosed ? unit_from_u8(kb) - lE : __builtin_fmaf((float)kb, kInv255L, -lE);
                     const float rl = r * l;
                     const float rlz = rl * z;
-                    if (!(kExpWaterPass1 && kClosed)) {   // (the experiment has formed these in pass one)
-                        acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
-                        pa[c] = __builtin_fmaf(rl, a, pa[c]);
-                        pb[c] = __builtin_fmaf(rlz, a, pb[c]);
-                        acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
-                        acc.s[3 + c] = __builtin_fmaf(rlz, g2, acc.s[3 + c]);
-                    }
-                    dl = __builtin_fmaf(r, E, dl);
+                    acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
+                    pa[c] = __builtin_fmaf(rl, a, pa[c]);
+                    pb[c] = __builtin_fmaf(rlz, a, pb[c]);
+                    acc.s[c] = __builtin_fmaf(rl, omg, acc.s[c]);
+                    acc.s[3 + c] = __builtin_fmaf(rlz, g2, acc.s[3 + c]);
+                    dl = __builtin_fmaf(r, lE, dl);
                     dz = __builtin_fmaf(rl, __builtin_fmaf(gB[c], g2, -(bJ[c] * a)), dz);
                 }
                 if (kColour) continue;  // no light: nothing flows into cam2light / sigma
-                // chain rule into lP (common factor -2 s applied in the step kernel); M symmetric:
-                // d(lp^T M lp)/dlp = 2 M lp = 2 (w0, w1)
-                const float kf = dl * (-0.5f * l);
-                const float kf2 = kf + kf;
-                const float dlp0 = kf2 * o.w0;
-                const float dlp1 = kf2 * o.w1;
-                const float iz = o.iz, dzi = dz * o.inl;
+                // chain rule into lP (common factor -2 s applied in the step kernel).  l = exp(-q / 2), q = lp^T M lp, M symmetric:
+                // dL/dlp = dl (-1/2) 2 M lp = -dl (w0, w1); lp = lP.xy / lP.z: dL/dlP.xy = dL/dlp iz, dL/dlP.z = -(dL/dlp . lp) iz
+                // = dl q iz (w . lp = q); z = ||cP|| + ||lP||: dL/dlP += dz lP / ||lP||.
+                const float kz = dl * o.iz;          // (-kz) (w0, w1, -q) is the light cone's share of dL/dlP
+                const float dzi = dz * o.inl;
                 float dlP[3];
-                dlP[0] = __builtin_fmaf(dzi, o.lP[0], dlp0 * iz);
-                dlP[1] = __builtin_fmaf(dzi, o.lP[1], dlp1 * iz);
-                dlP[2] = __builtin_fmaf(dzi, o.lP[2], -(__builtin_fmaf(dlp0, o.lp0, dlp1 * o.lp1) * iz));   // lP.xy iz = lp
+                dlP[0] = __builtin_fmaf(dzi, o.lP[0], -(kz * o.w0));
+                dlP[1] = __builtin_fmaf(dzi, o.lP[1], -(kz * o.w1));
+                dlP[2] = __builtin_fmaf(dzi, o.lP[2], kz * o.q);
+                // sum lP x dlP and sum dlP: what the six cam2light gradients factor through (kLightSums)
+                acc.s[10] = __builtin_fmaf(o.lP[1], dlP[2], __builtin_fmaf(-o.lP[2], dlP[1], acc.s[10]));
+                acc.s[11] = __builtin_fmaf(o.lP[2], dlP[0], __builtin_fmaf(-o.lP[0], dlP[2], acc.s[11]));
+                acc.s[12] = __builtin_fmaf(o.lP[0], dlP[1], __builtin_fmaf(-o.lP[1], dlP[0], acc.s[12]));
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    acc.s[19 + a] += dlP[a];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) acc.s[10 + a * 3 + b] = __builtin_fmaf(dlP[a], cP[b], acc.s[10 + a * 3 + b]);
-                }
+                for (int a = 0; a < 3; ++a) acc.s[13 + a] += dlP[a];
+                // dL/dM = sum dl (-1/2) lp lp^T
+                const float kf = -0.5f * dl;
                 const float k0 = kf * o.lp0;
-                acc.s[22] = __builtin_fmaf(k0, o.lp0, acc.s[22]);
-                acc.s[23] = __builtin_fmaf(k0, o.lp1, acc.s[23]);   // = s[24]: lp lp^T is symmetric
-                acc.s[25] = __builtin_fmaf(kf * o.lp1, o.lp1, acc.s[25]);
+                acc.s[16] = __builtin_fmaf(k0, o.lp0, acc.s[16]);
+                acc.s[17] = __builtin_fmaf(k0, o.lp1, acc.s[17]);   // (the other off-diagonal entry is the same: lp lp^T is symmetric)
+                acc.s[18] = __builtin_fmaf(kf * o.lp1, o.lp1, acc.s[18]);
+            }
+        };
+        // The next chunk's loads are issued before this chunk's arithmetic (one chunk = 19 registers ahead): the loop used to
+        // load, wait, compute -- with four waves per SIMD neither the memory system nor the VALU stayed busy (both ablations
+        // near the full kernel's time, profiles/r04_ablation_table.txt).  Two chunks per turn, in two named sets of registers
+        // (round 6: handing the prefetched chunk over -- `kk = kn` -- was 19 v_mov_b32 per chunk, one instruction in twenty-seven).
+        // Closed-form mode has just read the strip front to back for J: the gradient pass walks it BACK to front, so that what
+        // it reads first is what the caches saw last (a second front-to-back walk over a strip larger than a wave's share of
+        // the caches would find none of it).
+        if constexpr (kPingPong) {
+            LightChunk ka = nch ? load_at(0) : LightChunk{}, kb2 = LightChunk{};
+            for (uint32_t gi = 0; gi < nch; gi += 2u) {
+                if (gi + 1u < nch) kb2 = load_at(gi + 1u);
+                grad_chunk(ka, gi);
+                if (gi + 1u < nch) {
+                    if (gi + 2u < nch) ka = load_at(gi + 2u);
+                    grad_chunk(kb2, gi + 1u);
+                }
+            }
+        } else {   // (the float-colour instantiations hold more per observation: the second register set would cost them a wave per SIMD)
+            LightChunk kn = nch ? load_at(0) : LightChunk{};
+            for (uint32_t gi = 0; gi < nch; ++gi) {
+                const LightChunk kk = kn;
+                if (gi + 1u < nch) kn = load_at(gi + 1u);
+                grad_chunk(kk, gi);
             }
         }
         // the pixel's tail, in the lane that owns it

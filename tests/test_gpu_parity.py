@@ -958,9 +958,9 @@ def test_float32_store_as_24_bit_offsets_changes_no_bit():
 
 def test_24_bit_offsets_exactly_when_the_ranges_fit():
     """The decision at its boundaries, through the import path (explicit ranges): views whose ranges are the bit patterns
-    lo .. lo + span.  span = 2^24 - 3: the largest that fits 24-bit codes (code 0 is the empty slot); one more: 26-bit codes
-    (round 6), up to 2^26 - 3; one more: the float32 words are kept.  Whichever it is, the fit equals the one on the float32
-    words bit for bit."""
+    lo .. lo + span.  span = 2^24 - 3: the largest that fits 24-bit codes (code 0 is the empty slot); one more: the float32
+    words are kept -- or, for a caller who asked for 'f32z26' (round 6), 26-bit codes up to 2^26 - 3.  Whichever it is, the
+    fit equals the one on the float32 words bit for bit."""
     from sucre_amd import _lib, engine
     H, W = 32, 48
     g = torch.Generator().manual_seed(5)
@@ -971,8 +971,8 @@ def test_24_bit_offsets_exactly_when_the_ranges_fit():
     rgb_t = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g)
     depth_t = torch.full((H, W), 2.0)
     target = engine.DeviceView(depth=depth_t.cuda(), rgb=rgb_t.cuda(), K=torch.eye(3), R=torch.eye(3), t=torch.zeros(3, 1))
-    for span, want in ((0xfffffd, _lib.STORE_Z24), (0xfffffe, _lib.STORE_Z26), (5, _lib.STORE_Z24), (0x3fffffd, _lib.STORE_Z26),
-                       (0x3fffffe, _lib.STORE_F32)):
+    for span, want, want26 in ((0xfffffd, _lib.STORE_Z24, _lib.STORE_Z26), (0xfffffe, _lib.STORE_F32, _lib.STORE_Z26), (5, _lib.STORE_Z24, _lib.STORE_Z26),
+                               (0x3fffffd, _lib.STORE_F32, _lib.STORE_Z26), (0x3fffffe, _lib.STORE_F32, _lib.STORE_F32)):
         lists = []
         for k in range(3):
             bits = lo + torch.randint(0, span + 1, (n,), generator=g, dtype=torch.int64)
@@ -984,42 +984,43 @@ def test_24_bit_offsets_exactly_when_the_ranges_fit():
             rgb = torch.randint(0, 256, (n, 3), dtype=torch.uint8, generator=g)
             lists.append((u1[keep], v1[keep], z[keep], rgb[keep]))
         got = {}
-        for fmt in ('f32', 'f32plain'):
+        for fmt in ('f32', 'f32z26', 'f32plain'):
             r = engine.Restoration(H, W, len(lists), obs_format=fmt)
             r.import_matches(target, lists)
             word = r.store_format().cpu().numpy().astype(np.uint32)
             assert int(word[2]) == lo and int(word[3]) == lo + span
-            assert int(word[0]) == (want if fmt == 'f32' else _lib.STORE_F32), (span, fmt, word)
+            assert int(word[0]) == {'f32': want, 'f32z26': want26, 'f32plain': _lib.STORE_F32}[fmt], (span, fmt, word)
             got[fmt] = _fit_digest(r, target, T=6)
-        assert got['f32'] == got['f32plain'], hex(span)
+        assert got['f32'] == got['f32plain'] == got['f32z26'], hex(span)
 
 
 # ---- round 6: float32 ranges kept as 26-bit offsets when they span more than 2^24 bit patterns (layout.h kStoreZ26) ------------
 
 @pytest.mark.timeout(600)
-def test_deep_scene_keeps_26_bit_codes_and_changes_no_bit():
-    """A scene whose ranges span a factor of eleven (synth.make_deep_scene: 0.7 .. 8 m, more than 2^24 float32 bit patterns) --
-    until round 5 such an image fell back to the 7-byte float32 words; now the device keeps 26-bit codes (6.25 B/observation).
-    Same trace, J and parameters bit for bit as 'f32plain' in both J modes; also with 257 views (the strip_levels /
-    tile_offset / strip_offset path of the compaction, whose strip offsets are padded to whole chunks for this format)."""
+def test_deep_scene_as_words_and_as_26_bit_codes_changes_no_bit():
+    """A scene whose ranges span a factor of eleven (synth.make_deep_scene: 0.7 .. 8 m, more than 2^24 float32 bit patterns): the
+    default store keeps the float32 words (the device's decision), 'f32z26' keeps 26-bit codes (6.25 B/observation; built in
+    round 6 and measured slower to decode than the words are to read: an opt-in).  Same trace, J and parameters bit for bit in
+    both J modes; also with 257 views (the strip_levels / tile_offset / strip_offset path of the compaction, whose strip offsets
+    are padded to whole chunks for the 26-bit format)."""
     from sucre_amd import _lib, engine, synth
     for (W, H, nn) in ((333, 207, 8), (640, 480, 8), (96, 64, 256)):
         scene = synth.make_deep_scene(W, H, nn, seed=0, device='cuda')
         views = engine.device_views_from_scene(scene, 'cuda')
         got = {}
-        for fmt in ('f32', 'f32plain'):
+        for fmt in ('f32', 'f32z26', 'f32plain'):
             r = engine.Restoration(H, W, len(views), obs_format=fmt)
             r.match(views[scene.target], views)
             word = r.store_format().cpu().numpy().astype(np.uint32)
             lo, hi = int(word[2]), int(word[3])
             assert 0xfffffd < hi - lo <= 0x3fffffd, 'the deep scene spans more than 2^24 and less than 2^26 range bit patterns'
-            assert int(word[0]) == (_lib.STORE_Z26 if fmt == 'f32' else _lib.STORE_F32) and int(word[1]) == (lo - 1 if fmt == 'f32' else 0)
+            assert int(word[0]) == (_lib.STORE_Z26 if fmt == 'f32z26' else _lib.STORE_F32) and int(word[1]) == (lo - 1 if fmt == 'f32z26' else 0)
             got[fmt] = _fit_digest(r, views[scene.target]) + [int(r.n_obs())]
             r.fit_init(views[scene.target])
             r.update_J()
             got[fmt].append(r.J().cpu().numpy().tobytes())
             del r
-        assert got['f32'] == got['f32plain'], (W, H, nn)
+        assert got['f32'] == got['f32plain'] == got['f32z26'], (W, H, nn)
 
 
 @pytest.mark.timeout(600)

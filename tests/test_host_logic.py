@@ -622,7 +622,6 @@ def test_experiment_variants_compile(tmp_path):
         'tablate1': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_PRIO=3 -DSUCRE_EXACT_J_ADAM=1',
         'tablate2': '-DSUCRE_EXP_NOLOAD -DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4 -DSUCRE_DEAL_FIT=64,44,24,14,5 -DSUCRE_DEAL_CLOSED=64,48,32,20',
         'texactdiv': '-DSUCRE_EXACT_DIV=1 -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_MATCH_COUNT_ONLY',
-        'tlight1': '-DSUCRE_EXP_LIGHT_WATER_PASS1 -DSUCRE_EXP_NOCOMPUTE',
         'tlight2': '-DSUCRE_EXP_NOLOAD',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
         'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL -DSUCRE_EXP_SHFL_SUMS',
@@ -848,7 +847,8 @@ def test_bench_finds_the_profile_of_exactly_its_own_mode(monkeypatch, tmp_path):
     modes = {'jparam': (), 'closed': ('--use-closed-form',), 'light': ('--light-model',), 'light_closed': ('--light-model', '--use-closed-form'),
              'u16mm_4k': ('--config', '5'), 'shared4': ('--shared-water', '--batch-images', '4'), 'jparam_batch32': ('--config', '1'),
              'closed_batch32': ('--config', '1', '--use-closed-form'), 'jparam_f32plain': ('--obs-format', 'f32plain'),
-             'shared64': ('--config', '4'), 'jparam_f32z26': ('--obs-format', 'f32z26'), 'jparam_deep': ('--scene', 'deep')}
+             'shared64': ('--config', '4'), 'jparam_f32z26': ('--obs-format', 'f32z26'), 'jparam_deep': ('--scene', 'deep'),
+             'jparam_deep_f32z26': ('--scene', 'deep', '--obs-format', 'f32z26')}
     for mode, argv in modes.items():
         assert tag(*argv) == mode
     # every mode tools/profile.sh knows is one bench.py can name (the in-flight variant is the default command's second profile)

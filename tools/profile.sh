@@ -22,7 +22,8 @@ mode_args() {
     closed_batch32) echo "--config 1 --use-closed-form" ;;
     jparam_f32plain) echo "--obs-format f32plain" ;;   # the float32 words themselves (7 B/obs): what an image outside every code window pays
     jparam_f32z26) echo "--obs-format f32z26" ;;       # the 26-bit range codes forced on the default scene (A/B against the 24-bit ones)
-    jparam_deep) echo "--scene deep" ;;                # ranges 0.7-8 m: the device keeps 26-bit range codes (6.25 B/obs)
+    jparam_deep) echo "--scene deep" ;;                # ranges 0.7-8 m: outside the 24-bit range codes, the store keeps the float32 words
+    jparam_deep_f32z26) echo "--scene deep --obs-format f32z26" ;;   # ... as 26-bit range codes (6.25 B/obs): slower to decode than the words are to read
     *) echo "unknown mode $1" >&2; exit 2 ;;
   esac
 }

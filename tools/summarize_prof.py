@@ -20,7 +20,7 @@ dest.mkdir(exist_ok=True)
 DOMINANT = {'jparam': 'fit_grad_kernel<true, 0>', 'jparam_inflight2': 'fit_grad_kernel<true, 0>', 'closed': 'fit_closed_kernel<true, 0, false>',
             'light': 'light_grad_kernel<false, false', 'light_closed': 'light_grad_kernel<true, false', 'u16mm_4k': 'fit_grad_kernel<true, 1>',
             'shared4': 'group_iter_kernel<0, 0>', 'jparam_batch32': 'batch_iter_kernel<0, 0>', 'closed_batch32': 'batch_iter_kernel<1, 0>',
-            'jparam_f32plain': 'fit_grad_kernel<true, 0>', 'jparam_f32z26': 'fit_grad_kernel<true, 0>', 'jparam_deep': 'fit_grad_kernel<true, 0>'}
+            'jparam_f32plain': 'fit_grad_kernel<true, 0>', 'jparam_f32z26': 'fit_grad_kernel<true, 0>', 'jparam_deep': 'fit_grad_kernel<true, 0>', 'jparam_deep_f32z26': 'fit_grad_kernel<true, 0>'}
 MATCH_STAGE = ('match_kernel', 'view_partial_kernel', 'view_total_kernel', 'pixel_count_kernel', 'bin_scan_kernel',
                'permute_kernel', 'strip_table_kernel', 'strip_levels_kernel', 'tile_offset_kernel', 'strip_offset_kernel',
                'scatter_kernel', 'tail_bits_clear_kernel', 'plan_kernel')
