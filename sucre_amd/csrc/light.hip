@@ -451,8 +451,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                         for (int c = 0; c < 3; ++c) {
                             const float a = o.l * exp2_as<kGradual>(o.z * nb[c]);
                             const float b = o.l * B[c] * (1.0f - exp2_as<kGradual>(o.z * ng[c]));
-                            const float I = kBoth ? fc.c[c][j] : kColour ? cP[c] : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u);
-                            num[c] = __builtin_fmaf(I - b, a, num[c]);
+                            // uint8 colours: I = k/255 folded into I - b (one rounding instead of two, two instructions fewer), as
+                            // fit.hip's closed_terms does; float32 colours are what they are
+                            const float y = kBoth ? fc.c[c][j] - b : kColour ? cP[c] - b
+                                                  : __builtin_fmaf((float)((kk.cc[c] >> (8 * j)) & 255u), kInv255L, -b);
+                            num[c] = __builtin_fmaf(y, a, num[c]);
                             den[c] = __builtin_fmaf(a, a, den[c]);
                         }
                     }
@@ -524,12 +527,12 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     const float a = fast_exp2(z * nb[c]), g2 = fast_exp2(z * ng[c]);
                     const float omg = 1.0f - g2;
                     const float lE = l * __builtin_fmaf(J[c], a, B[c] * omg);
-                    // J-parameter mode: I = k/255 folded into the residual (one rounding instead of two), as in
-                    // fit_grad_kernel; the ill-conditioned closed-form trajectory keeps the reference's exact I
+                    // I = k/255 folded into the residual (one rounding instead of two), as in fit_grad_kernel (round 6: in
+                    // closed-form mode too, like fit.hip's closed_terms -- held to the reference's own spread by the knee tests)
                     const uint32_t kb = (kk.cc[c] >> (8 * j)) & 255u;
                     const float r = kBoth ? fc.c[c][j] - lE
                                   : kColour ? cP[c] - lE
-                                  : kClosed ? unit_from_u8(kb) - lE : __builtin_fmaf((float)kb, kInv255L, -lE);
+                                  : __builtin_fmaf((float)kb, kInv255L, -lE);
                     const float rl = r * l;
                     const float rlz = rl * z;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
