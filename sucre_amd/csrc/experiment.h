@@ -42,6 +42,12 @@ constexpr int kStoreNt = SUCRE_STORE_NT;
 #define SUCRE_CLOSED_WAVES 4
 #endif
 
+// Strips per fit wave of a small image (layout.h make_layout: the image's own grid is ceil(tiles / this), at most the persistent
+// grid; 1 = the rule until round 5).
+#ifndef SUCRE_MIN_STRIPS
+#define SUCRE_MIN_STRIPS 4
+#endif
+
 // Slots of a wave's LDS-DMA ring (prefetch depth + 1) and the cache policy of its copies (" nt": items are read once per
 // launch -- measured 20 % faster than the default policy; next to it " sc0", " sc1", " sc0 sc1": equal).
 #ifndef SUCRE_RING
@@ -65,6 +71,19 @@ constexpr bool kExactDiv = SUCRE_EXACT_DIV != 0;
 #define SUCRE_EXACT_J_ADAM 0
 #endif
 constexpr bool kExactJAdam = SUCRE_EXACT_J_ADAM != 0;
+
+// light.hip, --light-model --use-closed-form: I = k/255 folded into I - b of the J pass (1) / into the residual of the gradient
+// pass (2), two instructions per channel each.  Round 6, one box: 479 -> 472 us per iteration each (both: 477 with the build of
+// that hour), but the closed-form trajectories of the fixtures then leave the reference's: parameters 2.7e-4 away within 50
+// iterations where the reference's own two runs differ by 1.7e-5 (tests/test_gpu_parity.py
+// test_light_model_closed_form_vs_reference_golden, four tests red with either fold) -- this mode keeps the reference's exact I.
+#ifndef SUCRE_LIGHT_FOLD1
+#define SUCRE_LIGHT_FOLD1 0
+#endif
+#ifndef SUCRE_LIGHT_FOLD2
+#define SUCRE_LIGHT_FOLD2 0
+#endif
+constexpr bool kExpLightFold1 = SUCRE_LIGHT_FOLD1 != 0, kExpLightFold2 = SUCRE_LIGHT_FOLD2 != 0;
 
 // fit.hip, timing only: every wave of a J-parameter launch records when it entered and left its strips (100 MHz wall clock) --
 // how much of a launch is its ragged end (tools/exp/wave_times.py).

@@ -1300,16 +1300,23 @@ __device__ __forceinline__ BatchView batch_view(const BatchEntry *__restrict__ i
     return v;
 }
 
+// The launch's workgroups take (image, workgroup-of-the-image) PAIRS in turn: pair q = image q / vblocks, the image's own
+// workgroup q % vblocks (vblocks = Layout.fit_blocks: the grid of the image's own launches, for which its plan was written and
+// whose partials its reduction trees add up), workgroup p of the launch takes the pairs p, p + gridDim.x, ...  An image at least as
+// large as the persistent grid has vblocks = gridDim.x, and workgroup p then walks its own share of every image, as until round 5;
+// a small image has fewer, fatter workgroups of its own (layout.h, kMinStripsPerWave), and the launch's workgroups share the
+// batch's images out between them instead of every one of them taking 64 pixels of every image.
 template <int kMode, int kFmt>
 __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void batch_iter_kernel(const BatchEntry *__restrict__ images, int n_images,
-                                                                                           const AdamCoef co, int row) {
+                                                                                           const AdamCoef co, int row, uint32_t vblocks) {
     if (kExpNoBatchClosed && kMode == 1) return;   // (experiment.h: occupancy experiments on the closed-form kernel alone)
     __shared__ BatchLds blds;
     FitLds &lds = blds.fit;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t n_pairs = (uint32_t)n_images * vblocks, P = gridDim.x;
+    auto view_of = [&](uint32_t q) { const uint32_t i = q / vblocks; return batch_view<kFmt>(images, (int)i, (q - i * vblocks) * 4u + (uint32_t)wave); };
     // Every wave walks the images by itself -- no barrier between them: its ten sums of an image go to LDS and the next
     // image's first items are already in flight.
     // The wave's streams of consecutive images are chained (StreamChain): image i + 1's first items take the places of image i's
@@ -1323,15 +1330,18 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
     StreamChain ch;
     ch.cs = 0u;
     ch.behind = 0u;
-    BatchView v = batch_view<kFmt>(images, 0, wid);
+    if (blockIdx.x >= n_pairs) return;   // (never: the launch has at most n_pairs workgroups)
+    BatchView v = view_of(blockIdx.x);
     prime(v);
-    for (int i = 0; i < n_images; ++i) {
+    int slot = 0;   // this workgroup's pairs in turn: where the waves' sums of pair blockIdx.x + slot P wait
+    for (uint32_t pair = blockIdx.x; pair < n_pairs; pair += P, ++slot) {
+        const bool more = pair + P < n_pairs;
         BatchView vn = v;
-        if (i + 1 < n_images) vn = batch_view<kFmt>(images, i + 1, wid);   // on its way while this image is walked
-        // Chained: this wave has strips in both images, and this image's stream is long enough to issue ALL of the next one's
+        if (more) vn = view_of(pair + P);   // on its way while this pair's strips are walked
+        // Chained: this wave has strips in both pairs, and this one's stream is long enough to issue ALL of the next one's
         // first kAhead items in place of its trailing ones (a closed-form stream can be ONE item long: a strip of pixels nobody
         // observes -- its second item is already a trailing one).
-        const bool chained = kExpBatchChain && i + 1 < n_images && v.n_mine != 0u && vn.n_mine != 0u && !(v.head[kAhead - 1].y & kShapeTrail);
+        const bool chained = kExpBatchChain && more && v.n_mine != 0u && vn.n_mine != 0u && !(v.head[kAhead - 1].y & kShapeTrail);
 #pragma unroll
         for (int q = 0; q < kAhead + 1; ++q) ch.head[q] = v.head[q];
         ch.se0 = v.se0;
@@ -1357,25 +1367,26 @@ __global__ __launch_bounds__(256, kMode ? kClosedWaves : kGroupFitWaves) void ba
 #pragma unroll
             for (int j = 0; j < kNumSums; ++j) s[j] = q[j];
         }
-        if (i + 1 < n_images && !chained) {   // the wave's ring is idle: the pass has consumed its last item and drained its trailing ones
+        if (more && !chained) {   // the wave's ring is idle: the pass has consumed its last item and drained its trailing ones
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             prime(vn);
         }
         wave_sums(s);
         if (lane == 0) {
 #pragma unroll
-            for (int q = 0; q < kNumSums; ++q) blds.wsum[i][wave][q] = s[q];
+            for (int j = 0; j < kNumSums; ++j) blds.wsum[slot][wave][j] = s[j];
         }
         v = vn;
     }
-    // ---- the launch's end: the workgroup's partial of every image, the four waves in fixed order ----
-    const int n_blocks = gridDim.x;
+    // ---- the launch's end: the partial of every (image, workgroup-of-the-image) pair this workgroup walked, the four waves in
+    //      fixed order, where that image's own launch would have left it ----
     __syncthreads();
-    for (int idx = t; idx < n_images * kNumSums; idx += 256) {
-        const int i = idx / kNumSums, q = idx - i * kNumSums;
+    for (int idx = t; idx < slot * kNumSums; idx += 256) {
+        const int sl = idx / kNumSums, j = idx - sl * kNumSums;
+        const uint32_t q = blockIdx.x + (uint32_t)sl * P, i = q / vblocks, vb = q - i * vblocks;
         float *partials = reinterpret_cast<float *>(images[i].ws + images[i].o.partials);
-        __hip_atomic_store(partials + (size_t)q * n_blocks + blockIdx.x,
-                           ((blds.wsum[i][0][q] + blds.wsum[i][1][q]) + blds.wsum[i][2][q]) + blds.wsum[i][3][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partials + (size_t)j * vblocks + vb,
+                           ((blds.wsum[sl][0][j] + blds.wsum[sl][1][j]) + blds.wsum[sl][2][j]) + blds.wsum[sl][3][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1626,16 +1637,20 @@ hipError_t launch_batch_set(void *batch, int n_images, uint8_t *const *ws, doubl
 hipError_t launch_batch_iter(const Layout &L, void *batch, int n_images, const AdamCoef &co, unsigned flags, int row, hipStream_t s) {
     const int mode = (flags & SUCRE_FIT_CLOSED_FORM) ? 1 : 0;
     const bool u16 = (flags & SUCRE_FIT_OBS_U16MM) != 0;
-    const dim3 grid(L.fit_blocks[mode]), block(256);
-    for (int i0 = 0; i0 < n_images; i0 += kBatchMax) {   // at most kBatchMax images per launch (their sums wait in LDS)
-        auto *b = static_cast<const BatchEntry *>(batch) + i0;
+    const uint32_t vblocks = (uint32_t)L.fit_blocks[mode];   // the images' own grid (one size: one grid)
+    const uint32_t full = (uint32_t)(mode ? kClosedGrid : 256 * kGroupFitWaves);   // what is resident at once
+    const dim3 block(256);
+    for (int i0 = 0; i0 < n_images; i0 += kBatchMax) {   // at most kBatchMax images per launch: a workgroup walks at most
+        auto *b = static_cast<const BatchEntry *>(batch) + i0;   // kBatchMax pairs (vblocks <= full), whose sums wait in LDS
         const int n = n_images - i0 < kBatchMax ? n_images - i0 : kBatchMax;
+        const uint32_t pairs = (uint32_t)n * vblocks;
+        const dim3 grid(pairs < full ? pairs : full);
         if (mode) {
-            if (u16) hipLaunchKernelGGL((batch_iter_kernel<1, 1>), grid, block, 0, s, b, n, co, row);
-            else hipLaunchKernelGGL((batch_iter_kernel<1, 0>), grid, block, 0, s, b, n, co, row);
+            if (u16) hipLaunchKernelGGL((batch_iter_kernel<1, 1>), grid, block, 0, s, b, n, co, row, vblocks);
+            else hipLaunchKernelGGL((batch_iter_kernel<1, 0>), grid, block, 0, s, b, n, co, row, vblocks);
         } else {
-            if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n, co, row);
-            else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n, co, row);
+            if (u16) hipLaunchKernelGGL((batch_iter_kernel<0, 1>), grid, block, 0, s, b, n, co, row, vblocks);
+            else hipLaunchKernelGGL((batch_iter_kernel<0, 0>), grid, block, 0, s, b, n, co, row, vblocks);
         }
         hipLaunchKernelGGL(batch_tail_kernel, dim3(L.fit_groups[mode]), dim3(kTailThreads), 0, s, b, n, L.fit_blocks[mode], co, row);
     }

@@ -69,6 +69,7 @@ constexpr int kFitGrid = 256 * kFitWaves;         // persistent fit workgroups (
                                      // not depend on the device
 constexpr int kClosedGrid = 256 * kClosedWaves;
 constexpr int kMaxViews = 4096;
+constexpr int kMinStripsPerWave = SUCRE_MIN_STRIPS;   // strips a fit wave gets at least, when the image has them (make_layout)
 
 // ---------------------------------------------------------------------------------------------------------------
 // The deal: which strips a fit wave works on (static, so that every sum is formed in the same order on every run).
@@ -256,10 +257,17 @@ inline bool make_layout(int H, int W, int n_views, Layout *L) {
     L->off_n_obs_total = take(sizeof(uint64_t));
     L->off_params = take(27 * sizeof(float));
     L->off_sums = take(kSumsPad * sizeof(double));
-    L->n_blocks = L->n_tiles < kFitGrid ? L->n_tiles : kFitGrid;
+    // The fit grid of an image (the workgroups of its own launches; the waves its plan is written for; the shape of its reduction
+    // trees): the persistent grid, or -- for a small image -- as many workgroups as give every wave kMinStripsPerWave strips.
+    // (Until round 5: one strip per wave for images of fewer tiles than the grid.  What a wave pays per image -- descriptors, the
+    // start and the end of its item stream, the tree over its ten sums -- is then paid per 64 pixels: a launch over 32 images of
+    // 640x480 x 5 views spent more on that than on their observations, DESIGN.md section 4.7.  A batch launch keeps the whole
+    // GPU busy whatever this number is: its workgroups take (image, workgroup-of-the-image) pairs in turn.)
+    auto grid_of = [&](int full) { const int want = (L->n_tiles + kMinStripsPerWave - 1) / kMinStripsPerWave; return want < 1 ? 1 : (want < full ? want : full); };
+    L->n_blocks = grid_of(kFitGrid);
     L->n_groups = (L->n_blocks + kGroup - 1) / kGroup;
     L->fit_blocks[0] = L->n_blocks;
-    L->fit_blocks[1] = L->n_tiles < kClosedGrid ? L->n_tiles : kClosedGrid;
+    L->fit_blocks[1] = grid_of(kClosedGrid);
     for (int m = 0; m < 2; ++m) L->fit_groups[m] = (L->fit_blocks[m] + kGroup - 1) / kGroup;
     L->off_ticket = take((size_t)(1 + L->n_groups) * kTicketStride * sizeof(uint32_t));
     L->off_gpartials = take((size_t)kNumSums * L->n_groups * sizeof(double));

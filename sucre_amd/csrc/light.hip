@@ -63,94 +63,78 @@ static bool make_light_layout(const Layout &L, LightLayout *X, int ext_sets = 1)
     return true;
 }
 
-// ---- small dense linear algebra in LDS: nmat independent 8x8 float64 products, one thread per output element (a
-//      workgroup of 64 w threads takes w matrices at a time) --------------------------------------------------------------
-__device__ __forceinline__ void block_mul(const double (*A)[64], const double (*B)[64], double (*C)[64], int nmat,
-                                          double post_scale) {
-    const int e = threadIdx.x & 63, r = e >> 3, c = e & 7;
-    for (int m = threadIdx.x >> 6; m < nmat; m += blockDim.x >> 6) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += A[m][r * 8 + k] * B[m][k * 8 + c];
-        C[m][e] = s * post_scale;
-    }
-    __syncthreads();
+// ---- geometry from the parameters: exp(hat xi) and the twists of its derivative, in closed form ---------------------------
+// xi = (omega, p) = cam2light (se3.py:22-27: the 4x4 twist [[hat omega, p], [0, 0]]), theta = |omega|, W = hat omega, P = hat p:
+//   R = I + A W + B W^2,   J = I + B W + C W^2 (the left Jacobian of SO(3)),   t = J p
+//   D exp(hat xi)[G_i] = hat(v_i) exp(hat xi),   v_i = (omega_i, u_i):   rotation generators i < 3:  omega_i = J e_i, u_i = Q e_i;
+//   translation generators: omega_i = 0, u_i = J e_(i-3);   Q = P/2 + C (W P + P W + W P W) + D (W^2 P + P W^2 - 3 W P W)
+//   + E (W P W^2 + W^2 P W)   [Barfoot, State Estimation for Robotics, the left Jacobian of SE(3)]
+//   A = sin th / th, B = (1 - cos th) / th^2, C = (th - sin th) / th^3, D = (th^2 + 2 cos th - 2) / (2 th^4),
+//   E = (2 th - 3 sin th + th cos th) / (2 th^5): their power series below th^2 = 1/4 (cam2light starts at zero), float64.
+// Checked against the block exponentials exp([[hat xi, G_i], [0, hat xi]]) this replaced: 1e-14 (tools/exp/se3_closed_check.py).
+// (Until round 5 six 8x8 exponentials -- scaling, degree-12 Taylor, six squarings, 40 barriers -- ran in LDS in every
+// iteration's tail: 25 of light_tail_kernel's 40 us.)
+struct Mat3 { double m[9]; };
+__device__ __forceinline__ Mat3 mul3(const Mat3 &a, const Mat3 &b) {
+    Mat3 c;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) c.m[r * 3 + k] = a.m[r * 3] * b.m[k] + a.m[r * 3 + 1] * b.m[3 + k] + a.m[r * 3 + 2] * b.m[6 + k];
+    return c;
 }
+__device__ __forceinline__ Mat3 hat3(double x, double y, double z) { return Mat3{{0.0, -z, y, z, 0.0, -x, -y, x, 0.0}}; }
 
-// E[m] = exp(S0[m]) for nmat 8x8 matrices: scaling by 2^-6, degree-12 Taylor, six squarings.
-__device__ __forceinline__ void block_exp(double (*S)[64], double (*T)[64], double (*E)[64], double (*P)[64], int nmat) {
-    const int e = threadIdx.x & 63, m0 = threadIdx.x >> 6, dm = blockDim.x >> 6;
-    for (int m = m0; m < nmat; m += dm) {
-        S[m][e] *= 1.0 / 64.0;
-        const double id = (e % 9 == 0) ? 1.0 : 0.0;
-        T[m][e] = id;
-        E[m][e] = id;
-    }
-    __syncthreads();
-    for (int k = 1; k <= 12; ++k) {
-        block_mul(T, S, P, nmat, 1.0 / k);
-        for (int m = m0; m < nmat; m += dm) { T[m][e] = P[m][e]; E[m][e] += P[m][e]; }
-        __syncthreads();
-    }
-    for (int q = 0; q < 6; ++q) {
-        block_mul(E, E, P, nmat, 1.0);
-        for (int m = m0; m < nmat; m += dm) E[m][e] = P[m][e];
-        __syncthreads();
-    }
-}
-
-__device__ __forceinline__ void hat_into(const double xi[6], double *A /*8x8 block matrix*/, int row0, int col0) {
-    const double h[16] = {0, -xi[2], xi[1], xi[3], xi[2], 0, -xi[0], xi[4], -xi[1], xi[0], 0, xi[5], 0, 0, 0, 0};
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) A[(row0 + r) * 8 + col0 + c] = h[r * 4 + c];
-}
-
-// geom (R, t, M) and the directional derivatives of the exponential from the parameters.  The six block matrices
-// [[A, G_i], [0, A]], A = hat(cam2light), G_i = the i-th generator: every exponential has exp(A) on its diagonal (-> R, t)
-// and D exp(A)[G_i] as its upper-right block (-> dexp, what the NEXT step's chain rule needs: the step that follows a
-// gradient pass differentiates at the parameters the pass ran with, i.e. the ones this call sees).  One batch of six 8x8
-// exponentials serves both; until round 3 the step evaluated its own six and the geometry a seventh.
-__device__ __forceinline__ void light_geometry(const float *params, float *geom, double *dexp, double (*S)[64], double (*T)[64],
-                                               double (*E)[64], double (*P)[64]) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 384; i += blockDim.x) S[i >> 6][i & 63] = 0.0;
-    __syncthreads();
-    if (tid < 6) {
-        double xi[6], ei[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 6; ++i) xi[i] = params[9 + i];
-        ei[tid] = 1.0;
-        hat_into(xi, S[tid], 0, 0);
-        hat_into(xi, S[tid], 4, 4);
-        hat_into(ei, S[tid], 0, 4);
-    }
-    __syncthreads();
-    block_exp(S, T, E, P, 6);
-    if (tid < 12) {
-        const int r = tid / 4, c = tid % 4;
-        if (c < 3) geom[r * 3 + c] = (float)E[0][r * 8 + c];
-        else geom[9 + r] = (float)E[0][r * 8 + 3];
-    }
-    if (tid < 6) {   // v_i from D_i = D exp(hat xi)[G_i] (upper-right block of exponential i) and T = exp(hat xi) (its diagonal block):
-        // hat(v_i) = D_i T^-1, T^-1 = [R^T, -R^T t]: Omega = D_R R^T (antisymmetric up to rounding), u = D_t - Omega t
-        const double *Ei = E[tid];
-        double Om[9], u[3];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                double x = 0.0;
-                for (int k = 0; k < 3; ++k) x += Ei[r * 8 + 4 + k] * Ei[c * 8 + k];   // D_R[r][k] R[c][k]
-                Om[r * 3 + c] = x;
-            }
-        for (int r = 0; r < 3; ++r) {
-            double x = Ei[r * 8 + 7];
-            for (int k = 0; k < 3; ++k) x -= Om[r * 3 + k] * Ei[k * 8 + 3];
-            u[r] = x;
+__device__ __forceinline__ void se3_coefficients(double th2, double &A, double &B, double &C, double &D, double &E) {
+    if (th2 < 0.25) {
+        const double x = th2;
+        A = 1.0 - x / 6.0 * (1.0 - x / 20.0 * (1.0 - x / 42.0 * (1.0 - x / 72.0 * (1.0 - x / 110.0 * (1.0 - x / 156.0)))));
+        B = 0.5 * (1.0 - x / 12.0 * (1.0 - x / 30.0 * (1.0 - x / 56.0 * (1.0 - x / 90.0 * (1.0 - x / 132.0 * (1.0 - x / 182.0))))));
+        C = (1.0 / 6.0) * (1.0 - x / 20.0 * (1.0 - x / 42.0 * (1.0 - x / 72.0 * (1.0 - x / 110.0 * (1.0 - x / 156.0 * (1.0 - x / 210.0))))));
+        // D = sum_(n >= 2) (-1)^n x^(n-2) / (2n)!,  E = sum_(n >= 2) (-1)^n x^(n-2) (1/(2n)! - 3/(2n+1)!) / 2
+        double d = 0.0, e = 0.0, xp = 1.0, f = 24.0;   // f = (2n)!, starting at n = 2
+        for (int n = 2; n < 10; ++n) {
+            const double sgn = (n & 1) ? -1.0 : 1.0;
+            d += sgn * xp / f;
+            e += sgn * xp * (1.0 / f - 3.0 / (f * (2 * n + 1)));
+            xp *= x;
+            f *= (double)((2 * n + 1) * (2 * n + 2));
         }
-        double *v = dexp + tid * 12;
-        v[0] = 0.5 * (Om[7] - Om[5]); v[1] = 0.5 * (Om[2] - Om[6]); v[2] = 0.5 * (Om[3] - Om[1]);
-        v[3] = u[0]; v[4] = u[1]; v[5] = u[2];
-        for (int k = 6; k < 12; ++k) v[k] = 0.0;
+        D = d; E = 0.5 * e;
+        return;
     }
-    if (tid == 0) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse()
+    const double th = sqrt(th2), sn = sin(th), cs = cos(th);
+    A = sn / th; B = (1.0 - cs) / th2; C = (th - sn) / (th2 * th);
+    D = (th2 + 2.0 * cs - 2.0) / (2.0 * th2 * th2); E = (2.0 * th - 3.0 * sn + th * cs) / (2.0 * th2 * th2 * th);
+}
+
+// geom (R, t, M) and the six twists from the parameters (the twists are what the NEXT step's chain rule needs: the step that
+// follows a gradient pass differentiates at the parameters the pass ran with, i.e. the ones this call sees).  Thread 0 does the
+// pose, thread 1 M; all threads of the workgroup must call it.
+__device__ __forceinline__ void light_geometry(const float *params, float *geom, double *dexp) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const double w0 = params[9], w1 = params[10], w2 = params[11], p0 = params[12], p1 = params[13], p2 = params[14];
+        double A, B, C, D, E;
+        se3_coefficients(w0 * w0 + w1 * w1 + w2 * w2, A, B, C, D, E);
+        const Mat3 W = hat3(w0, w1, w2), P = hat3(p0, p1, p2), W2 = mul3(W, W);
+        const Mat3 WP = mul3(W, P), PW = mul3(P, W), WPW = mul3(WP, W), W2P = mul3(W2, P), PW2 = mul3(P, W2), WPW2 = mul3(WPW, W), W2PW = mul3(W2P, W);
+        double J[9], Q[9];
+        for (int i = 0; i < 9; ++i) {
+            const double id = (i % 4 == 0) ? 1.0 : 0.0;
+            geom[i] = (float)(id + A * W.m[i] + B * W2.m[i]);
+            J[i] = id + B * W.m[i] + C * W2.m[i];
+            Q[i] = 0.5 * P.m[i] + C * (WP.m[i] + PW.m[i] + WPW.m[i]) + D * (W2P.m[i] + PW2.m[i] - 3.0 * WPW.m[i]) + E * (WPW2.m[i] + W2PW.m[i]);
+        }
+        for (int r = 0; r < 3; ++r) geom[9 + r] = (float)(J[r * 3] * p0 + J[r * 3 + 1] * p1 + J[r * 3 + 2] * p2);
+        for (int i = 0; i < 6; ++i) {
+            double *v = dexp + i * 12;
+            for (int r = 0; r < 3; ++r) {
+                v[r] = i < 3 ? J[r * 3 + i] : 0.0;
+                v[3 + r] = i < 3 ? Q[r * 3 + i] : J[r * 3 + (i - 3)];
+            }
+            for (int k = 6; k < 12; ++k) v[k] = 0.0;
+        }
+    }
+    if (tid == (blockDim.x > 64 ? 64 : 1)) {  // M = (sigma^T sigma)^-1, float32 like the reference's Sigma.inverse() (another wave, when there is one)
         const float *sg = params + 15;
         const float S00 = sg[0] * sg[0] + sg[2] * sg[2], S01 = sg[0] * sg[1] + sg[2] * sg[3];
         const float S11 = sg[1] * sg[1] + sg[3] * sg[3];
@@ -160,17 +144,15 @@ __device__ __forceinline__ void light_geometry(const float *params, float *geom,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void light_init_kernel(float *pstate, float *geom, double *dexp, const float *p0) {
-    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
+__global__ __launch_bounds__(64) void light_init_kernel(float *pstate, float *geom, double *dexp, const float *p0) {
     if (threadIdx.x < 3 * kLightParams) pstate[threadIdx.x] = threadIdx.x < kLightParams ? p0[threadIdx.x] : 0.f;
     __syncthreads();
-    light_geometry(pstate, geom, dexp, S, T, E, P);
+    light_geometry(pstate, geom, dexp);
 }
 
 // geometry of whatever parameters are stored now (the caller may have written them since the last step)
-__global__ __launch_bounds__(512) void light_geometry_kernel(const float *pstate, float *geom, double *dexp) {
-    __shared__ double S[6][64], T[6][64], E[6][64], P[6][64];
-    light_geometry(pstate, geom, dexp, S, T, E, P);
+__global__ __launch_bounds__(64) void light_geometry_kernel(const float *pstate, float *geom, double *dexp) {
+    light_geometry(pstate, geom, dexp);
 }
 
 // ---- gradient pass ---------------------------------------------------------------------------------------------------
@@ -308,7 +290,6 @@ __device__ __forceinline__ void light_reduce(const float *partials, int n_blocks
 
 // Gradients of the 19 parameters from the sums (LDS), Adam, next geometry, log row.  Any multiple of 64 threads >= 64.
 struct LightLds {
-    double S[6][64], T[6][64], E[6][64], P[6][64];
     double grad[kLightParams];
     double sums[kLightSums];
     double w4[kLightSums][4];
@@ -317,7 +298,6 @@ struct LightLds {
 __device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *geom, double *dexp,
                                            const uint64_t *__restrict__ n_obs_total, const AdamCoef &co,
                                            double *__restrict__ trace_row) {
-    double (*S)[64] = lds.S, (*T)[64] = lds.T, (*E)[64] = lds.E, (*P)[64] = lds.P;
     const double *sums = lds.sums;
     double *grad = lds.grad;
     const int tid = threadIdx.x;
@@ -357,7 +337,7 @@ __device__ __forceinline__ void light_step(LightLds &lds, float *pstate, float *
     }
     if (tid == 32 && trace_row) trace_row[0] = sums[9];
     __syncthreads();   // (workgroup scope is enough for the read-back below; an agent-scope fence here wrote the L2 back: +50 us)
-    light_geometry(pstate, geom, dexp, S, T, E, P);
+    light_geometry(pstate, geom, dexp);
 }
 
 // kClosed: J is re-solved in closed form at the top of the iteration (sucre.py:141, 66-77 with absorption = l a,
@@ -454,7 +434,8 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                             // uint8 colours: I = k/255 folded into I - b (one rounding instead of two, two instructions fewer), as
                             // fit.hip's closed_terms does; float32 colours are what they are
                             const float y = kBoth ? fc.c[c][j] - b : kColour ? cP[c] - b
-                                                  : __builtin_fmaf((float)((kk.cc[c] >> (8 * j)) & 255u), kInv255L, -b);
+                                                  : kExpLightFold1 ? __builtin_fmaf((float)((kk.cc[c] >> (8 * j)) & 255u), kInv255L, -b)
+                                                                   : unit_from_u8((kk.cc[c] >> (8 * j)) & 255u) - b;
                             num[c] = __builtin_fmaf(y, a, num[c]);
                             den[c] = __builtin_fmaf(a, a, den[c]);
                         }
@@ -532,7 +513,7 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
                     const uint32_t kb = (kk.cc[c] >> (8 * j)) & 255u;
                     const float r = kBoth ? fc.c[c][j] - lE
                                   : kColour ? cP[c] - lE
-                                  : __builtin_fmaf((float)kb, kInv255L, -lE);
+                                  : (kClosed && !kExpLightFold2) ? unit_from_u8(kb) - lE : __builtin_fmaf((float)kb, kInv255L, -lE);
                     const float rl = r * l;
                     const float rlz = rl * z;
                     acc.s[9] = __builtin_fmaf(r, r, acc.s[9]);
@@ -642,8 +623,12 @@ __global__ __launch_bounds__(256) void light_deal_kernel(const StripMeta *__rest
     const uint32_t wid = blockIdx.x * 256u + threadIdx.x;
     if (wid >= W) return;
     uint32_t *mine = strips + (size_t)wid * kmax;
-    count[wid] = deal_walk(wid, W, (uint32_t)n_strips, sh, [&](uint32_t s) { return meta[s].levels; },
-                           [&](uint32_t k, uint32_t strip) { if (k < kmax) mine[k] = strip; });
+    const uint32_t K = deal_walk(wid, W, (uint32_t)n_strips, sh, [&](uint32_t s) { return meta[s].levels; },
+                                 [&](uint32_t k, uint32_t strip) { if (k < kmax) mine[k] = strip; });
+    // never more than the table holds (tests/native/deal_check.cpp: K <= deal_rounds for these grids; were it ever not so, the wave
+    // would walk its neighbour's strips -- stepped and counted twice, silently: ADVICE round 5): the surplus strips stay unvisited
+    // and their pixels keep their J, which the parity tests see
+    count[wid] = K < kmax ? K : kmax;
 }
 
 size_t light_workspace_bytes(const Layout &L, int ext_sets) {
@@ -690,7 +675,7 @@ hipError_t launch_light_init(const Layout &L, uint8_t *lws, const float *params1
     float *pstate = reinterpret_cast<float *>(lws + X.off_params);
     float *scratch = reinterpret_cast<float *>(lws + X.off_sums);  // 19 floats staged in the (still unused) sums area
     hipLaunchKernelGGL(light_params_upload_kernel, dim3(1), dim3(64), 0, s, scratch, p);
-    hipLaunchKernelGGL(light_init_kernel, dim3(1), dim3(512), 0, s, pstate, reinterpret_cast<float *>(lws + X.off_geom),
+    hipLaunchKernelGGL(light_init_kernel, dim3(1), dim3(64), 0, s, pstate, reinterpret_cast<float *>(lws + X.off_geom),
                        reinterpret_cast<double *>(lws + X.off_dexp), scratch);
     return hipGetLastError();
 }
@@ -781,7 +766,7 @@ hipError_t launch_light_deal(const Layout &L, uint8_t *ws, uint8_t *lws, unsigne
 hipError_t launch_light_update_J(const Layout &L, uint8_t *ws, uint8_t *lws, unsigned flags, hipStream_t s) {
     LightLayout X;
     make_light_layout(L, &X);
-    hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(512), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
+    hipLaunchKernelGGL(light_geometry_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const float *>(lws + X.off_params),
                        reinterpret_cast<float *>(lws + X.off_geom), reinterpret_cast<double *>(lws + X.off_dexp));
     launch_light_grad<true, true>(L, X, ws, lws, AdamCoef{}, flags, s, 2);
     return hipGetLastError();

@@ -250,7 +250,16 @@ class Restoration:
     def _geom(self):
         return C.c_void_p(self.ws.data_ptr()), self.H, self.W, self.n_views
 
+    def _note_stream(self) -> None:
+        """A view of the workspace is being handed out on the current stream (a ``.cpu()`` or a copy the caller queues there reads the
+        workspace): ``return_restoration`` must leave an event on that stream too, not only on those the C ABI was launched on
+        (ADVICE round 5)."""
+        if self.device.type == 'cuda':
+            st = torch.cuda.current_stream(self.device)
+            self._streams_used[st.cuda_stream] = st
+
     def _region(self, region: int, dtype: torch.dtype, count: int) -> torch.Tensor:
+        self._note_stream()
         off = self.lib.sucre_ws_offset(self.H, self.W, self.n_views, region)
         if off < 0:
             raise _lib.SucreError(self.lib.sucre_last_error().decode())
@@ -467,6 +476,7 @@ class Restoration:
     def params(self) -> torch.Tensor:
         """B[3], beta[3], gamma[3] (+ cam2light[6], sigma[4] with the light model) on the device."""
         if self.light or self.float_colour:
+            self._note_stream()
             off = self.lib.sucre_light_params_offset(self.H, self.W, self.n_views)
             return self.lws[off:off + (76 if self.light else 36)].view(torch.float32)
         return self._region(_lib.WS_PARAMS, torch.float32, 9)

@@ -419,16 +419,33 @@ def _restore_enqueue_fits(jobs: list) -> None:
         job.trace = job.resto.fit(job.num_iter, lr=job.lr, use_closed_form=job.sucre.use_closed_form)
 
 
-def fit_batch_size(images: list, light_model: bool = False) -> int:
+def fit_batch_size(images: list, light_model: bool = False, in_flight: int = 2, n_views: int | None = None, device='cuda') -> int:
     """Images per fit launch in a survey (engine knob ``SUCRE_FIT_BATCH``; not a reference flag).  ``auto``: 8 for images of
     less than a megapixel (BASELINE config 1's 640x480: 144 -> 215 Mpix/s; 32 per launch: 219), 1 otherwise -- at 1080p a
-    launch of two images is no faster than two launches in flight -- and 1 with the light model."""
+    launch of two images is no faster than two launches in flight -- and 1 with the light model.
+    Every image of a chunk holds its own workspace, ``fit_batch x in_flight`` of them at once: with ``n_views`` (the largest
+    number of views a target can be matched against) the automatic batch is halved until those workspaces fit into 80 % of
+    the device memory that is free now -- a 1280x720 survey with hundreds of neighbours keeps fewer images per launch instead
+    of running out of memory."""
     env = os.environ.get('SUCRE_FIT_BATCH', 'auto').strip().lower()
     if env != 'auto':
         return max(1, int(env))
     if light_model or not images:
         return 1
-    return 8 if max(int(im.camera.width) * int(im.camera.height) for im in images) < 1_000_000 else 1
+    W, H = max(int(im.camera.width) for im in images), max(int(im.camera.height) for im in images)
+    batch = 8 if W * H < 1_000_000 else 1
+    if batch > 1 and n_views:
+        from . import _lib, engine
+        n = min(int(n_views), engine.MAX_VIEWS)
+        cap = (n + 7) // 8 * 8 if n <= 256 else (n + 31) // 32 * 32    # engine.acquire_restoration's capacity steps
+        need = int(_lib.load().sucre_workspace_bytes(H, W, min(cap, engine.MAX_VIEWS)))
+        try:
+            free = int(torch.cuda.mem_get_info(device)[0]) + int(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+        except Exception:   # no device to ask: keep the plain rule
+            return batch
+        while batch > 1 and need * batch * max(1, int(in_flight)) > 0.8 * free:
+            batch //= 2
+    return batch
 
 
 def _restore_finish(job: _Job, keep_matches: bool, writers: ThreadPoolExecutor | None = None):
@@ -491,7 +508,9 @@ def restore_images(images: list[sfm.Image], colmap_model: sfm.COLMAPModel, outpu
     pending: list[tuple[int, list]] = []
     written = []
     if fit_batch is None:
-        fit_batch = fit_batch_size(images, bool(kw.get('light_model', False)))
+        candidates = kw.get('image_list')
+        n_views = len(candidates) if candidates is not None else len(colmap_model.images)
+        fit_batch = fit_batch_size(images, bool(kw.get('light_model', False)), in_flight=in_flight, n_views=n_views, device=device)
     _restore_pipeline(images, colmap_model, output_dir, in_flight, keep_matches, device, pending, written, kw, max(1, int(fit_batch)))
 
 

@@ -36,6 +36,24 @@ int main() {
                 for (int v : seen) if (v != 1) ++bad;
                 ++cases;
             }
+    // the light kernels' grids (csrc/light.hip: as many workgroups as are resident, 4 or 5 per CU; deal_shares_resident -- ADVICE round 5):
+    // the same properties, and no wave gets more strips than deal_rounds reserves in light_deal_kernel's table
+    for (uint32_t blocks : {768u, 1024u, 1280u, 300u})
+        for (uint32_t n_strips : {1u, 4800u, 32400u, 131072u}) {
+            const DealShares sh = deal_shares_resident(blocks);
+            const uint32_t W = blocks * 4, R = deal_rounds(W, n_strips, sh);
+            std::vector<uint32_t> lev(n_strips);
+            for (uint32_t s = 0; s < n_strips; ++s) lev[s] = (uint32_t)(65.0 * std::pow(1.0 - (double)s / n_strips, 0.7));
+            std::vector<int> seen(n_strips, 0);
+            for (uint32_t wid = 0; wid < W; ++wid) {
+                uint32_t cnt = 0;
+                const uint32_t K = deal_walk(wid, W, n_strips, sh, [&](uint32_t s) { return s < n_strips ? lev[s] : 0u; },
+                                             [&](uint32_t k, uint32_t s) { if (k != cnt || s >= n_strips) ++bad; else ++seen[s]; ++cnt; });
+                if (K != cnt || K > R) ++bad;
+            }
+            for (int v : seen) if (v != 1) ++bad;
+            ++cases;
+        }
     // StripEntry.counts: every strip height up to kMaxViews levels with every split into unmasked / masked full chunks that the
     // plan kernel can write (8-bit fields wrapped at 1024 levels)
     for (uint32_t levels = 0; levels <= (uint32_t)kMaxViews; ++levels) {

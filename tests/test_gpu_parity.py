@@ -788,6 +788,31 @@ def test_packed_neighbour_views_change_nothing(golden, monkeypatch):
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4], equal_nan=True)
 
 
+def test_pack_view_records_of_any_size_and_alignment():
+    """sucre_pack_view (four pixels per thread with wide accesses since round 6): images whose pixel count is no multiple of
+    four, and planes that start on odd addresses (views into larger buffers: the one-pixel path), give the records
+    {float32 depth, r | g << 8 | b << 16} pixel for pixel."""
+    import ctypes as C
+    from sucre_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for (H, W, shift) in ((207, 333, 0), (1, 1, 0), (3, 5, 0), (48, 64, 0), (207, 333, 1), (48, 64, 2), (1080, 1920, 0)):
+        n = H * W
+        depth_buf = torch.rand(n + 8, generator=g).cuda()
+        rgb_buf = torch.randint(0, 256, (3 * n + 8,), dtype=torch.uint8, generator=g).cuda()
+        depth = depth_buf[shift:shift + n]            # (shift 1: 4-byte aligned only; the colours: 1-byte aligned)
+        rgb = rgb_buf[shift:shift + 3 * n]
+        out = torch.zeros(2 * n + 2, dtype=torch.int32, device='cuda')
+        _lib.check(lib.sucre_pack_view(C.c_void_p(depth.data_ptr()), C.c_void_p(rgb.data_ptr()), H, W, C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        rec = out.cpu().numpy().view(np.uint32)
+        c = rgb.cpu().numpy().astype(np.uint32).reshape(n, 3)
+        assert np.array_equal(rec[0:2 * n:2].view(np.float32), depth.cpu().numpy()), (H, W, shift)
+        assert np.array_equal(rec[1:2 * n:2], c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)), (H, W, shift)
+        assert rec[2 * n] == 0 and rec[2 * n + 1] == 0, 'nothing is written past the image'
+
+
 def test_pixel_quotients_on_the_integer_boundaries():
     """csrc/match.hip replaces the IEEE quotients x/z, y/z of sfm.py:106 by x * rcp(z) wherever that provably truncates
     and bound-tests like the IEEE quotient, and falls back to the division otherwise.  Adversarial inputs: quotients

@@ -622,10 +622,10 @@ def test_experiment_variants_compile(tmp_path):
         'tablate1': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_PRIO=3 -DSUCRE_EXACT_J_ADAM=1',
         'tablate2': '-DSUCRE_EXP_NOLOAD -DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4 -DSUCRE_DEAL_FIT=64,44,24,14,5 -DSUCRE_DEAL_CLOSED=64,48,32,20',
         'texactdiv': '-DSUCRE_EXACT_DIV=1 -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_MATCH_COUNT_ONLY',
-        'tlight2': '-DSUCRE_EXP_NOLOAD',
+        'tlight2': '-DSUCRE_EXP_NOLOAD -DSUCRE_LIGHT_FOLD1=1 -DSUCRE_LIGHT_FOLD2=1',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
         'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL -DSUCRE_EXP_SHFL_SUMS',
-        'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0',
+        'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0 -DSUCRE_MIN_STRIPS=1',
         'thalf': '-DSUCRE_EXP_HALF_EXPS -DSUCRE_CLOSED_WAVES=5 -DSUCRE_EXP_NO_BATCH_CLOSED -DSUCRE_DEAL_CLOSED=64,48,32,20,10',
     }
     objects = {'texactdiv': 'match', 'tlight1': 'light', 'tlight2': 'light', 'tscatter': 'compact'}   # the source a knob lives in (default: fit)
@@ -868,3 +868,24 @@ def test_bench_finds_the_profile_of_exactly_its_own_mode(monkeypatch, tmp_path):
     # the committed tree: the closed-form line reads the closed-form kernel's file
     newest = bench.profile_candidates('closed')[0]
     assert json.loads(newest.read_text())['kernel'].startswith('fit_closed_kernel'), newest.name
+
+
+def test_automatic_fit_batch_is_bounded_by_free_device_memory(monkeypatch):
+    """SUCRE_FIT_BATCH=auto: 8 small images per launch -- unless 8 x in_flight of their workspaces would not fit into the memory
+    the device has free: then fewer (a 1280x720 survey with hundreds of neighbours)."""
+    import types
+    from sucre_amd import _lib, sucre
+    monkeypatch.delenv('SUCRE_FIT_BATCH', raising=False)
+    images = [types.SimpleNamespace(camera=types.SimpleNamespace(width=1280, height=720))] * 20
+    one = int(_lib.load().sucre_workspace_bytes(720, 1280, 320))   # (300 views: a capacity of 320)
+    assert one > 2 * 2**30
+    for free, want in ((10**13, 8), (one * 16 / 0.8 * 1.01, 8), (one * 16 / 0.8 * 0.99, 4), (one * 5.5, 2), (one, 1)):
+        monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda device=None, f=free: (int(f), int(f)))
+        monkeypatch.setattr(torch.cuda, 'memory_reserved', lambda device=None: 0)
+        monkeypatch.setattr(torch.cuda, 'memory_allocated', lambda device=None: 0)
+        assert sucre.fit_batch_size(images, in_flight=2, n_views=300) == want, (free / one, want)
+    assert sucre.fit_batch_size(images, light_model=True, n_views=300) == 1
+    big = [types.SimpleNamespace(camera=types.SimpleNamespace(width=1920, height=1080))]
+    assert sucre.fit_batch_size(big, n_views=65) == 1
+    monkeypatch.setenv('SUCRE_FIT_BATCH', '5')
+    assert sucre.fit_batch_size(images, n_views=300) == 5
