@@ -627,7 +627,10 @@ def test_six_hundred_views_of_a_small_image():
         assert np.array_equal(np.isnan(J), np.isnan(Jo))
         assert helpers.rms_per_channel(J, Jo).max() < (1e-4 if closed else 1e-5)
         assert np.abs(tr[:, 1:] - to[:, 1:]).max() < (2e-4 if closed else 1e-5)
-        assert abs(tr[0, 0] / to[0, 0] - 1) < 1e-6                                         # no step behind the first cost
+        # no step behind the first cost: what differs is the order of 1.7 M float32 additions.  (2e-6 since round 6, when a
+        # wave of a small image got four strips instead of one -- a lane adds up four times as many squares before the trees
+        # take over: 1.14e-6 here; the config-2 cost stays 4e-6 from the reference's over all 200 rows.)
+        assert abs(tr[0, 0] / to[0, 0] - 1) < 2e-6
         assert np.abs(tr[:, 0] / to[:, 0] - 1).max() < (1e-4 if closed else 1e-5)          # closed form amplifies
 
 
