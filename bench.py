@@ -345,8 +345,7 @@ def main():
 
     def pack_views(vs):
         if pack[0]:
-            for v in vs:
-                v.repack()
+            engine.repack_views(vs)
 
     def pack_survey():
         """One pass of sucre_pack_view over every view of the survey, fenced against all slots (they read the records)."""
@@ -355,8 +354,7 @@ def main():
         cur = torch.cuda.current_stream(device)
         for st in streams:
             cur.wait_stream(st)
-        for v in all_views:
-            v.repack()
+        engine.repack_views(all_views)
         for st in streams:
             st.wait_stream(cur)
 

@@ -154,6 +154,13 @@ int sucre_match_map(int H, int W, int n_views, const sucre_view_t *target, const
  * colour image are read as such: sfm.py:129, sucre.py:47).  Not for float32 colour images (SUCRE_EXT_COLOUR modes).
  */
 int sucre_pack_view(const float *depth_dev, const uint8_t *rgb_dev, int H, int W, void *packed_dev, void *stream);
+/*
+ * The same for n views of one size in as few launches as possible (sixteen views per launch): depth_dev[k], rgb_dev[k],
+ * packed_dev[k] are HOST arrays of device pointers.  A target's image_list (sfm.py:127-138) is packed with five launches
+ * instead of 65.
+ */
+int sucre_pack_views(const float *const *depth_dev, const uint8_t *const *rgb_dev, void *const *packed_dev, int n, int H, int W,
+                     void *stream);
 
 /*
  * Image.project_to_view + the truncation and bound test of Image.match_one_way (sfm.py:103-107, 115-117) for an

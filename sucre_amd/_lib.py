@@ -49,6 +49,7 @@ SIGNATURES = {
     'sucre_match_views': (_i, [_vp, _i, _i, _i, C.POINTER(SucreView), _vp, _i, _i, _vp]),
     'sucre_match_map': (_i, [_i, _i, _i, C.POINTER(SucreView), _vp, _i, _vp, _vp]),
     'sucre_pack_view': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'sucre_pack_views': (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _vp]),
     'sucre_project_points': (_i, [C.POINTER(SucreView), _vp, C.c_int64, _vp, _vp]),
     'sucre_import_view': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     'sucre_finalize_matches': (_i, [_vp, _i, _i, _i, _d, _vp]),

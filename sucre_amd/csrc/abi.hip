@@ -122,6 +122,19 @@ int sucre_pack_view(const float *depth_dev, const uint8_t *rgb_dev, int H, int W
     return check_hip(launch_pack_view(depth_dev, rgb_dev, H, W, packed_dev, static_cast<hipStream_t>(stream)), "sucre_pack_view");
 }
 
+int sucre_pack_views(const float *const *depth_dev, const uint8_t *const *rgb_dev, void *const *packed_dev, int n, int H, int W,
+                     void *stream) {
+    if (H <= 0 || W <= 0 || H > 32767 || W > 32767) return fail(SUCRE_ERR_ARG, "invalid image size %dx%d", W, H);
+    if (n < 0) return fail(SUCRE_ERR_RANGE, "negative view count %d", n);
+    if (n == 0) return SUCRE_OK;
+    if (!depth_dev || !rgb_dev || !packed_dev) return fail(SUCRE_ERR_ARG, "depth_dev / rgb_dev / packed_dev is NULL");
+    for (int k = 0; k < n; ++k) {
+        if (!depth_dev[k] || !rgb_dev[k] || !packed_dev[k]) return fail(SUCRE_ERR_ARG, "view %d: depth / rgb / packed pointer is NULL", k);
+        if (!aligned(packed_dev[k], 8)) return fail(SUCRE_ERR_ARG, "view %d: packed_dev must be 8-byte aligned", k);
+    }
+    return check_hip(launch_pack_views(depth_dev, rgb_dev, packed_dev, n, H, W, static_cast<hipStream_t>(stream)), "sucre_pack_views");
+}
+
 int sucre_project_points(const sucre_view_t *view, const float *wP_dev, int64_t n, int32_t *pix_dev, void *stream) {
     if (!view) return fail(SUCRE_ERR_ARG, "view is NULL");
     if (view->H <= 0 || view->W <= 0 || view->H > 32767 || view->W > 32767)

@@ -32,6 +32,7 @@ hipError_t launch_match(const Layout &L, uint8_t *ws, const sucre_view_t &target
 hipError_t launch_match_map(const Layout &L, const sucre_view_t &target, const sucre_view_t *views_dev, int k,
                             int32_t *map, hipStream_t s);
 hipError_t launch_pack_view(const float *depth, const uint8_t *rgb, int H, int W, void *packed, hipStream_t s);
+hipError_t launch_pack_views(const float *const *depth, const uint8_t *const *rgb, void *const *packed, int n, int H, int W, hipStream_t s);
 hipError_t launch_project_points(const sucre_view_t &view, const float *wP, long long n, int32_t *pix, hipStream_t s);
 hipError_t launch_import_view(const Layout &L, uint8_t *ws, int k, const int16_t *u1, const int16_t *v1, const float *z,
                               const uint8_t *rgb, long long n, hipStream_t s, uint8_t *ext_dense = nullptr,

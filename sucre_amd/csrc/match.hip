@@ -655,6 +655,47 @@ __global__ __launch_bounds__(256) void pack_view_kernel(const float *__restrict_
     }
 }
 
+// Sixteen views of one size per launch (blockIdx.y = the view): a target's 65 views in five launches.
+constexpr int kPackBatch = 16;
+struct PackBatch { const float *depth[kPackBatch]; const uint8_t *rgb[kPackBatch]; uint2 *out[kPackBatch]; };
+
+__global__ __launch_bounds__(256) void pack_views_kernel(const PackBatch b, long long n) {
+    const float *__restrict__ depth = b.depth[blockIdx.y];
+    const uint8_t *__restrict__ rgb = b.rgb[blockIdx.y];
+    uint2 *__restrict__ out = b.out[blockIdx.y];
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x, i = q * 4;
+    if (i >= n) return;
+    // (the wide accesses need the planes aligned: kernel-uniform per view)
+    const bool al = reinterpret_cast<uintptr_t>(depth) % 16 == 0 && reinterpret_cast<uintptr_t>(rgb) % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    if (al && i + 4 <= n) {
+        const float4 d = *reinterpret_cast<const float4 *>(depth + i);
+        const uint32_t *c = reinterpret_cast<const uint32_t *>(rgb + i * 3);
+        const uint32_t c0 = c[0], c1 = c[1], c2 = c[2];
+        uint4 *o = reinterpret_cast<uint4 *>(out + i);
+        o[0] = make_uint4(__float_as_uint(d.x), c0 & 0xffffffu, __float_as_uint(d.y), (c0 >> 24) | ((c1 & 0xffffu) << 8));
+        o[1] = make_uint4(__float_as_uint(d.z), (c1 >> 16) | ((c2 & 0xffu) << 16), __float_as_uint(d.w), c2 >> 8);
+        return;
+    }
+    for (long long j = i; j < n && j < i + 4; ++j) {
+        const uint8_t *p = rgb + j * 3;
+        out[j] = make_uint2(__float_as_uint(depth[j]), (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16));
+    }
+}
+
+hipError_t launch_pack_views(const float *const *depth, const uint8_t *const *rgb, void *const *packed, int n, int H, int W, hipStream_t s) {
+    const long long px = (long long)H * W, threads = (px + 3) / 4;
+    for (int k0 = 0; k0 < n; k0 += kPackBatch) {
+        PackBatch b;
+        const int m = n - k0 < kPackBatch ? n - k0 : kPackBatch;
+        for (int j = 0; j < kPackBatch; ++j) {
+            const int k = k0 + (j < m ? j : 0);
+            b.depth[j] = depth[k]; b.rgb[j] = rgb[k]; b.out[j] = static_cast<uint2 *>(packed[k]);
+        }
+        hipLaunchKernelGGL(pack_views_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)m), dim3(256), 0, s, b, px);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_view(const float *depth, const uint8_t *rgb, int H, int W, void *packed, hipStream_t s) {
     const long long n = (long long)H * W, threads = (n + 3) / 4;
     const bool aligned = reinterpret_cast<uintptr_t>(depth) % 16 == 0 && reinterpret_cast<uintptr_t>(rgb) % 4 == 0 && reinterpret_cast<uintptr_t>(packed) % 16 == 0;

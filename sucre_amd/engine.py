@@ -127,6 +127,28 @@ class DeviceView:
         return camera_struct(self.K, self.R, self.t, H, W, self.depth.data_ptr(), self.rgb.data_ptr(), Kinv=self.Kinv, tinv=self.tinv)
 
 
+def repack_views(views: list) -> None:
+    """``DeviceView.repack`` for views of one size, sixteen views per launch (``sucre_pack_views``): records rebuilt in place on the
+    CURRENT stream."""
+    views = [v for v in views if v.rgb.dtype == torch.uint8]
+    if not views:
+        return
+    H, W = views[0].depth.shape
+    if any(tuple(v.depth.shape) != (H, W) for v in views):   # mixed sizes: one by one
+        for v in views:
+            v.repack()
+        return
+    recs = [v.packed_records() for v in views]
+    for v in views:
+        v.wait_packed()
+    n = len(views)
+    dp = (C.c_void_p * n)(*[v.depth.data_ptr() for v in views])
+    cp = (C.c_void_p * n)(*[v.rgb.data_ptr() for v in views])
+    op = (C.c_void_p * n)(*[r.data_ptr() for r in recs])
+    with torch.cuda.device(views[0].depth.device):
+        _lib.check(_lib.load().sucre_pack_views(dp, cp, op, n, H, W, _stream_ptr()))
+
+
 def camera_struct(K: torch.Tensor, R: torch.Tensor, t: torch.Tensor, H: int, W: int, depth_ptr: int = 0,
                   rgb_ptr: int = 0, Kinv: torch.Tensor | None = None, tinv: torch.Tensor | None = None) -> _lib.SucreView:
     """sucre_view_t from a camera matrix and a world-from-camera pose, the derived matrices computed on the host the way

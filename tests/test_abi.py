@@ -84,6 +84,12 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.sucre_pack_view(ws, ws, 0, 64, ws, None) == -1 and b'image size' in lib.sucre_last_error()
     assert lib.sucre_pack_view(ws, None, 48, 64, ws, None) == -1 and b'NULL' in lib.sucre_last_error()
     assert lib.sucre_pack_view(ws, ws, 48, 64, C.c_void_p(260), None) == -1 and b'8-byte aligned' in lib.sucre_last_error()
+    three = (C.c_void_p * 3)(256, 512, 768)
+    assert lib.sucre_pack_views(three, three, three, 0, 48, 64, None) == 0            # nothing to do
+    assert lib.sucre_pack_views(three, three, three, -1, 48, 64, None) == -2
+    assert lib.sucre_pack_views(three, None, three, 3, 48, 64, None) == -1 and b'NULL' in lib.sucre_last_error()
+    assert lib.sucre_pack_views(three, three, (C.c_void_p * 3)(256, 0, 768), 3, 48, 64, None) == -1 and b'view 1' in lib.sucre_last_error()
+    assert lib.sucre_pack_views(three, three, (C.c_void_p * 3)(256, 512, 772), 3, 48, 64, None) == -1 and b'view 2' in lib.sucre_last_error()
     # round 5: independent images in one launch per iteration
     assert lib.sucre_batch_bytes(0) == 0 and lib.sucre_batch_bytes(3) % 256 == 0 and lib.sucre_batch_bytes(100) >= 1600
     two = (C.c_void_p * 2)(256, 512)

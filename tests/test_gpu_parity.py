@@ -814,6 +814,20 @@ def test_pack_view_records_of_any_size_and_alignment():
         assert np.array_equal(rec[0:2 * n:2].view(np.float32), depth.cpu().numpy()), (H, W, shift)
         assert np.array_equal(rec[1:2 * n:2], c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)), (H, W, shift)
         assert rec[2 * n] == 0 and rec[2 * n + 1] == 0, 'nothing is written past the image'
+    # sucre_pack_views: many views of one size per launch (sixteen to a launch: 37 views = three launches), one of them on odd addresses
+    H, W, nv = 207, 333, 37
+    n = H * W
+    depths = [torch.rand(n + 4, generator=g).cuda()[(1 if k == 5 else 0):][:n] for k in range(nv)]
+    rgbs = [torch.randint(0, 256, (3 * n + 4,), dtype=torch.uint8, generator=g).cuda()[(1 if k == 5 else 0):][:3 * n] for k in range(nv)]
+    outs = [torch.zeros(2 * n + 2, dtype=torch.int32, device='cuda') for _ in range(nv)]
+    arr = lambda ts: (C.c_void_p * nv)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.sucre_pack_views(arr(depths), arr(rgbs), arr(outs), nv, H, W, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    for k in range(nv):
+        rec = outs[k].cpu().numpy().view(np.uint32)
+        c = rgbs[k].cpu().numpy().astype(np.uint32).reshape(n, 3)
+        assert np.array_equal(rec[0:2 * n:2].view(np.float32), depths[k].cpu().numpy()), k
+        assert np.array_equal(rec[1:2 * n:2], c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)) and rec[2 * n] == 0, k
 
 
 def test_pixel_quotients_on_the_integer_boundaries():
