@@ -77,6 +77,11 @@ constexpr bool kExactJAdam = SUCRE_EXACT_J_ADAM != 0;
 // that hour), but the closed-form trajectories of the fixtures then leave the reference's: parameters 2.7e-4 away within 50
 // iterations where the reference's own two runs differ by 1.7e-5 (tests/test_gpu_parity.py
 // test_light_model_closed_form_vs_reference_golden, four tests red with either fold) -- this mode keeps the reference's exact I.
+#ifdef SUCRE_EXP_LIGHT_VECTOR_BASES   // (A/B: the strip's bases as the compiler holds them, not forced into scalar registers)
+constexpr bool kExpLightVectorBases = true;
+#else
+constexpr bool kExpLightVectorBases = false;
+#endif
 #ifndef SUCRE_LIGHT_FOLD1
 #define SUCRE_LIGHT_FOLD1 0
 #endif

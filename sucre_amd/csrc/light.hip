@@ -395,10 +395,10 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             if (strip >= (uint32_t)n_strips) continue;
         }
         const StripMeta sm = meta[strip];
-        const uint32_t n = __builtin_amdgcn_readfirstlane(sm.levels), nch = (n + 3u) >> 2;
+        const uint32_t n = kExpLightVectorBases ? sm.levels : __builtin_amdgcn_readfirstlane(sm.levels), nch = (n + 3u) >> 2;
         // wave-uniform bases, held in scalar registers: the loads below are base + 32-bit lane offset (with per-lane 64-bit
         // pointers the address arithmetic was 7 vector instructions per observation)
-        const uint64_t lvoff = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sm.lvoff >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)sm.lvoff);
+        const uint64_t lvoff = kExpLightVectorBases ? sm.lvoff : ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(sm.lvoff >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)sm.lvoff);
         const uint8_t *sobs = comp + lvoff * (uint64_t)level_bytes(0);
         const uint8_t *sext = ext + lvoff * (uint64_t)kExtLevelBytes;
         const uint8_t *sext2 = kBoth ? ext2 + lvoff * (uint64_t)kExtLevelBytes : nullptr;
