@@ -8,7 +8,9 @@ set -u
 TAG=${1:-r06}
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
-bash tools/profile.sh $TAG jparam jparam_inflight2 closed light light_closed u16mm_4k shared4 jparam_batch32 closed_batch32 \
+# (SKIP_PROFILE=1: the bench lines only -- e.g. once more after the profiles have been committed, so that every line's
+# `profile_frac` / `traffic` come from this round's files)
+[ -n "${SKIP_PROFILE:-}" ] || bash tools/profile.sh $TAG jparam jparam_inflight2 closed light light_closed u16mm_4k shared4 jparam_batch32 closed_batch32 \
      jparam_f32plain jparam_f32z26 jparam_deep jparam_deep_f32z26 > $OUT/profile.log 2>&1
 run() { name=$1; shift; python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
 run default
