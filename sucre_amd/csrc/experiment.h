@@ -82,6 +82,11 @@ constexpr bool kExpLightVectorBases = true;
 #else
 constexpr bool kExpLightVectorBases = false;
 #endif
+#ifdef SUCRE_EXP_LIGHT_LOAD_Z   // (A/B: the J-parameter light kernel loads the stored ranges, as until round 6, instead of forming ||cP||)
+constexpr bool kExpLightLoadZ = true;
+#else
+constexpr bool kExpLightLoadZ = false;
+#endif
 #ifndef SUCRE_LIGHT_FOLD1
 #define SUCRE_LIGHT_FOLD1 0
 #endif

@@ -217,7 +217,10 @@ __device__ __forceinline__ ColourChunk load_colour_chunk(const uint8_t *sext2, u
 // J as a parameter: 356 -> 341 us per iteration at config 2).  The closed-form kernel reads every chunk twice, a strip
 // apart: its first read stays a plain load (with both reads non-temporal it was 4 % slower: what the caches still hold
 // of the strip serves the second read).
-template <bool kLastUse = true>
+// kNoZ (round 6, the J-parameter light kernel): the chunk's ranges are NOT loaded -- 16 of a lane's 76 bytes per chunk; the kernel
+// forms ||cP|| from the camera point it loads anyway (zz then carries the point's z coordinate, whose being non-zero marks a real
+// observation: it is the depth, and an empty slot's planes are zeros).
+template <bool kLastUse = true, bool kNoZ = false>
 __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, const uint8_t *sext, uint32_t g, uint32_t r, int lane) {
     const uint8_t *ch = sobs + (size_t)g * (kGroupLv * level_bytes(0));
     const float *ex = reinterpret_cast<const float *>(sext + (size_t)g * (kGroupLv * kExtLevelBytes));
@@ -232,12 +235,14 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
         typedef float f4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u3 __attribute__((ext_vector_type(3)));
         auto ld4 = [](const void *p) { return kLastUse ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p); };
-        const f4 z4 = ld4(ch + lane * 16);
+        f4 z4;
+        if (!kNoZ) z4 = ld4(ch + lane * 16);
         const u3 cw = kLastUse ? __builtin_nontemporal_load(reinterpret_cast<const u3 *>(ch + 4 * kStripPx * kGroupLv + 12 * lane))
                                : *reinterpret_cast<const u3 *>(ch + 4 * kStripPx * kGroupLv + 12 * lane);
         const f4 x4 = ld4(ex + lane * 4);
         const f4 y4 = ld4(ex + kStripPx * kGroupLv + lane * 4);
         const f4 w4 = ld4(ex + 2 * kStripPx * kGroupLv + lane * 4);
+        if (kNoZ) z4 = w4;
         c = LightChunk{{z4.x, z4.y, z4.z, z4.w}, {x4.x, x4.y, x4.z, x4.w}, {y4.x, y4.y, y4.z, y4.w}, {w4.x, w4.y, w4.z, w4.w},
                        {cw.x, cw.y, cw.z}};
     } else {
@@ -247,10 +252,10 @@ __device__ __forceinline__ LightChunk load_light_chunk(const uint8_t *sobs, cons
         for (int j = 0; j < kGroupLv; ++j) {
             const bool has = (uint32_t)j < r;
             const uint32_t i = lane * r + (has ? j : 0);
-            c.zz[j] = has ? reinterpret_cast<const float *>(ch)[i] : 0.0f;
             c.xx[j] = has ? ex[i] : 0.0f;
             c.yy[j] = has ? ex[kStripPx * r + i] : 0.0f;
             c.ww[j] = has ? ex[2 * kStripPx * r + i] : 0.0f;
+            c.zz[j] = kNoZ ? c.ww[j] : has ? reinterpret_cast<const float *>(ch)[i] : 0.0f;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) c.cc[pl] |= (has ? (uint32_t)cb[pl * kStripPx * r + i] : 0u) << (8 * j);
         }
@@ -485,7 +490,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
         // the caches would find none of it).
         auto chunk_at = [&](uint32_t i) { return kClosed ? nch - 1u - i : i; };
         auto levels_of = [&](uint32_t g) { return min((uint32_t)kGroupLv, n - g * kGroupLv); };
-        auto load_at = [&](uint32_t i) { return load_light_chunk(sobs, sext, chunk_at(i), levels_of(chunk_at(i)), lane); };
+        // The J-parameter kernel on uint8 colours leaves the ranges in HBM and forms ||cP|| itself (v_sqrt_f32, 1 ulp: this mode is held
+        // to a tolerance; the closed-form trajectories are not touched -- they amplify a last-bit change of one range, see the
+        // k/255 fold in experiment.h): 21 % fewer bytes for a kernel that waits for its loads, three FMAs and a square root more.
+        constexpr bool kNoZ = !kClosed && !kColour && !kBoth && !kExpLightLoadZ;
+        auto load_at = [&](uint32_t i) { return load_light_chunk<true, kNoZ>(sobs, sext, chunk_at(i), levels_of(chunk_at(i)), lane); };
         // one chunk: four levels of this lane's pixel
         auto grad_chunk = [&](const LightChunk &kk, uint32_t gi) {
             ColourChunk fc;
@@ -496,11 +505,11 @@ __global__ __launch_bounds__(256) void light_grad_kernel(const uint8_t *__restri
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (!(kk.zz[j] > 0.0f)) continue;  // padding slot
+                if (kNoZ ? kk.zz[j] == 0.0f : !(kk.zz[j] > 0.0f)) continue;  // padding slot
                 const float cP[3] = {kk.xx[j], kk.yy[j], kk.ww[j]};
                 LightObs o;
                 if (kColour) { o.l = 1.0f; o.z = kk.zz[j]; }
-                else o = light_obs(cP, kk.zz[j], R, tl, M);
+                else o = light_obs(cP, kNoZ ? __builtin_amdgcn_sqrtf(__builtin_fmaf(cP[2], cP[2], __builtin_fmaf(cP[1], cP[1], cP[0] * cP[0]))) : kk.zz[j], R, tl, M);
                 const float l = o.l, z = o.z;
                 float dl = 0.f, dz = 0.f;   // dl = l dL/dl (the factor l rides in the modelled colour l E), dz = dL/dz
 #pragma unroll

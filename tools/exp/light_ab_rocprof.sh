@@ -1,6 +1,8 @@
+# same-box A/B of the light kernels under rocprofv3 (kernel-only durations): the product against other builds of the library
+#   gpurun -- bash tools/exp/light_ab_rocprof.sh name [name ...]     (sucre_amd/libsucre_hip_<name>.so)
 export TMPDIR=/tmp
 for rep in 1 2; do
-for v in product r05 vbases; do
+for v in product "$@"; do
   if [ $v = product ]; then unset SUCRE_HIP_LIB; else export SUCRE_HIP_LIB=$PWD/sucre_amd/libsucre_hip_$v.so; fi
   for m in "" "--use-closed-form"; do
   rm -rf /tmp/lp; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lp -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --images-in-flight 1 --light-model $m > /tmp/lp.log 2>&1
