@@ -3,7 +3,9 @@
 
 A step = one full restoration of one synthetic 1920x1080 image against 65 views (64 neighbours + itself):
 match all views -> min_cover/finalize -> init -> 200 Adam iterations -> export J, with every input already
-resident in HBM.  Consecutive steps are kept in flight two at a time (own HIP stream + own workspace each,
+resident in HBM.  A single-image step matches against the views' plain depth and colour planes (sucre_pack_view records
+pay off when targets share views: a survey step -- configs 3, 4 -- builds them inside the step; --pack-views does so
+for a single image too).  Consecutive steps are kept in flight two at a time (own HIP stream + own workspace each,
 engine.in_flight_slot): the 200 launches of one fit depend on each other, so a second image fills their ramp-up
 and tails; the roofline block times the kernel of one image restored alone.  N>1: one process per GPU (torchrun contract), every rank restores its own image of the scene
 (per-image mode of the reference: no data-path collective, weak scaling); --shared-water adds the one
@@ -70,6 +72,10 @@ def parse():
                         '1 = 640x480, 4 neighbours; 2 = 1920x1080, 64 neighbours (the default workload, the one the metric is '
                         'quoted on); 3 = --batch-images 32; 4 = --shared-water --batch-images 64 (the 512-image scene, 64 images '
                         'per rank, one all-reduce per iteration); 5 = 3840x2160, 256 neighbours, --obs-format u16mm')
+    p.add_argument('--pack-views', action='store_true',
+                   help='single-image steps (configs 1, 2, 5): match against sucre_pack_view records built INSIDE every step, as a survey '
+                        'step does (configs 3, 4), instead of against the plain depth and colour planes -- for one target the records cost '
+                        'eight times what they save')
     p.add_argument('--digest', action='store_true',
                    help='config.J_sha256_per_rank: SHA-256 of the last J every rank produced (per-image mode shards with no '
                         'collective: a rank\'s J must be the bits a 1-GPU run of the same image gives)')
@@ -332,6 +338,11 @@ def main():
     # into its own records (DeviceView.twin), so that slot 1's packing never rewrites records slot 0's match kernel is reading;
     # a survey step (configs 3, 4: many targets sharing views) packs each of the survey's views once, behind a fence.
     pack = [engine.PACKED_VIEWS]   # [0]: pack inside the step (the timed region) / views already packed (the second timed region)
+    # A single-image step matches ONE target against views nobody will meet again: it takes them as they are (plain depth and
+    # colour planes, two gathers per landing pixel) unless --pack-views; the second timed region is the survey's steady state for
+    # the same image (records already built).  plain[0]: the current region matches against plain planes.
+    single = args.batch_images == 1
+    plain = [single and not args.pack_views and engine.PACKED_VIEWS]
     slot_jobs = [jobs] * S
     if args.batch_images == 1 and S > 1:
         slot_jobs = [jobs]
@@ -344,8 +355,11 @@ def main():
                 v.packed_records()
 
     def pack_views(vs):
-        if pack[0]:
+        if pack[0] and not plain[0]:
             engine.repack_views(vs)
+
+    def packed_arg():
+        return False if plain[0] else None   # Restoration.match(packed=...): None = the engine's knob
 
     def pack_survey():
         """One pass of sucre_pack_view over every view of the survey, fenced against all slots (they read the records)."""
@@ -427,7 +441,7 @@ def main():
 
     def restore_batch_on(rs, slot, chunk, record):
         for r, (tgt, views) in zip(rs, chunk):
-            r.match(tgt, views, min_cover=1e-6)
+            r.match(tgt, views, min_cover=1e-6, packed=packed_arg())
             r.fit_init(tgt)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -439,7 +453,7 @@ def main():
         J_out[slot] = [r.J() for r in rs][0]
 
     def restore_on(resto, slot, tgt, views, record):
-        resto.match(tgt, views, min_cover=1e-6)
+        resto.match(tgt, views, min_cover=1e-6, packed=packed_arg())
         resto.fit_init(tgt)
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -490,6 +504,7 @@ def main():
     elapsed_prepacked = None
     if pack[0]:
         pack[0] = False
+        was_plain, plain[0] = plain[0], False
         note(rank, 'second timed region (views already packed)')
         barrier()
         t1 = time.perf_counter()
@@ -502,6 +517,7 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed_prepacked = float(te.item())
         pack[0] = True
+        plain[0] = was_plain
 
     n_obs = resto.n_obs()
     n_fits = len(fit_events)
@@ -551,11 +567,11 @@ def main():
                 else:
                     pack_views(views)
                 m0.record()
-                restos[0].match(tgt, views, min_cover=1e-6)
+                restos[0].match(tgt, views, min_cover=1e-6, packed=packed_arg())
                 m1.record()
                 restos[0].fit_init(tgt)
                 for r, (tg, vs) in list(zip(slots[0], solo_chunk))[1:]:
-                    r.match(tg, vs, min_cover=1e-6)
+                    r.match(tg, vs, min_cover=1e-6, packed=packed_arg())
                     r.fit_init(tg)
                 f0.record()
                 if args.shared_water:
@@ -578,7 +594,7 @@ def main():
         match_ms = sum(a.elapsed_time(b) for a, b in solo_match) / len(solo_match)
         match_ms_each = [a.elapsed_time(b) for a, b in solo_match]
         # sucre_pack_view of all views of ONE image (a survey packs a view once for all its targets: there this is an upper bound)
-        pack_ms = sum(a.elapsed_time(b) for a, b in solo_pack) / len(solo_pack) / (B if args.batch_images == 1 else 1) if pack[0] else None
+        pack_ms = (sum(a.elapsed_time(b) for a, b in solo_pack) / len(solo_pack) / (B if args.batch_images == 1 else 1)) if (pack[0] and not plain[0]) else None
         solo_ms_per_image = sum(a.elapsed_time(b) for a, b in solo_all) / len(solo_all) / B   # pack + match + init + T iterations + export, alone
     else:
         iter_ms, match_ms, match_ms_each, pack_ms, solo_ms_per_image = timed_region_iter_ms, None, None, None, None
@@ -701,11 +717,15 @@ def main():
                        'J_sha256_per_rank': digests,
                        'shared_water_trace_rank0': water_trace[0][0] if isinstance(water_trace[0], tuple) else None,
                        'shared_water_trace_sha256_per_rank': water_trace[0][1] if isinstance(water_trace[0], tuple) else None,
-                       'pack_view_in_timed_region': bool(pack[0]),
+                       'views_in_timed_region': ('plain depth and colour planes, two gathers per landing pixel (one target: building sucre_pack_view records '
+                                                 'for its views costs eight times what they save; --pack-views builds them inside the step)') if plain[0]
+                                                else 'sucre_pack_view records built inside every step' if pack[0] else 'as they are (SUCRE_PACKED_VIEWS=0)',
+                       'pack_view_in_timed_region': bool(pack[0] and not plain[0]),
                        'pack_view_ms_per_image': pack_ms,
-                       'pack_view_note': 'sucre_pack_view ({depth, r, g, b} records of every view) runs INSIDE every timed step since round 6: '
-                                         'per image for single-image steps (its views are new), once per step for a survey step (configs 3, 4: '
-                                         'the targets share the views); value_views_prepacked = the same steps with the records already built',
+                       'pack_view_note': 'a survey step (configs 3, 4: the targets share the views) builds the sucre_pack_view records of the survey\'s views '
+                                         'INSIDE every timed step since round 6; a single-image step matches against the plain planes (or, --pack-views, '
+                                         'builds the records inside the step); value_views_prepacked = the same steps against records already built '
+                                         '(the steady state of a survey)',
                        # the three throughputs of VERDICT round 5 (weak point 5), all in this line: `value` (pack_view inside, images in
                        # flight), the same with every view's records already built, and one image strictly alone (pack_view inside)
                        'value_views_prepacked': (world * args.steps * len(jobs) * W * H / 1e6 / elapsed_prepacked) if elapsed_prepacked else None,

@@ -289,11 +289,15 @@ class Restoration:
         return self.ws[off:off + nbytes].view(dtype)
 
     # -- matching (sfm.py:127-138 + loader.py:78-118) ---------------------------------------------------------
-    def match(self, target: DeviceView, views: list[DeviceView], min_cover: float = 1e-6) -> None:
+    def match(self, target: DeviceView, views: list[DeviceView], min_cover: float = 1e-6, packed: bool | None = None) -> None:
+        """``packed``: neighbour views as ``sucre_pack_view`` records (one gather per landing pixel: -7 % on the match kernel, the
+        records built once per view and cached) or as their plain depth and colour planes (two gathers).  None = the engine knob
+        ``PACKED_VIEWS``.  Records pay off for a survey, whose targets share views; for ONE target, building them (0.36 ms for 65
+        views at 1080p) costs eight times what they save (45 us).  Same match sets, ranges and colours either way."""
         assert 1 <= len(views) <= self.capacity, (len(views), self.capacity)
         self.n_views = len(views)   # the workspace layout is a function of (H, W, n_views) and grows with n_views
         tgt = target.to_struct()
-        packed = PACKED_VIEWS and not self.float_colour   # (float32 colour images keep the two-gather form)
+        packed = (PACKED_VIEWS if packed is None else bool(packed)) and not self.float_colour   # (float32 colour images keep the two-gather form)
         table = (_lib.SucreView * self.n_views)(*[v.to_struct(packed) for v in views])
         if packed:
             with torch.cuda.device(self.device):
