@@ -82,6 +82,11 @@ constexpr bool kExpLightVectorBases = true;
 #else
 constexpr bool kExpLightVectorBases = false;
 #endif
+// light.hip: workgroups of a gradient launch (0: as many as are resident).  Round 6, light + closed form, whose second pass re-reads
+// what the first read (a wave's strip is 83 KB at 65 levels; 4096 waves: 340 MB against the 256 MB memory-side cache): see HISTORY 14.
+#ifndef SUCRE_EXP_LIGHT_GRID
+#define SUCRE_EXP_LIGHT_GRID 0
+#endif
 #ifdef SUCRE_EXP_LIGHT_LOAD_Z   // (A/B: the J-parameter light kernel loads the stored ranges, as until round 6, instead of forming ||cP||)
 constexpr bool kExpLightLoadZ = true;
 #else

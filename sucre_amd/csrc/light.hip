@@ -718,6 +718,7 @@ static int resident_grid(K kernel, const Layout &L) {
         }
         grid = per_device[dev];
     }
+    if (SUCRE_EXP_LIGHT_GRID > 0) grid = SUCRE_EXP_LIGHT_GRID;   // (experiment.h: fewer resident workgroups -- a smaller working set)
     return L.n_blocks < grid ? L.n_blocks : grid;
 }
 

@@ -622,7 +622,7 @@ def test_experiment_variants_compile(tmp_path):
         'tablate1': '-DSUCRE_EXP_NOCOMPUTE -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_PRIO=3 -DSUCRE_EXACT_J_ADAM=1',
         'tablate2': '-DSUCRE_EXP_NOLOAD -DSUCRE_RING=4 -DSUCRE_FIT_WAVES=4 -DSUCRE_DEAL_FIT=64,44,24,14,5 -DSUCRE_DEAL_CLOSED=64,48,32,20',
         'texactdiv': '-DSUCRE_EXACT_DIV=1 -DSUCRE_EXP_WAVE_TIMES -DSUCRE_EXP_MATCH_COUNT_ONLY',
-        'tlight2': '-DSUCRE_EXP_NOLOAD -DSUCRE_LIGHT_FOLD1=1 -DSUCRE_LIGHT_FOLD2=1 -DSUCRE_EXP_LIGHT_VECTOR_BASES -DSUCRE_EXP_LIGHT_LOAD_Z',
+        'tlight2': '-DSUCRE_EXP_NOLOAD -DSUCRE_LIGHT_FOLD1=1 -DSUCRE_LIGHT_FOLD2=1 -DSUCRE_EXP_LIGHT_VECTOR_BASES -DSUCRE_EXP_LIGHT_LOAD_Z -DSUCRE_EXP_LIGHT_GRID=512',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
         'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL -DSUCRE_EXP_SHFL_SUMS',
         'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0 -DSUCRE_MIN_STRIPS=1',
