@@ -735,15 +735,45 @@ __device__ __forceinline__ void water_step(const double *__restrict__ sums, floa
 // The lanes' ten sums -> lane 0 holds the wave's: x_l + x_(l+32), then + (l+16), ... + (l+1) -- the additions of the
 // __shfl_down tree that lane 0 depends on, in its association (the other lanes end with values nobody reads).
 __device__ __forceinline__ void wave_sums(float (&s)[kNumSums]) {
+    if (kExpShflSums || kExpPlainWaveSums) {
 #pragma unroll
-    for (int q = 0; q < kNumSums; ++q) {
-        if (kExpShflSums) {
+        for (int q = 0; q < kNumSums; ++q) {
+            if (kExpShflSums) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
-        } else {
-            s[q] = wave_sum_lane0(s[q]);
+                for (int off = 32; off > 0; off >>= 1) s[q] += __shfl_down(s[q], off, 64);
+            } else {
+                s[q] = wave_sum_lane0(s[q]);
+            }
         }
+        return;
     }
+    // The same ten trees, several to a register (round 6: 38 instructions instead of 80 -- a small image's stream in a batch launch is
+    // a few hundred).  v_permlane32_swap a, b leaves [a.lo | b.lo] and [a.hi | b.hi]: their sum holds x_l + x_(l+32) of quantity q in
+    // its lower half and of quantity q + 5 in its upper one; v_permlane16_swap of two such registers and one addition leaves the
+    // 16-lane sums of FOUR quantities in the four rows of one register; the row shifts then serve all four at once.  Every addition
+    // is the one lane 0's __shfl_down tree makes, operand for operand; the totals come back by v_readlane_b32 (wave-uniform).
+    static_assert(kNumSums == 10, "five pairs");
+    float h[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s[q]), __float_as_uint(s[q + 5]), false, false);
+        h[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);                     // [q | q + 5]
+    }
+    float R[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const float a = h[2 * p], b = h[p < 2 ? 2 * p + 1 : 4];
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        R[p] = __uint_as_float(r[0]) + __uint_as_float(r[1]);                     // rows: [2p, 2p + 1, 2p + 5, 2p + 6]  (p = 2: [4, 4, 9, 9])
+        R[p] += lane_down<8>(R[p]);
+        R[p] += lane_down<4>(R[p]);
+        R[p] += lane_down<2>(R[p]);
+        R[p] += lane_down<1>(R[p]);
+    }
+    auto at = [](float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); };
+    s[0] = at(R[0], 0); s[1] = at(R[0], 16); s[5] = at(R[0], 32); s[6] = at(R[0], 48);
+    s[2] = at(R[1], 0); s[3] = at(R[1], 16); s[7] = at(R[1], 32); s[8] = at(R[1], 48);
+    s[4] = at(R[2], 0); s[9] = at(R[2], 32);
 }
 
 template <bool kFused, bool kStep>

@@ -625,7 +625,7 @@ def test_experiment_variants_compile(tmp_path):
         'tlight2': '-DSUCRE_EXP_NOLOAD -DSUCRE_LIGHT_FOLD1=1 -DSUCRE_LIGHT_FOLD2=1 -DSUCRE_EXP_LIGHT_VECTOR_BASES -DSUCRE_EXP_LIGHT_LOAD_Z -DSUCRE_EXP_LIGHT_GRID=512',
         'tscatter': '-DSUCRE_EXP_WAVE_TIMES',
         'tstorent': '-DSUCRE_STORE_NT=1 -DSUCRE_EXP_STORE_LOCAL -DSUCRE_EXP_SHFL_SUMS',
-        'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0 -DSUCRE_MIN_STRIPS=1',
+        'tbatch': '-DSUCRE_EXP_BATCH=2 -DSUCRE_EXP_NOSTORE -DSUCRE_EXP_BATCH_CHAIN=0 -DSUCRE_MIN_STRIPS=1 -DSUCRE_EXP_PLAIN_WAVE_SUMS',
         'thalf': '-DSUCRE_EXP_HALF_EXPS -DSUCRE_CLOSED_WAVES=5 -DSUCRE_EXP_NO_BATCH_CLOSED -DSUCRE_DEAL_CLOSED=64,48,32,20,10',
     }
     objects = {'texactdiv': 'match', 'tlight1': 'light', 'tlight2': 'light', 'tscatter': 'compact'}   # the source a knob lives in (default: fit)
