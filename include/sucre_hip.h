@@ -349,6 +349,9 @@ int sucre_finalize_matches_ext(void *ws, void *lws, int H, int W, int n_views, d
  * for colours that are not k/255; rgb_dev may be NULL), or both as six planes [6][n], cP first (SUCRE_EXT_POINTS_COLOUR;
  * rgb_dev may be NULL).  This is how a caller-built MatchesData (loader.py:36-53)
  * enters the engine; sucre_export_view_ext returns the planes of view k as (3, H, W), zero where nothing was observed.
+ * With the light model the range of an observation IS the norm of its camera point (sucre.py:53, compute_l_z): the
+ * J-parameter light kernel forms it from the point instead of reading the stored range, and takes a non-zero cP.z (the
+ * depth) as the mark of a real observation.
  */
 int sucre_import_view_ext(void *ws, void *lws, int H, int W, int n_views, int k, const int16_t *u1_dev, const int16_t *v1_dev,
                           const float *z_dev, const uint8_t *rgb_dev, const float *ext_dev, int64_t n, int ext_mode, void *stream);
