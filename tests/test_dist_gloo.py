@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two gloo ranks drive ``dist.fit_shared_water`` with an oracle-backed backend.
+"""N>1 path on CPU: two -- and eight -- gloo ranks drive ``dist.fit_shared_water`` with an oracle-backed backend.
 
 The data-path collective is the one all-reduce of ten float64 sums per iteration; per-image mode has none
 (``shard_images`` only).  Checks: both ranks end with identical water parameters, and the 2-rank result equals
@@ -83,6 +83,38 @@ def test_shared_water_two_ranks_equals_one_process(tmp_path):
     assert helpers.rms_per_channel(be.images[0].J, r0['J']).max() < 1e-6
     assert helpers.rms_per_channel(be.images[1].J, r1['J']).max() < 1e-6
     assert np.abs(be.pstate[:9] - 0.1).max() > 1e-2          # the parameters actually moved
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, lr, w = sdist.init_process_group(backend='gloo')
+    assert (r, w) == (rank, world)
+    mine = sdist.shard_images(list(range(20, 20 + 2 * world)), rank, world)     # two images (seeds) per rank, contiguous
+    assert mine == [20 + 2 * rank, 21 + 2 * rank]
+    be = OracleBackend([make_image(s) for s in mine])
+    sdist.fit_shared_water(be, 6)
+    np.savez(Path(out_dir) / f'rank{rank}.npz', pstate=be.pstate, J0=be.images[0].J, J1=be.images[1].J, total=be.total)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_shared_water_eight_ranks_equals_one_process(tmp_path):
+    """The north star's rank count on the CPU tier: eight gloo ranks, two images each, one all-reduce of ten float64 sums per
+    iteration -- eight identical parameter sets, equal (1e-6) to ONE process holding all sixteen images, every rank's J equal to
+    that process's J of the same image."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(r['pstate'], rs[0]['pstate']) and int(r['total']) == int(rs[0]['total'])
+    be = OracleBackend([make_image(s) for s in range(20, 20 + 2 * world)])
+    sdist.fit_shared_water(be, 6)
+    assert int(rs[0]['total']) == be.total
+    assert np.abs(be.pstate[:9] - rs[0]['pstate'][:9]).max() < 1e-6
+    for rank, r in enumerate(rs):
+        for j, key in enumerate(('J0', 'J1')):
+            assert helpers.rms_per_channel(be.images[2 * rank + j].J, r[key]).max() < 1e-6, (rank, key)
 
 
 def test_shared_water_with_one_image_reduces_to_reference_fit():
